@@ -1,0 +1,149 @@
+/*
+ * schro_oracle.h -- CPU restatement of the Dirac/VC-2 decode pixel path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the CPU number printed next
+ * to the GPU number.  The product path (schroedinger_amd/, include/) never
+ * links, imports or falls back to it.
+ *
+ * Every function restates, in plain C, the algorithm of the reference
+ * (dschleef/schroedinger 1.0.11.1) for one piece of the hot path and cites
+ * the reference file:line it follows.
+ *
+ * Parity status ("how this oracle is pinned"), see also DESIGN.md:
+ *   - arithmetic primitives (16/32-bit wrap points, rounding, saturation):
+ *     pinned kernel-by-kernel against the reference's own C bodies, compiled
+ *     unmodified from /root/reference/schroedinger/schroorc-dist.c into
+ *     oracle/_ref/libschroorc_ref.so (tests/test_oracle_ref_kernels.py);
+ *   - composition (row schedule, clamps, level loop): pinned by re-driving
+ *     those compiled reference kernels in the reference's in-place row
+ *     schedule (oracle/ref_driver.c) and by the reference's own test design
+ *     (testsuite/wavelet_2d.c: forward->inverse perfect reconstruction and a
+ *     scalar column-then-row model built on testsuite/common.c synth());
+ *   - the reference holds NO golden vectors / known-answer data for this
+ *     path, and the full reference library cannot be built
+ *     here without writing stand-ins for liborc, so OBMC composition is
+ *     "parity unpinned by reference output": it is cross-checked by two
+ *     independent formulations only (block scatter here vs per-pixel gather
+ *     in tests/ and on the GPU).
+ */
+#ifndef SCHRO_ORACLE_H
+#define SCHRO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Wavelet filter indices, schroedinger/schrobitstream.h:124-132 */
+enum {
+  ORACLE_WAVELET_DESLAURIERS_DUBUC_9_7 = 0,
+  ORACLE_WAVELET_LE_GALL_5_3 = 1,
+  ORACLE_WAVELET_DESLAURIERS_DUBUC_13_7 = 2,
+  ORACLE_WAVELET_HAAR_0 = 3,
+  ORACLE_WAVELET_HAAR_1 = 4,
+  ORACLE_WAVELET_FIDELITY = 5,
+  ORACLE_WAVELET_DAUBECHIES_9_7 = 6
+};
+
+/* ---- wavelet (oracle_wavelet.c) ---------------------------------------- */
+
+/* One level, in place, on a strided view {data, stride bytes, width, height}.
+ * bpp = 2 (s16) or 4 (s32).  Restates schro_wavelet_inverse_transform_2d
+ * (schrowaveletorc.c:121-188) with dest == src. Returns 0, or -1 on bad args. */
+int oracle_iiwt_2d (void *data, int stride, int width, int height,
+    int filter, int bpp);
+
+/* Forward twin, schro_wavelet_transform_2d (schrowaveletorc.c:60-117).
+ * Test-vector generator only. */
+int oracle_iwt_2d (void *data, int stride, int width, int height,
+    int filter, int bpp);
+
+/* Level loop of one component, schro_decoder_inverse_iwt_transform
+ * (schrodecoder.c:1831-1848): level = depth-1 .. 0 on the view
+ * {width>>level, height>>level, stride<<level}. */
+int oracle_inverse_iwt_component (void *data, int stride, int iwt_width,
+    int iwt_height, int depth, int filter, int bpp);
+
+/* Forward level loop (encoder order, level 0 .. depth-1). */
+int oracle_forward_iwt_component (void *data, int stride, int iwt_width,
+    int iwt_height, int depth, int filter, int bpp);
+
+/* ---- frame ops (oracle_frame.c) ---------------------------------------- */
+
+/* An "upsampled reference component": four u8 planes (integer, h-half,
+ * v-half, hv-half) of width x height, each surrounded by an `ext`-pixel apron,
+ * as schro_frame_new_and_alloc_full(..., extension=32, upsampled=TRUE) lays
+ * out one component (schroframe.c:60-191).  plane[i] points at pixel (0,0)
+ * of plane i; rows are `stride` bytes apart. */
+typedef struct {
+  uint8_t *plane[4];
+  int stride;
+  int width;
+  int height;
+  int ext;
+  uint8_t *alloc;
+} OracleUpComp;
+
+OracleUpComp *oracle_upcomp_new (int width, int height, int ext);
+void oracle_upcomp_free (OracleUpComp * c);
+/* copy a width x height u8 picture into plane 0 */
+void oracle_upcomp_set_plane0 (OracleUpComp * c, const uint8_t * src,
+    int src_stride);
+/* schro_frame_mc_edgeextend on plane 0 (schroframe.c:1940-1997) */
+void oracle_upcomp_edgeextend (OracleUpComp * c);
+/* schro_upsampled_frame_upsample for this component (schroframe.c:2000-2030);
+ * plane 0 must already be edge-extended. */
+void oracle_upcomp_upsample (OracleUpComp * c);
+/* copy plane i (in-picture part only) out to dst */
+void oracle_upcomp_get_plane (const OracleUpComp * c, int i, uint8_t * dst,
+    int dst_stride);
+/* raw read incl. apron, for the apron-equivalence test */
+int oracle_upcomp_get (const OracleUpComp * c, int i, int x, int y);
+
+/* intra path: out_u8 = sat_u8 (s16/s32 + 128), cropped to out dims;
+ * schro_frame_convert -> convert_u8_s16 (schrovirtframe.c:1689-1697,
+ * orc_offsetconvert_u8_s16 schroorc.orc:504-521). */
+void oracle_convert_u8_from_signed (uint8_t * dst, int dst_stride,
+    const void *src, int src_stride, int bpp, int width, int height);
+
+/* ---- OBMC (oracle_motion.c) -------------------------------------------- */
+
+/* Mirrors SchroMotionVector (schromotion.h:20-37), 20 bytes:
+ *   flags bits 0-1 pred_mode, bit 2 using_global, bits 3-4 split, 8-15 scan;
+ *   v[] = dx[0],dx[1],dy[0],dy[1]   or   dc[0],dc[1],dc[2]. */
+typedef struct {
+  uint32_t flags;
+  uint32_t metric;
+  uint32_t chroma_metric;
+  int16_t v[4];
+} OracleMotionVector;
+
+typedef struct {
+  int x_num_blocks, y_num_blocks;
+  int xblen_luma, yblen_luma, xbsep_luma, ybsep_luma;
+  int mv_precision;
+  int picture_weight_bits, picture_weight_1, picture_weight_2;
+  int chroma_h_shift, chroma_v_shift;
+} OracleMotionParams;
+
+/* schro_motion_render_u8 for ONE component k (schromotion8.c:700-929),
+ * add == TRUE branch: block scatter into the s16 accumulator `acc`
+ * (width x height, acc_stride bytes), interior blocks through the five
+ * run-time Orc programs (schromotion8.c:15-167), edge blocks through
+ * predict_block + accumulate_slow, then
+ * out = sat_u8 (residual + ((acc + 32) >> 6)) (orc_rrshift6_add_s16_2d /
+ * _s32_2d, schroorc.orc:636-661).  ref2 may be NULL when no block uses it. */
+int oracle_motion_render_u8 (const OracleMotionVector * mvs,
+    const OracleMotionParams * p, int k,
+    const OracleUpComp * ref1, const OracleUpComp * ref2,
+    const void *residual, int res_stride, int res_bpp,
+    int16_t * acc, int acc_stride,
+    uint8_t * out, int out_stride, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+"""ctypes binding of oracle/libschro_oracle.so (the CPU checker).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+_REFDRV = None
+_REFORC = None
+
+
+def build_oracle():
+    """(Re)build the oracle; also _ref/ when /root/reference is present."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "libschro_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        vp, i = C.c_void_p, C.c_int
+        for name in ("oracle_iiwt_2d", "oracle_iwt_2d"):
+            getattr(L, name).argtypes = [vp, i, i, i, i, i]
+            getattr(L, name).restype = i
+        for name in ("oracle_inverse_iwt_component", "oracle_forward_iwt_component"):
+            getattr(L, name).argtypes = [vp, i, i, i, i, i, i]
+            getattr(L, name).restype = i
+        L.oracle_upcomp_new.argtypes = [i, i, i]
+        L.oracle_upcomp_new.restype = vp
+        L.oracle_upcomp_free.argtypes = [vp]
+        L.oracle_upcomp_set_plane0.argtypes = [vp, vp, i]
+        L.oracle_upcomp_edgeextend.argtypes = [vp]
+        L.oracle_upcomp_upsample.argtypes = [vp]
+        L.oracle_upcomp_get_plane.argtypes = [vp, i, vp, i]
+        L.oracle_upcomp_get.argtypes = [vp, i, i, i]
+        L.oracle_upcomp_get.restype = i
+        L.oracle_convert_u8_from_signed.argtypes = [vp, i, vp, i, i, i, i]
+        L.oracle_motion_render_u8.argtypes = [vp, vp, i, vp, vp, vp, i, i, vp, i, vp, i, i, i]
+        L.oracle_motion_render_u8.restype = i
+        _LIB = L
+    return _LIB
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libschro_refdrv.so"))
+
+
+def refdrv():
+    global _REFDRV
+    if _REFDRV is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libschro_refdrv.so"))
+        L.refdrv_iiwt_2d.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.refdrv_iiwt_2d.restype = C.c_int
+        _REFDRV = L
+    return _REFDRV
+
+
+def reforc():
+    """The reference's own kernels (schroorc-dist.c compiled unmodified)."""
+    global _REFORC
+    if _REFORC is None:
+        _REFORC = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libschroorc_ref.so"))
+    return _REFORC
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _bpp(a):
+    assert a.dtype in (np.int16, np.int32)
+    return a.dtype.itemsize
+
+
+# ---- wavelet ---------------------------------------------------------------
+
+def iiwt_2d(a, filt):
+    """One inverse level, returns a new array."""
+    a = np.ascontiguousarray(a).copy()
+    h, w = a.shape
+    r = lib().oracle_iiwt_2d(_ptr(a), a.strides[0], w, h, filt, _bpp(a))
+    assert r == 0
+    return a
+
+
+def iwt_2d(a, filt):
+    a = np.ascontiguousarray(a).copy()
+    h, w = a.shape
+    r = lib().oracle_iwt_2d(_ptr(a), a.strides[0], w, h, filt, _bpp(a))
+    assert r == 0
+    return a
+
+
+def inverse_iwt(a, depth, filt):
+    a = np.ascontiguousarray(a).copy()
+    h, w = a.shape
+    r = lib().oracle_inverse_iwt_component(_ptr(a), a.strides[0], w, h, depth, filt, _bpp(a))
+    assert r == 0
+    return a
+
+
+def forward_iwt(a, depth, filt):
+    a = np.ascontiguousarray(a).copy()
+    h, w = a.shape
+    r = lib().oracle_forward_iwt_component(_ptr(a), a.strides[0], w, h, depth, filt, _bpp(a))
+    assert r == 0
+    return a
+
+
+def refdrv_iiwt_2d(a, filt):
+    a = np.ascontiguousarray(a).copy()
+    h, w = a.shape
+    r = refdrv().refdrv_iiwt_2d(_ptr(a), a.strides[0], w, h, filt, _bpp(a))
+    assert r == 0
+    return a
+
+
+# ---- frames ----------------------------------------------------------------
+
+class UpComp:
+    """One component of an upsampled reference (4 planes + 32-px aprons)."""
+
+    def __init__(self, pic, ext=32, upsample=True):
+        pic = np.ascontiguousarray(pic, dtype=np.uint8)
+        self.h, self.w = pic.shape
+        self.ext = ext
+        self.c = lib().oracle_upcomp_new(self.w, self.h, ext)
+        lib().oracle_upcomp_set_plane0(self.c, _ptr(pic), pic.strides[0])
+        lib().oracle_upcomp_edgeextend(self.c)
+        if upsample:
+            lib().oracle_upcomp_upsample(self.c)
+
+    def plane(self, i):
+        out = np.empty((self.h, self.w), np.uint8)
+        lib().oracle_upcomp_get_plane(self.c, i, _ptr(out), out.strides[0])
+        return out
+
+    def get(self, i, x, y):
+        return lib().oracle_upcomp_get(self.c, i, x, y)
+
+    def __del__(self):
+        try:
+            lib().oracle_upcomp_free(self.c)
+        except Exception:
+            pass
+
+
+def convert_u8(src, width, height):
+    src = np.ascontiguousarray(src)
+    out = np.empty((height, width), np.uint8)
+    lib().oracle_convert_u8_from_signed(_ptr(out), out.strides[0], _ptr(src), src.strides[0],
+                                        _bpp(src), width, height)
+    return out
+
+
+MV_DTYPE = np.dtype([("flags", "<u4"), ("metric", "<u4"), ("chroma_metric", "<u4"),
+                     ("v", "<i2", (4,))])
+assert MV_DTYPE.itemsize == 20
+
+
+class MotionParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "x_num_blocks", "y_num_blocks", "xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma",
+        "mv_precision", "picture_weight_bits", "picture_weight_1", "picture_weight_2",
+        "chroma_h_shift", "chroma_v_shift")]
+
+
+def motion_render(mvs, params, k, ref1, ref2, residual, width, height):
+    """schro_motion_render_u8 (add=TRUE) for component k -> u8 (height, width)."""
+    mvs = np.ascontiguousarray(mvs)
+    assert mvs.dtype == MV_DTYPE
+    residual = np.ascontiguousarray(residual)
+    acc = np.zeros((height, width), np.int16)
+    out = np.zeros((height, width), np.uint8)
+    r = lib().oracle_motion_render_u8(
+        _ptr(mvs), C.byref(params), k, ref1.c, ref2.c if ref2 is not None else None,
+        _ptr(residual), residual.strides[0], _bpp(residual),
+        _ptr(acc), acc.strides[0], _ptr(out), out.strides[0], width, height)
+    assert r == 0
+    return out
