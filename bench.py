@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s of the Dirac/VC-2 decode pixel path on MI355X.
+
+Workload (BASELINE.json configs[3], the 2160p configuration the metric is
+quoted on; it fits one GPU): synthetic 3840x2160 4:2:0 inter pictures,
+3-level Deslauriers-Dubuc (9,7) inverse wavelet on s16 coefficients (Y,U,V),
+12x12/8x8 OBMC at quarter-pel from two references with the residual add and
+u8 clamp fused, plus the half-pel upsampling of both references.
+
+One "step" = one batch of --frames pictures through that path, everything
+resident in HBM.  Frames shard across GPUs (one process per GPU, no data-path
+collective): weak scaling, value = pictures * 3840*2160 / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  The roofline block is the dominant kernel's
+algorithmic bytes / its HIP-event time, measured during the timed steps; the
+cpu_baseline block is the CPU oracle (a port of the reference algorithm, see
+oracle/) timed on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402  (synthetic input generators shared with tests/)
+
+W, H, DEPTH, FILTER = 3840, 2160, 3, 0
+XBLEN, XBSEP, PREC = 12, 8, 2
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def coeff_plane(h, w, seed):
+    """Synthetic s16 coefficients in the reference's in-place sub-band layout:
+    small values in the detail bands, larger ones in the depth-3 LL band."""
+    v = synth.lcg(h * w, seed).astype(np.int32).reshape(h, w)
+    c = (v & 0x3f) - 32
+    ll = ((v >> 6) & 0x3ff) - 512
+    c[0::8, : w // 8] = ll[0::8, : w // 8]
+    return c.astype(np.int16)
+
+
+class Workload:
+    def __init__(self, ctx, frames, seed):
+        import schroedinger_amd as sa
+        self.ctx, self.frames = ctx, frames
+        self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
+        dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+        self.dims = dims
+        # two references (planar u8) + their half-pel images
+        self.ref_np = [[synth.picture_u8(h, w, seed=seed + 100 + 10 * r + k) for k, (h, w) in
+                        enumerate(dims)] for r in range(2)]
+        self.ref = [[ctx.upload(p) for p in comps] for comps in self.ref_np]
+        self.hp = [[ctx.plane(2 * h, 2 * w, np.uint8) for (h, w) in dims] for _ in range(2)]
+        self.up_pairs = [(self.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
+        self.iwt_pairs, self.obmc_jobs = [], []
+        self.coeff_np, self.mv_np, self.out = [], [], []
+        base = {}
+        for f in range(frames):
+            mv = synth.motion_field(self.P["x_num_blocks"], self.P["y_num_blocks"], 64,
+                                    seed=seed + 2 + f)
+            d_mv = ctx.upload_bytes(mv)
+            self.mv_np.append(mv)
+            co_f, out_f = [], []
+            for k, (h, w) in enumerate(dims):
+                key = (k, f % 4)        # 4 distinct coefficient sets, uploaded to distinct buffers
+                if key not in base:
+                    base[key] = coeff_plane(h, w, seed + 7 * f + k)
+                co = base[key]
+                d_co = ctx.upload(co)
+                d_res = ctx.plane(h, w, np.int16)
+                out = ctx.plane(h, w, np.uint8)
+                self.iwt_pairs.append((d_co, d_res))
+                self.obmc_jobs.append(sa.obmc_plane(d_mv, self.P, k, self.hp[0][k], self.hp[1][k],
+                                                    d_res, out))
+                co_f.append(co)
+                out_f.append(out)
+            self.coeff_np.append(co_f)
+            self.out.append(out_f)
+
+    def step(self):
+        c = self.ctx
+        c.upsample_batch(self.up_pairs)
+        c.iiwt_batch(self.iwt_pairs, DEPTH, FILTER)
+        c.obmc_batch(self.obmc_jobs)
+
+
+def cpu_baseline(wl, cores):
+    """The oracle on `cores` pictures (one per thread, the reference's own
+    picture-level parallelism), also used to check the GPU output of frame 0."""
+    import oracle_lib as O      # cpu_baseline leg only
+    O.lib()
+    ups = [[O.UpComp(p, upsample=False) for p in comps] for comps in wl.ref_np]
+    results = [None] * cores
+
+    def one(i):
+        f = i % wl.frames
+        outs = []
+        for k, (h, w) in enumerate(wl.dims):
+            res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
+            outs.append(O.motion_render(wl.mv_np[f], O.MotionParams(**wl.P), k, ups[0][k], ups[1][k],
+                                        res, w, h))
+        results[i] = outs
+
+    t0 = time.perf_counter()
+    for comps in ups:                      # reference upsampling, once per reference
+        ths = [threading.Thread(target=lambda u=u: O.lib().oracle_upcomp_upsample(u.c)) for u in comps]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    ths = [threading.Thread(target=one, args=(i,)) for i in range(cores)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    ok = all(np.array_equal(wl.out[0][k].download(), results[0][k]) for k in range(3))
+    return cores * W * H / dt / 1e6, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import schroedinger_amd as sa
+    if sa.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    ctx = sa.Context(local_rank % sa.device_count())
+    wl = Workload(ctx, args.frames, seed=1 + 1000 * rank)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    if rank == 0:
+        pictures = args.frames * world * args.steps
+        value = pictures * W * H / dt / 1e6
+        # dominant kernel = the class with the largest summed event time
+        dom = max(prof, key=lambda k: prof[k][0])
+        samples = args.frames * (W * H * 3 // 2)            # 4:2:0 samples per launch
+        alg_bytes = {
+            "iiwt_finest": 4 * samples,                     # 2 B read + 2 B written per sample
+            "iiwt_coarse": 4 * (samples // 4),
+            "obmc": int((2 + 1 + 1.6) * samples) + 20 * args.frames * wl.P["x_num_blocks"]
+                    * wl.P["y_num_blocks"],                 # residual + out + ~1.6 refs/px + MVs
+            "upsample": 2 * (W * H * 3 // 2) * 5,           # 1 B read + 4 B written, two refs
+            "convert": 3 * samples,
+        }
+        kernels = {}
+        for k, (ms, n) in prof.items():
+            if n:
+                avg = ms / n
+                kernels[k] = {"avg_ms": round(avg, 4), "launches": n,
+                              "alg_GBs": round(alg_bytes[k] / (avg * 1e-3) / 1e9, 1)}
+        d_avg = prof[dom][0] / max(prof[dom][1], 1)
+        achieved = alg_bytes[dom] / (d_avg * 1e-3) / 1e9
+        out = {
+            "metric": "Mpix/s IIWT+OBMC decode, 2160p s16",
+            "value": round(value, 1), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "s16", "data": "synthetic",
+            "config": {"workload": "2160p 4:2:0 inter pictures: 3-level DD(9,7) IIWT s16 + "
+                       "half-pel upsample of 2 refs + 12x12/8x8 quarter-pel OBMC + add/clamp",
+                       "frames_per_step_per_gpu": args.frames, "width": W, "height": H,
+                       "sharding": "pictures across GPUs, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(d_avg, 4)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = args.cpu_cores or min(8, os.cpu_count() or 1)
+            v, ok = cpu_baseline(wl, cores)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpix/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": "%d pictures (one per thread) of the same workload + the "
+                                   "two reference upsamples, oracle/ C port, gcc -O3" % cores}
+            out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
+        print(json.dumps(out))
+        if out.get("parity", "").startswith("MISMATCH"):
+            sys.exit(1)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,307 @@
+/*
+ * schro_hip.h -- C ABI of libschro_hip.so, the MI355X (gfx950) execution
+ * domain for the Dirac/VC-2 decode pixel path:
+ *
+ *     inverse lifting wavelet (7 filters, s16/s32)  ->  reference half-pel
+ *     upsampling  ->  OBMC prediction + residual add + u8 clamp
+ *
+ * It occupies the slot the reference reserves for a GPU back end
+ * (schroedinger/schrocuda.h:8-16, schrogpuframe.h:13-31, called from the
+ * stage bodies schrodecoder.c:1697-2141), but produces the CPU path's bits:
+ * every entry point is bit-exact to the reference's Orc/C implementation.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *   1. "plane" layer  -- batched kernel launches over device pointers.  This
+ *      is what a host that already owns device memory binds (and what
+ *      bench.py times).
+ *   2. "frame" layer  -- SchroFrame-shaped structs and the stage-level calls
+ *      a patched schrodecoder.c makes (INTEGRATION.md shows the patch).
+ *
+ * Error convention.  The reference has no return codes at this boundary:
+ * device errors are SCHRO_ASSERT -> abort (schrogpuframe.c:249-253).  Here
+ * every call returns 0 on success or a negative SCHRO_HIP_E* code and
+ * records a message (schro_hip_last_error); schro_hip_set_abort_on_error(1)
+ * restores the reference's abort behaviour.  All calls are synchronous with
+ * respect to the context's stream only when they say so; the frame layer
+ * returns after the work is complete, as the reference's stage scheduler
+ * expects (schroasync-pthread.c:320-328).
+ *
+ * Threading: one SchroHipContext per exec-domain thread (the reference
+ * creates exactly one such thread per GPU domain,
+ * schroasync-pthread.c:362-390).  A context is not thread-safe.
+ */
+#ifndef SCHRO_HIP_H
+#define SCHRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCHRO_HIP_OK 0
+#define SCHRO_HIP_EINVAL (-1)   /* bad argument (what SCHRO_ASSERT would trap) */
+#define SCHRO_HIP_EDEVICE (-2)  /* HIP runtime error */
+#define SCHRO_HIP_ENOMEM (-3)
+#define SCHRO_HIP_EUNSUPPORTED (-4)
+
+/* schroedinger/schrodomain.h:30-36 -- ids for the new domain */
+#define SCHRO_EXEC_DOMAIN_HIP 0x0004
+#define SCHRO_MEMORY_DOMAIN_HIP 0x0008
+
+/* SchroFrameFormat bits, schroedinger/schroframe.h:16-54 */
+#define SCHRO_HIP_FORMAT_DEPTH(f) ((f) & 0xc)
+#define SCHRO_HIP_FORMAT_DEPTH_U8 0x00
+#define SCHRO_HIP_FORMAT_DEPTH_S16 0x04
+#define SCHRO_HIP_FORMAT_DEPTH_S32 0x08
+#define SCHRO_HIP_FORMAT_H_SHIFT(f) ((f) & 0x1)
+#define SCHRO_HIP_FORMAT_V_SHIFT(f) (((f) >> 1) & 0x1)
+
+typedef struct SchroHipContext SchroHipContext;
+
+/* ---- context / memory domain -------------------------------------------- */
+
+/* replaces schro_cuda_init (schrocuda.h:8) + schro_memory_domain_new_cuda
+ * (schrocuda.h:9): binds `device`, creates the stream and the size-keyed
+ * device allocation cache (schrodomain.c:58-137 semantics: freed blocks are
+ * kept and handed back to the next request of the same size). */
+SchroHipContext *schro_hip_context_new (int device);
+void schro_hip_context_free (SchroHipContext * ctx);
+int schro_hip_device_count (void);
+const char *schro_hip_last_error (void);
+void schro_hip_set_abort_on_error (int enable);
+
+/* SchroMemoryDomain.alloc / .free (schrodomain.h:18-22) */
+void *schro_hip_domain_alloc (SchroHipContext * ctx, size_t size);
+int schro_hip_domain_free (SchroHipContext * ctx, void *ptr);
+/* bytes currently held by the domain (in use + cached) */
+size_t schro_hip_domain_bytes (SchroHipContext * ctx);
+
+/* host<->device copies on the context stream; *_sync wait for completion.
+ * 2-D copies move `height` rows of `row_bytes`. */
+int schro_hip_upload_2d (SchroHipContext * ctx, void *dst, int dst_stride,
+    const void *src, int src_stride, int row_bytes, int height);
+int schro_hip_download_2d (SchroHipContext * ctx, void *dst, int dst_stride,
+    const void *src, int src_stride, int row_bytes, int height);
+int schro_hip_memset (SchroHipContext * ctx, void *dst, int value,
+    size_t bytes);
+int schro_hip_synchronize (SchroHipContext * ctx);
+/* the context's hipStream_t, for hosts that enqueue their own work or events */
+void *schro_hip_stream (SchroHipContext * ctx);
+
+/* HIP-event timing of everything enqueued between begin and end on the
+ * context stream; schro_hip_timer_end synchronises and returns milliseconds
+ * (< 0 on error). */
+int schro_hip_timer_begin (SchroHipContext * ctx);
+float schro_hip_timer_end (SchroHipContext * ctx);
+
+/* Per-kernel HIP-event profiling.  When enabled, every kernel launch of the
+ * plane layer is bracketed by an event pair on the context stream;
+ * schro_hip_profile_read synchronises and returns the summed elapsed time and
+ * the number of launches of one kernel class since the last reset.  bench.py
+ * uses this for the roofline figure of the dominant kernel. */
+#define SCHRO_HIP_KERNEL_IIWT_FINEST 0  /* level-0 launch of the inverse wavelet */
+#define SCHRO_HIP_KERNEL_IIWT_COARSE 1  /* levels >= 1 */
+#define SCHRO_HIP_KERNEL_UPSAMPLE 2
+#define SCHRO_HIP_KERNEL_OBMC 3
+#define SCHRO_HIP_KERNEL_CONVERT 4
+#define SCHRO_HIP_KERNEL_CLASSES 5
+int schro_hip_profile_enable (SchroHipContext * ctx, int enable);
+int schro_hip_profile_reset (SchroHipContext * ctx);
+int schro_hip_profile_read (SchroHipContext * ctx, int kernel_class,
+    double *total_ms, int *launches);
+
+/* ---- plane layer: batched launches --------------------------------------- */
+
+/* One component of one picture for the inverse wavelet.
+ * Replaces the level loop schro_decoder_inverse_iwt_transform
+ * (schrodecoder.c:1809-1853) / schro_gpuframe_inverse_iwt_transform
+ * (schrogpuframe.c:399-478).  `src` holds the coefficients in the reference's
+ * in-place sub-band layout (schroparams.c:319-352: level view
+ * {w>>l, h>>l, stride<<l}; even rows = [LL|HL], odd rows = [LH|HH]);
+ * `dst` receives the iwt_width x iwt_height result.  src and dst must not
+ * overlap (the transform is tiled, not in place); src is left untouched. */
+typedef struct {
+  const void *src;
+  int src_stride;               /* bytes */
+  void *dst;
+  int dst_stride;               /* bytes */
+  int width;                    /* iwt_{luma,chroma}_width  */
+  int height;                   /* iwt_{luma,chroma}_height */
+} SchroHipIwtPlane;
+
+/* depth levels, Dirac filter index 0..6 (schrobitstream.h:124-132),
+ * bpp 2 (s16) or 4 (s32).  width/height must be multiples of 1<<depth.
+ * Enqueues `depth` launches (coarse to fine), each covering all planes. */
+int schro_hip_iiwt_batch (SchroHipContext * ctx,
+    const SchroHipIwtPlane * planes, int nplanes, int depth, int filter,
+    int bpp);
+
+/* intra pictures: dst_u8 = sat_u8 (src + 128), cropped to width x height;
+ * replaces schro_frame_convert (ref_output_frame, frame)
+ * (schrodecoder.c:1788-1790) / schro_gpuframe_convert. */
+typedef struct {
+  const void *src;
+  int src_stride;
+  uint8_t *dst;
+  int dst_stride;
+  int width;
+  int height;
+} SchroHipConvertPlane;
+
+int schro_hip_convert_u8_batch (SchroHipContext * ctx,
+    const SchroHipConvertPlane * planes, int nplanes, int bpp);
+
+/* Half-pel upsampling of one u8 component; replaces
+ * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /
+ * schro_upsampled_gpuframe_upsample.  Device layout of an upsampled
+ * component is ONE interleaved image HP of 2*width x 2*height bytes:
+ *   HP[2y][2x] = integer pel, HP[2y][2x+1] = h-half, HP[2y+1][2x] = v-half,
+ *   HP[2y+1][2x+1] = hv-half  (the reference's planes 0,1,2,3).
+ * No aprons are stored: the OBMC kernel clamps the half-pel coordinate to
+ * [0, 2w-2] x [0, 2h-2], which is what the reference's 32-pixel aprons
+ * materialise. */
+typedef struct {
+  const uint8_t *src;
+  int src_stride;
+  uint8_t *dst;
+  int dst_stride;               /* bytes, >= 2*width */
+  int width;
+  int height;
+} SchroHipUpsamplePlane;
+
+int schro_hip_upsample_batch (SchroHipContext * ctx,
+    const SchroHipUpsamplePlane * planes, int nplanes);
+
+/* OBMC prediction + residual add + clamp for one component of one picture;
+ * replaces schro_motion_render (..., add=TRUE, output_frame)
+ * (schromotion.c:95 -> schro_motion_render_u8 schromotion8.c:700-929).
+ *
+ * mvs: DEVICE copy of the picture's SchroMotionVector array
+ *      (schromotion.h:20-37, 20-byte records, x_num_blocks*y_num_blocks).
+ * Block geometry is the LUMA one; the kernel derives chroma geometry from
+ * chroma_h_shift/chroma_v_shift when component > 0 exactly as
+ * schromotion8.c:730-758 does.
+ * ref1/ref2: mv_precision == 0 -> plain u8 planes (width x height);
+ *            mv_precision >= 1 -> interleaved half-pel images (see above).
+ *            ref2 may be NULL when no block uses it. */
+typedef struct {
+  const void *mvs;
+  int x_num_blocks, y_num_blocks;
+  int xblen_luma, yblen_luma, xbsep_luma, ybsep_luma;
+  int mv_precision;
+  int picture_weight_bits, picture_weight_1, picture_weight_2;
+  int chroma_h_shift, chroma_v_shift;
+  int component;                /* 0,1,2: selects dc[k] and chroma scaling */
+  const uint8_t *ref1;
+  int ref1_stride;
+  const uint8_t *ref2;
+  int ref2_stride;
+  const void *residual;         /* s16 or s32 plane at picture coordinates */
+  int residual_stride;
+  int residual_bpp;             /* 2 or 4 */
+  uint8_t *out;
+  int out_stride;
+  int width;                    /* component picture size */
+  int height;
+} SchroHipObmcPlane;
+
+int schro_hip_obmc_batch (SchroHipContext * ctx,
+    const SchroHipObmcPlane * planes, int nplanes);
+
+/* ---- frame layer: the reference's stage boundary ------------------------- */
+
+/* Field-for-field SchroFrameData (schroframe.h:58-67) */
+typedef struct {
+  int format;
+  void *data;
+  int stride;
+  int width;
+  int height;
+  int length;
+  int h_shift;
+  int v_shift;
+} SchroHipFrameData;
+
+/* The part of SchroFrame (schroframe.h:69-94) this boundary reads.  Device
+ * frames come from schro_hip_frame_new_and_alloc; host frames are views the
+ * caller fills from its SchroFrame. */
+typedef struct {
+  int refcount;
+  SchroHipContext *domain;      /* NULL: host memory */
+  void *regions[3];
+  int format;
+  int width;
+  int height;
+  SchroHipFrameData components[3];
+  int extension;
+  int is_upsampled;             /* device: components hold half-pel images */
+  int upsample_done;
+  void *priv;                   /* device: the integer-pel source frame of an upsampled frame */
+} SchroHipFrame;
+
+/* schro_frame_new_and_alloc (schroframe.c:60-191) on the device domain:
+ * planar Y,U,V, stride = round-up-64 (width * bytes); upsampled == 1
+ * allocates 2w x 2h half-pel images per component. */
+SchroHipFrame *schro_hip_frame_new_and_alloc (SchroHipContext * ctx,
+    int format, int width, int height, int upsampled);
+SchroHipFrame *schro_hip_frame_ref (SchroHipFrame * frame);
+void schro_hip_frame_unref (SchroHipFrame * frame);
+
+/* schro_frame_to_gpu / schro_gpuframe_to_cpu (schrogpuframe.h:17-18):
+ * whole-frame copies, all three components, synchronous on return. */
+int schro_frame_to_hip (SchroHipFrame * dest, const SchroHipFrame * src);
+int schro_hipframe_to_cpu (SchroHipFrame * dest, const SchroHipFrame * src);
+
+/* The SchroParams fields read at this boundary (schroparams.h:31-74) */
+typedef struct {
+  int wavelet_filter_index;
+  int transform_depth;
+  int iwt_luma_width, iwt_luma_height;
+  int iwt_chroma_width, iwt_chroma_height;
+  int num_refs;
+  int xblen_luma, yblen_luma, xbsep_luma, ybsep_luma;
+  int mv_precision;
+  int picture_weight_bits, picture_weight_1, picture_weight_2;
+  int x_num_blocks, y_num_blocks;
+  int have_global_motion;
+} SchroHipParams;
+
+/* schro_frame_inverse_iwt_transform_cuda (schrocuda.h:13-14) replacement:
+ * upload transform_frame (host) or use it in place (device), run the
+ * multi-level inverse transform into `frame` (device, iwt-padded size). */
+int schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
+    const SchroHipFrame * transform_frame, const SchroHipParams * params);
+
+/* schro_upsampled_gpuframe_upsample (schrogpuframe.h:27) replacement:
+ * dest (device, is_upsampled) <- half-pel images of src (device u8). */
+int schro_upsampled_hipframe_upsample (SchroHipFrame * dest,
+    const SchroHipFrame * src);
+
+/* SchroMotion (schromotion.h:53-86) as read by schro_motion_render */
+typedef struct {
+  const SchroHipFrame *src1;    /* device; plain u8 if mv_precision==0 else upsampled */
+  const SchroHipFrame *src2;    /* may be NULL */
+  const void *motion_vectors;   /* HOST SchroMotionVector array */
+  const SchroHipParams *params;
+} SchroHipMotion;
+
+/* schro_motion_render (motion, dest, addframe, add=TRUE, output_frame)
+ * (schromotion.h:100) replacement.  addframe: device s16/s32 residual
+ * (picture->frame), output_frame: device u8.  Global motion is not
+ * supported (the reference routes it to a different renderer,
+ * schromotion.c:113-118) -> SCHRO_HIP_EUNSUPPORTED. */
+int schro_motion_render_hip (const SchroHipMotion * motion,
+    const SchroHipFrame * addframe, SchroHipFrame * output_frame);
+
+/* schro_gpuframe_convert (schrogpuframe.h:20) replacement for the two
+ * conversions the decode path performs: s16/s32 -> u8 (+128, clamp, crop)
+ * and u8 -> u8 copy. */
+int schro_hipframe_convert (SchroHipFrame * dest, const SchroHipFrame * src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""schroedinger_amd -- MI355X (gfx950) execution domain for the Dirac/VC-2 decode
+pixel path (inverse wavelet -> half-pel upsample -> OBMC + residual add).
+
+The product is libschro_hip.so (C ABI: include/schro_hip.h; kernels:
+schroedinger_amd/csrc/*.hip).  This package is only the thin Python view of
+that ABI used by tests/ and bench.py: device planes, batched launches and the
+SchroFrame-shaped stage calls.  No CPU fallback exists: every operator calls
+the HIP library or raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SchroHipError, check  # noqa: F401
+
+# SchroFrameFormat values, schroedinger/schroframe.h:22-35
+FORMAT_U8_444, FORMAT_U8_422, FORMAT_U8_420 = 0x00, 0x01, 0x03
+FORMAT_S16_444, FORMAT_S16_422, FORMAT_S16_420 = 0x04, 0x05, 0x07
+FORMAT_S32_444, FORMAT_S32_422, FORMAT_S32_420 = 0x08, 0x09, 0x0b
+
+# SchroMotionVector, schroedinger/schromotion.h:20-37 (20 bytes)
+MV_DTYPE = np.dtype([("flags", "<u4"), ("metric", "<u4"), ("chroma_metric", "<u4"),
+                     ("v", "<i2", (4,))])
+
+
+def device_count():
+    return _lib.load().schro_hip_device_count()
+
+
+class DevicePlane:
+    """A 2-D array in the context's memory domain."""
+
+    def __init__(self, ctx, height, width, dtype, stride=None):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.height, self.width = int(height), int(width)
+        row = self.width * self.dtype.itemsize
+        self.stride = int(stride) if stride else (row + 63) // 64 * 64
+        self.nbytes = self.stride * self.height
+        self.ptr = ctx.alloc(self.nbytes)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.shape == (self.height, self.width), (a.shape, self.height, self.width)
+        check(self.ctx.lib.schro_hip_upload_2d(
+            self.ctx.h, self.ptr, self.stride, a.ctypes.data_as(C.c_void_p), a.strides[0],
+            self.width * self.dtype.itemsize, self.height))
+        return self
+
+    def download(self):
+        out = np.empty((self.height, self.width), self.dtype)
+        check(self.ctx.lib.schro_hip_download_2d(
+            self.ctx.h, out.ctypes.data_as(C.c_void_p), out.strides[0], self.ptr, self.stride,
+            self.width * self.dtype.itemsize, self.height))
+        return out
+
+    def fill(self, byte):
+        check(self.ctx.lib.schro_hip_memset(self.ctx.h, self.ptr, byte, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One exec-domain context: device, stream, memory domain."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.h = self.lib.schro_hip_context_new(device)
+        if not self.h:
+            raise SchroHipError("cannot create context on device %d: %s" % (
+                device, self.lib.schro_hip_last_error().decode()))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.schro_hip_context_free(self.h)
+            self.h = None
+
+    def alloc(self, nbytes):
+        p = self.lib.schro_hip_domain_alloc(self.h, nbytes)
+        if not p:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        return p
+
+    def free(self, ptr):
+        check(self.lib.schro_hip_domain_free(self.h, ptr))
+
+    def domain_bytes(self):
+        return self.lib.schro_hip_domain_bytes(self.h)
+
+    def synchronize(self):
+        check(self.lib.schro_hip_synchronize(self.h))
+
+    def timer_begin(self):
+        check(self.lib.schro_hip_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = self.lib.schro_hip_timer_end(self.h)
+        if ms < 0:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        return ms
+
+    KERNEL_CLASSES = ("iiwt_finest", "iiwt_coarse", "upsample", "obmc", "convert")
+
+    def profile_enable(self, on=True):
+        check(self.lib.schro_hip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.schro_hip_profile_reset(self.h))
+
+    def profile_read(self):
+        """{kernel class: (total_ms, launches)} from the per-launch HIP events."""
+        out = {}
+        for k, name in enumerate(self.KERNEL_CLASSES):
+            ms, n = C.c_double(), C.c_int()
+            check(self.lib.schro_hip_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def plane(self, height, width, dtype, stride=None):
+        return DevicePlane(self, height, width, dtype, stride)
+
+    def upload(self, a, stride=None):
+        a = np.ascontiguousarray(a)
+        return DevicePlane(self, a.shape[0], a.shape[1], a.dtype, stride).upload(a)
+
+    def upload_bytes(self, a):
+        """1-D blob (e.g. a SchroMotionVector array) -> device pointer."""
+        raw = np.ascontiguousarray(a).view(np.uint8).reshape(1, -1)
+        return DevicePlane(self, 1, raw.shape[1], np.uint8).upload(raw)
+
+    # ---- batched plane-level launches (asynchronous on the context stream) ----
+
+    def iiwt_batch(self, pairs, depth, filt):
+        """pairs: [(src DevicePlane, dst DevicePlane)], all s16 or all s32."""
+        n = len(pairs)
+        arr = (_lib.IwtPlane * n)()
+        bpp = pairs[0][0].dtype.itemsize
+        for k, (s, d) in enumerate(pairs):
+            assert s.dtype == d.dtype and s.dtype.itemsize == bpp
+            arr[k] = _lib.IwtPlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height)
+        check(self.lib.schro_hip_iiwt_batch(self.h, arr, n, depth, filt, bpp))
+
+    def convert_u8_batch(self, pairs):
+        n = len(pairs)
+        arr = (_lib.ConvertPlane * n)()
+        bpp = pairs[0][0].dtype.itemsize
+        for k, (s, d) in enumerate(pairs):
+            arr[k] = _lib.ConvertPlane(s.ptr, s.stride, d.ptr, d.stride, d.width, d.height)
+        check(self.lib.schro_hip_convert_u8_batch(self.h, arr, n, bpp))
+
+    def upsample_batch(self, pairs):
+        """pairs: [(src u8 plane h x w, dst u8 plane 2h x 2w)]."""
+        n = len(pairs)
+        arr = (_lib.UpsamplePlane * n)()
+        for k, (s, d) in enumerate(pairs):
+            assert d.height == 2 * s.height and d.width == 2 * s.width
+            arr[k] = _lib.UpsamplePlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height)
+        check(self.lib.schro_hip_upsample_batch(self.h, arr, n))
+
+    def obmc_batch(self, planes):
+        n = len(planes)
+        arr = (_lib.ObmcPlane * n)(*planes)
+        check(self.lib.schro_hip_obmc_batch(self.h, arr, n))
+
+
+def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
+    """Fill a SchroHipObmcPlane.  params: dict with the SchroParams motion fields
+    plus chroma_h_shift / chroma_v_shift; mvs: DevicePlane holding the records."""
+    p = _lib.ObmcPlane()
+    p.mvs = mvs.ptr
+    for name in ("x_num_blocks", "y_num_blocks", "xblen_luma", "yblen_luma", "xbsep_luma",
+                 "ybsep_luma", "mv_precision", "picture_weight_bits", "picture_weight_1",
+                 "picture_weight_2", "chroma_h_shift", "chroma_v_shift"):
+        setattr(p, name, int(params[name]))
+    p.component = component
+    p.ref1, p.ref1_stride = ref1.ptr, ref1.stride
+    if ref2 is not None:
+        p.ref2, p.ref2_stride = ref2.ptr, ref2.stride
+    p.residual, p.residual_stride = residual.ptr, residual.stride
+    p.residual_bpp = residual.dtype.itemsize
+    p.out, p.out_stride = out.ptr, out.stride
+    p.width, p.height = out.width, out.height
+    return p

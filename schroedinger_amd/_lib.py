@@ -1,0 +1,181 @@
+"""ctypes binding of libschro_hip.so -- the declarations of include/schro_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded,
+importing the operators raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libschro_hip.so")
+
+# every extern "C" symbol include/schro_hip.h declares
+EXPORTED_SYMBOLS = [
+    "schro_hip_context_new", "schro_hip_context_free", "schro_hip_device_count",
+    "schro_hip_last_error", "schro_hip_set_abort_on_error",
+    "schro_hip_domain_alloc", "schro_hip_domain_free", "schro_hip_domain_bytes",
+    "schro_hip_upload_2d", "schro_hip_download_2d", "schro_hip_memset",
+    "schro_hip_synchronize", "schro_hip_stream",
+    "schro_hip_timer_begin", "schro_hip_timer_end",
+    "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
+    "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
+    "schro_hip_obmc_batch",
+    "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
+    "schro_frame_to_hip", "schro_hipframe_to_cpu",
+    "schro_frame_inverse_iwt_transform_hip", "schro_upsampled_hipframe_upsample",
+    "schro_motion_render_hip", "schro_hipframe_convert",
+]
+
+
+class IwtPlane(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
+                ("dst", C.c_void_p), ("dst_stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class ConvertPlane(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
+                ("dst", C.c_void_p), ("dst_stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class UpsamplePlane(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
+                ("dst", C.c_void_p), ("dst_stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class ObmcPlane(C.Structure):
+    _fields_ = [("mvs", C.c_void_p),
+                ("x_num_blocks", C.c_int), ("y_num_blocks", C.c_int),
+                ("xblen_luma", C.c_int), ("yblen_luma", C.c_int),
+                ("xbsep_luma", C.c_int), ("ybsep_luma", C.c_int),
+                ("mv_precision", C.c_int),
+                ("picture_weight_bits", C.c_int), ("picture_weight_1", C.c_int),
+                ("picture_weight_2", C.c_int),
+                ("chroma_h_shift", C.c_int), ("chroma_v_shift", C.c_int),
+                ("component", C.c_int),
+                ("ref1", C.c_void_p), ("ref1_stride", C.c_int),
+                ("ref2", C.c_void_p), ("ref2_stride", C.c_int),
+                ("residual", C.c_void_p), ("residual_stride", C.c_int),
+                ("residual_bpp", C.c_int),
+                ("out", C.c_void_p), ("out_stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class FrameData(C.Structure):
+    _fields_ = [("format", C.c_int), ("data", C.c_void_p), ("stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int), ("length", C.c_int),
+                ("h_shift", C.c_int), ("v_shift", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("refcount", C.c_int), ("domain", C.c_void_p),
+                ("regions", C.c_void_p * 3),
+                ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("components", FrameData * 3),
+                ("extension", C.c_int), ("is_upsampled", C.c_int),
+                ("upsample_done", C.c_int), ("priv", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "wavelet_filter_index", "transform_depth",
+        "iwt_luma_width", "iwt_luma_height", "iwt_chroma_width", "iwt_chroma_height",
+        "num_refs", "xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma",
+        "mv_precision", "picture_weight_bits", "picture_weight_1", "picture_weight_2",
+        "x_num_blocks", "y_num_blocks", "have_global_motion")]
+
+
+class Motion(C.Structure):
+    _fields_ = [("src1", C.POINTER(Frame)), ("src2", C.POINTER(Frame)),
+                ("motion_vectors", C.c_void_p), ("params", C.POINTER(Params))]
+
+
+_lib = None
+
+
+def load():
+    """Load libschro_hip.so; raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "schroedinger_amd: %s is missing -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C schroedinger_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.schro_hip_context_new.argtypes = [i]
+    L.schro_hip_context_new.restype = vp
+    L.schro_hip_context_free.argtypes = [vp]
+    L.schro_hip_context_free.restype = None
+    L.schro_hip_device_count.restype = i
+    L.schro_hip_last_error.restype = C.c_char_p
+    L.schro_hip_set_abort_on_error.argtypes = [i]
+    L.schro_hip_domain_alloc.argtypes = [vp, sz]
+    L.schro_hip_domain_alloc.restype = vp
+    L.schro_hip_domain_free.argtypes = [vp, vp]
+    L.schro_hip_domain_free.restype = i
+    L.schro_hip_domain_bytes.argtypes = [vp]
+    L.schro_hip_domain_bytes.restype = sz
+    L.schro_hip_upload_2d.argtypes = [vp, vp, i, vp, i, i, i]
+    L.schro_hip_upload_2d.restype = i
+    L.schro_hip_download_2d.argtypes = [vp, vp, i, vp, i, i, i]
+    L.schro_hip_download_2d.restype = i
+    L.schro_hip_memset.argtypes = [vp, vp, i, sz]
+    L.schro_hip_memset.restype = i
+    L.schro_hip_synchronize.argtypes = [vp]
+    L.schro_hip_synchronize.restype = i
+    L.schro_hip_stream.argtypes = [vp]
+    L.schro_hip_stream.restype = vp
+    L.schro_hip_timer_begin.argtypes = [vp]
+    L.schro_hip_timer_begin.restype = i
+    L.schro_hip_timer_end.argtypes = [vp]
+    L.schro_hip_timer_end.restype = C.c_float
+    L.schro_hip_profile_enable.argtypes = [vp, i]
+    L.schro_hip_profile_enable.restype = i
+    L.schro_hip_profile_reset.argtypes = [vp]
+    L.schro_hip_profile_reset.restype = i
+    L.schro_hip_profile_read.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.schro_hip_profile_read.restype = i
+    L.schro_hip_iiwt_batch.argtypes = [vp, C.POINTER(IwtPlane), i, i, i, i]
+    L.schro_hip_iiwt_batch.restype = i
+    L.schro_hip_convert_u8_batch.argtypes = [vp, C.POINTER(ConvertPlane), i, i]
+    L.schro_hip_convert_u8_batch.restype = i
+    L.schro_hip_upsample_batch.argtypes = [vp, C.POINTER(UpsamplePlane), i]
+    L.schro_hip_upsample_batch.restype = i
+    L.schro_hip_obmc_batch.argtypes = [vp, C.POINTER(ObmcPlane), i]
+    L.schro_hip_obmc_batch.restype = i
+    L.schro_hip_frame_new_and_alloc.argtypes = [vp, i, i, i, i]
+    L.schro_hip_frame_new_and_alloc.restype = C.POINTER(Frame)
+    L.schro_hip_frame_ref.argtypes = [C.POINTER(Frame)]
+    L.schro_hip_frame_ref.restype = C.POINTER(Frame)
+    L.schro_hip_frame_unref.argtypes = [C.POINTER(Frame)]
+    L.schro_hip_frame_unref.restype = None
+    L.schro_frame_to_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_frame_to_hip.restype = i
+    L.schro_hipframe_to_cpu.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_hipframe_to_cpu.restype = i
+    L.schro_frame_inverse_iwt_transform_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
+                                                        C.POINTER(Params)]
+    L.schro_frame_inverse_iwt_transform_hip.restype = i
+    L.schro_upsampled_hipframe_upsample.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_upsampled_hipframe_upsample.restype = i
+    L.schro_motion_render_hip.argtypes = [C.POINTER(Motion), C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_motion_render_hip.restype = i
+    L.schro_hipframe_convert.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_hipframe_convert.restype = i
+    _lib = L
+    return L
+
+
+class SchroHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().schro_hip_last_error()
+        raise SchroHipError("schro_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,920 @@
+// api.cpp -- the C ABI of libschro_hip.so (include/schro_hip.h): context and
+// memory domain, batched plane-level launches, and the SchroFrame-shaped
+// stage boundary.  Host logic only; the kernels are in iiwt.hip,
+// frameops.hip and obmc.hip.
+
+#include "schro_hip_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+namespace schro {
+
+static thread_local char g_err[512] = "";
+static int g_abort_on_error = 0;
+
+int
+set_error (int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (g_err, sizeof (g_err), fmt, ap);
+  va_end (ap);
+  if (g_abort_on_error) {
+    // the reference's convention at this boundary: SCHRO_ASSERT -> abort
+    fprintf (stderr, "schro_hip: %s\n", g_err);
+    abort ();
+  }
+  return code;
+}
+
+int
+push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
+{
+  size_t need = (bytes + 255) & ~(size_t) 255;
+  if (need > ctx->args_size)
+    return set_error (SCHRO_HIP_EINVAL, "job table of %zu bytes exceeds the staging ring", bytes);
+  if (ctx->args_off + need > ctx->args_size) {
+    // wrap: everything enqueued so far must have consumed its table
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+    ctx->args_off = 0;
+  }
+  memcpy (ctx->h_args + ctx->args_off, host, bytes);
+  SCHRO_HIP_CHECK (hipMemcpyAsync (ctx->d_args + ctx->args_off, ctx->h_args + ctx->args_off,
+          bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = ctx->d_args + ctx->args_off;
+  ctx->args_off += need;
+  return 0;
+}
+
+int
+ensure_scratch (SchroHipContext * ctx, size_t bytes)
+{
+  if (bytes <= ctx->scratch_size)
+    return 0;
+  if (ctx->scratch) {
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+    SCHRO_HIP_CHECK (hipFree (ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_size = 0;
+  }
+  SCHRO_HIP_CHECK (hipMalloc (&ctx->scratch, bytes));
+  ctx->scratch_size = bytes;
+  return 0;
+}
+
+ProfileScope::ProfileScope (SchroHipContext * c, int cls):ctx (c), idx (-1)
+{
+  if (!c->profile)
+    return;
+  if (c->ev_used == c->ev_pool.size ()) {
+    if (c->ev_pool.size () >= 16384)
+      return;                   // pool exhausted: stop sampling, keep running
+    SchroHipContext::EvPair p;
+    if (hipEventCreate (&p.a) != hipSuccess)
+      return;
+    if (hipEventCreate (&p.b) != hipSuccess) {
+      (void) hipEventDestroy (p.a);
+      return;
+    }
+    c->ev_pool.push_back (p);
+  }
+  idx = (int) c->ev_used++;
+  c->ev_pool[idx].cls = cls;
+  (void) hipEventRecord (c->ev_pool[idx].a, c->stream);
+}
+
+ProfileScope::~ProfileScope ()
+{
+  if (idx >= 0)
+    (void) hipEventRecord (ctx->ev_pool[idx].b, ctx->stream);
+}
+
+}                               // namespace schro
+
+using namespace schro;
+
+static inline int
+div_up (int a, int b)
+{
+  return (a + b - 1) / b;
+}
+
+static inline size_t
+round_up (size_t a, size_t b)
+{
+  return (a + b - 1) / b * b;
+}
+
+extern "C" {
+
+// ---- context / domain ---------------------------------------------------------
+
+int
+schro_hip_device_count (void)
+{
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+const char *
+schro_hip_last_error (void)
+{
+  return g_err;
+}
+
+void
+schro_hip_set_abort_on_error (int enable)
+{
+  g_abort_on_error = enable;
+}
+
+SchroHipContext *
+schro_hip_context_new (int device)
+{
+  if (hipSetDevice (device) != hipSuccess) {
+    set_error (SCHRO_HIP_EDEVICE, "hipSetDevice(%d) failed", device);
+    return nullptr;
+  }
+  SchroHipContext *ctx = new SchroHipContext ();
+  ctx->device = device;
+  ctx->domain_bytes = 0;
+  ctx->scratch = nullptr;
+  ctx->scratch_size = 0;
+  ctx->args_size = 4u << 20;
+  ctx->args_off = 0;
+  ctx->profile = false;
+  ctx->ev_used = 0;
+  ctx->h_args = nullptr;
+  ctx->d_args = nullptr;
+  bool ok = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking) == hipSuccess
+      && hipEventCreate (&ctx->ev_begin) == hipSuccess
+      && hipEventCreate (&ctx->ev_end) == hipSuccess
+      && hipHostMalloc ((void **) &ctx->h_args, ctx->args_size, hipHostMallocDefault) == hipSuccess
+      && hipMalloc ((void **) &ctx->d_args, ctx->args_size) == hipSuccess;
+  if (!ok) {
+    set_error (SCHRO_HIP_EDEVICE, "context creation failed on device %d: %s", device,
+        hipGetErrorString (hipGetLastError ()));
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+
+void
+schro_hip_context_free (SchroHipContext * ctx)
+{
+  if (!ctx)
+    return;
+  (void) hipSetDevice (ctx->device);
+  (void) hipStreamSynchronize (ctx->stream);
+  for (auto & s : ctx->slots)
+    (void) hipFree (s.ptr);
+  if (ctx->scratch)
+    (void) hipFree (ctx->scratch);
+  if (ctx->d_args)
+    (void) hipFree (ctx->d_args);
+  if (ctx->h_args)
+    (void) hipHostFree (ctx->h_args);
+  for (auto & p : ctx->ev_pool) {
+    (void) hipEventDestroy (p.a);
+    (void) hipEventDestroy (p.b);
+  }
+  (void) hipEventDestroy (ctx->ev_begin);
+  (void) hipEventDestroy (ctx->ev_end);
+  (void) hipStreamDestroy (ctx->stream);
+  delete ctx;
+}
+
+// schro_memory_domain_alloc, schrodomain.c:58-103: reuse a free slot of
+// exactly this size, else allocate a new one; nothing is returned to the
+// device before the domain dies (schrodomain.c:105-137).
+void *
+schro_hip_domain_alloc (SchroHipContext * ctx, size_t size)
+{
+  if (!ctx || size == 0) {
+    set_error (SCHRO_HIP_EINVAL, "domain_alloc: bad arguments");
+    return nullptr;
+  }
+  for (auto & s : ctx->slots) {
+    if (!s.in_use && s.size == size) {
+      s.in_use = true;
+      return s.ptr;
+    }
+  }
+  void *p = nullptr;
+  (void) hipSetDevice (ctx->device);
+  hipError_t e = hipMalloc (&p, size);
+  if (e != hipSuccess) {
+    set_error (SCHRO_HIP_ENOMEM, "hipMalloc(%zu): %s", size, hipGetErrorString (e));
+    return nullptr;
+  }
+  ctx->slots.push_back ({p, size, true});
+  ctx->domain_bytes += size;
+  return p;
+}
+
+int
+schro_hip_domain_free (SchroHipContext * ctx, void *ptr)
+{
+  if (!ctx)
+    return set_error (SCHRO_HIP_EINVAL, "domain_free: no context");
+  for (auto & s : ctx->slots) {
+    if (s.ptr == ptr && s.in_use) {
+      s.in_use = false;
+      return 0;
+    }
+  }
+  return set_error (SCHRO_HIP_EINVAL, "domain_free: %p is not a live block of this domain", ptr);
+}
+
+size_t
+schro_hip_domain_bytes (SchroHipContext * ctx)
+{
+  return ctx ? ctx->domain_bytes : 0;
+}
+
+int
+schro_hip_upload_2d (SchroHipContext * ctx, void *dst, int dst_stride, const void *src,
+    int src_stride, int row_bytes, int height)
+{
+  SCHRO_HIP_REQUIRE (ctx && dst && src && row_bytes > 0 && height > 0, "upload_2d: bad arguments");
+  SCHRO_HIP_CHECK (hipMemcpy2DAsync (dst, dst_stride, src, src_stride, row_bytes, height,
+          hipMemcpyHostToDevice, ctx->stream));
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+int
+schro_hip_download_2d (SchroHipContext * ctx, void *dst, int dst_stride, const void *src,
+    int src_stride, int row_bytes, int height)
+{
+  SCHRO_HIP_REQUIRE (ctx && dst && src && row_bytes > 0 && height > 0, "download_2d: bad arguments");
+  SCHRO_HIP_CHECK (hipMemcpy2DAsync (dst, dst_stride, src, src_stride, row_bytes, height,
+          hipMemcpyDeviceToHost, ctx->stream));
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+int
+schro_hip_memset (SchroHipContext * ctx, void *dst, int value, size_t bytes)
+{
+  SCHRO_HIP_REQUIRE (ctx && dst, "memset: bad arguments");
+  SCHRO_HIP_CHECK (hipMemsetAsync (dst, value, bytes, ctx->stream));
+  return 0;
+}
+
+int
+schro_hip_synchronize (SchroHipContext * ctx)
+{
+  SCHRO_HIP_REQUIRE (ctx, "synchronize: no context");
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+void *
+schro_hip_stream (SchroHipContext * ctx)
+{
+  return ctx ? (void *) ctx->stream : nullptr;
+}
+
+int
+schro_hip_timer_begin (SchroHipContext * ctx)
+{
+  SCHRO_HIP_REQUIRE (ctx, "timer: no context");
+  SCHRO_HIP_CHECK (hipEventRecord (ctx->ev_begin, ctx->stream));
+  return 0;
+}
+
+float
+schro_hip_timer_end (SchroHipContext * ctx)
+{
+  if (!ctx)
+    return -1.f;
+  float ms = -1.f;
+  if (hipEventRecord (ctx->ev_end, ctx->stream) != hipSuccess
+      || hipEventSynchronize (ctx->ev_end) != hipSuccess
+      || hipEventElapsedTime (&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) {
+    set_error (SCHRO_HIP_EDEVICE, "timer_end failed");
+    return -1.f;
+  }
+  return ms;
+}
+
+int
+schro_hip_profile_enable (SchroHipContext * ctx, int enable)
+{
+  SCHRO_HIP_REQUIRE (ctx, "profile: no context");
+  ctx->profile = enable != 0;
+  return 0;
+}
+
+int
+schro_hip_profile_reset (SchroHipContext * ctx)
+{
+  SCHRO_HIP_REQUIRE (ctx, "profile: no context");
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  ctx->ev_used = 0;
+  return 0;
+}
+
+int
+schro_hip_profile_read (SchroHipContext * ctx, int kernel_class, double *total_ms, int *launches)
+{
+  SCHRO_HIP_REQUIRE (ctx && total_ms && launches && kernel_class >= 0
+      && kernel_class < SCHRO_HIP_KERNEL_CLASSES, "profile_read: bad arguments");
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  double sum = 0;
+  int n = 0;
+  for (size_t i = 0; i < ctx->ev_used; i++) {
+    if (ctx->ev_pool[i].cls != kernel_class)
+      continue;
+    float ms = 0;
+    SCHRO_HIP_CHECK (hipEventElapsedTime (&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b));
+    sum += ms;
+    n++;
+  }
+  *total_ms = sum;
+  *launches = n;
+  return 0;
+}
+
+// ---- plane layer ----------------------------------------------------------------
+
+int
+schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes,
+    int depth, int filter, int bpp)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0, "iiwt_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (nplanes <= kMaxJobs, "iiwt_batch: at most %d planes per call", kMaxJobs);
+  SCHRO_HIP_REQUIRE (depth >= 1 && depth <= 6, "iiwt_batch: transform depth %d out of range", depth);
+  SCHRO_HIP_REQUIRE (filter >= 0 && filter <= 6, "iiwt_batch: wavelet filter index %d out of range",
+      filter);
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "iiwt_batch: bpp must be 2 or 4");
+  (void) hipSetDevice (ctx->device);
+
+  // scratch for the intermediate LL images: levels depth-1 .. 1 of every plane
+  std::vector < size_t > scratch_off ((size_t) nplanes * depth, 0);
+  std::vector < int >scratch_stride ((size_t) nplanes * depth, 0);
+  size_t total = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipIwtPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.src && pl.dst, "iiwt_batch: plane %d has a NULL pointer", p);
+    SCHRO_HIP_REQUIRE (pl.width > 0 && pl.height > 0 && pl.width % (1 << depth) == 0
+        && pl.height % (1 << depth) == 0,
+        "iiwt_batch: plane %d size %dx%d is not a multiple of 2^depth", p, pl.width, pl.height);
+    SCHRO_HIP_REQUIRE (pl.src_stride >= pl.width * bpp && pl.dst_stride >= pl.width * bpp,
+        "iiwt_batch: plane %d stride too small", p);
+    {
+      const char *s0 = (const char *) pl.src, *s1 = s0 + (size_t) pl.src_stride * pl.height;
+      const char *d0 = (const char *) pl.dst, *d1 = d0 + (size_t) pl.dst_stride * pl.height;
+      SCHRO_HIP_REQUIRE (s1 <= d0 || d1 <= s0, "iiwt_batch: plane %d src and dst overlap", p);
+    }
+    for (int l = 1; l < depth; l++) {
+      int w = pl.width >> l, h = pl.height >> l;
+      int stride = (int) round_up ((size_t) w * bpp, 64);
+      scratch_off[(size_t) p * depth + l] = total;
+      scratch_stride[(size_t) p * depth + l] = stride;
+      total += round_up ((size_t) stride * h, 256);
+    }
+  }
+  if (total) {
+    int r = ensure_scratch (ctx, total);
+    if (r)
+      return r;
+  }
+
+  int uc, ur;
+  iiwt_tile_geometry (filter, bpp, &uc, &ur);
+  std::vector < IwtJob > jobs (nplanes);
+  for (int level = depth - 1; level >= 0; level--) {
+    int tile_base = 0;
+    for (int p = 0; p < nplanes; p++) {
+      const SchroHipIwtPlane & pl = planes[p];
+      IwtJob & j = jobs[p];
+      int w = pl.width >> level, h = pl.height >> level;
+      // level view of the coefficient frame: {w, h, stride << level}
+      // (schrodecoder.c:1834-1845); sub-band positions schroparams.c:319-352
+      const char *base = (const char *) pl.src;
+      int vstride = pl.src_stride << level;
+      const char *ll = base;
+      int ll_stride = vstride * 2;
+      if (level < depth - 1) {
+        ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + level + 1];
+        ll_stride = scratch_stride[(size_t) p * depth + level + 1];
+      }
+      j.sb[0] = ll;
+      j.sb_stride[0] = ll_stride;
+      j.sb[1] = base + (size_t) (w / 2) * bpp;
+      j.sb_stride[1] = vstride * 2;
+      j.sb[2] = base + vstride;
+      j.sb_stride[2] = vstride * 2;
+      j.sb[3] = base + vstride + (size_t) (w / 2) * bpp;
+      j.sb_stride[3] = vstride * 2;
+      if (level == 0) {
+        j.dst = pl.dst;
+        j.dst_stride = pl.dst_stride;
+      } else {
+        j.dst = (char *) ctx->scratch + scratch_off[(size_t) p * depth + level];
+        j.dst_stride = scratch_stride[(size_t) p * depth + level];
+      }
+      j.w = w;
+      j.h = h;
+      int nc = w / 2, nr = h / 2;
+      j.tiles_x = div_up (nc, uc);
+      j.tile_base = tile_base;
+      tile_base += j.tiles_x * div_up (nr, ur);
+      int vl = 8 / bpp;
+      bool src_al = (nc % vl) == 0 && nc >= vl;
+      for (int s = 0; s < 4; s++)
+        src_al = src_al && (((uintptr_t) j.sb[s] | (uintptr_t) j.sb_stride[s]) & 7) == 0;
+      bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
+      j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
+      j.pad = 0;
+    }
+    void *d_jobs;
+    int r = push_args (ctx, jobs.data (), sizeof (IwtJob) * nplanes, &d_jobs);
+    if (r)
+      return r;
+    {
+      ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
+      r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, nplanes, tile_base, filter, bpp);
+    }
+    if (r)
+      return r;
+  }
+  return 0;
+}
+
+int
+schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * planes,
+    int nplanes, int bpp)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs,
+      "convert_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "convert_batch: bpp must be 2 or 4");
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  convert_tile_geometry (&tw, &th);
+  std::vector < ConvertJob > jobs (nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipConvertPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0,
+        "convert_batch: plane %d invalid", p);
+    ConvertJob & j = jobs[p];
+    j.src = pl.src;
+    j.dst = pl.dst;
+    j.src_stride = pl.src_stride;
+    j.dst_stride = pl.dst_stride;
+    j.w = pl.width;
+    j.h = pl.height;
+    j.tiles_x = div_up (pl.width, tw);
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (pl.height, th);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (ConvertJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
+  return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
+}
+
+int
+schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * planes, int nplanes)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs,
+      "upsample_batch: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  upsample_tile_geometry (&tw, &th);
+  std::vector < UpsampleJob > jobs (nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipUpsamplePlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0
+        && pl.dst_stride >= 2 * pl.width && pl.src_stride >= pl.width,
+        "upsample_batch: plane %d invalid", p);
+    UpsampleJob & j = jobs[p];
+    j.src = pl.src;
+    j.dst = pl.dst;
+    j.src_stride = pl.src_stride;
+    j.dst_stride = pl.dst_stride;
+    j.w = pl.width;
+    j.h = pl.height;
+    j.tiles_x = div_up (pl.width, tw);
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (pl.height, th);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (UpsampleJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_UPSAMPLE);
+  return launch_upsample (ctx->stream, (const UpsampleJob *) d_jobs, nplanes, tile_base);
+}
+
+int
+schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, int nplanes)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs,
+      "obmc_batch: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  obmc_tile_geometry (&tw, &th);
+
+  // one launch per (precision class, simple-weight) group, keeping plane order
+  std::vector < char >done (nplanes, 0);
+  for (int first = 0; first < nplanes; first++) {
+    if (done[first])
+      continue;
+    const int prec = planes[first].mv_precision;
+    const int simple = planes[first].picture_weight_1 == 1 && planes[first].picture_weight_2 == 1
+        && planes[first].picture_weight_bits == 1;
+    std::vector < ObmcJob > jobs;
+    int tile_base = 0;
+    for (int p = first; p < nplanes; p++) {
+      const SchroHipObmcPlane & pl = planes[p];
+      const int psimple = pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1
+          && pl.picture_weight_bits == 1;
+      if (done[p] || pl.mv_precision != prec || psimple != simple)
+        continue;
+      done[p] = 1;
+      SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
+      SCHRO_HIP_REQUIRE (pl.mv_precision >= 0 && pl.mv_precision <= 3,
+          "obmc_batch: mv_precision %d out of range", pl.mv_precision);
+      SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
+      SCHRO_HIP_REQUIRE (pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
+      SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
+          "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
+      ObmcJob j;
+      memset (&j, 0, sizeof (j));
+      const int hs = pl.component ? pl.chroma_h_shift : 0, vs = pl.component ? pl.chroma_v_shift : 0;
+      // schromotion8.c:730-764
+      j.xbsep = pl.xbsep_luma >> hs;
+      j.ybsep = pl.ybsep_luma >> vs;
+      j.xblen = pl.xblen_luma >> hs;
+      j.yblen = pl.yblen_luma >> vs;
+      SCHRO_HIP_REQUIRE (j.xbsep > 0 && j.ybsep > 0 && j.xblen >= j.xbsep && j.yblen >= j.ybsep
+          && j.xblen <= 2 * j.xbsep && j.yblen <= 2 * j.ybsep && j.xblen <= 64 && j.yblen <= 64,
+          "obmc_batch: plane %d block geometry %dx%d sep %dx%d unsupported", p, j.xblen, j.yblen,
+          j.xbsep, j.ybsep);
+      j.xoff = (j.xblen - j.xbsep) / 2;
+      j.yoff = (j.yblen - j.ybsep) / 2;
+      SCHRO_HIP_REQUIRE (pl.width >= j.xblen && pl.height >= j.yblen,
+          "obmc_batch: plane %d smaller than one block", p);
+      j.nbx = pl.x_num_blocks;
+      j.nby = pl.y_num_blocks;
+      SCHRO_HIP_REQUIRE (j.nbx > 0 && j.nby > 0, "obmc_batch: plane %d has no blocks", p);
+      // schromotion8.c:794-797
+      j.max_x_blocks = std::min (j.nbx - 1, (pl.width - j.xoff) / j.xbsep);
+      j.max_y_blocks = std::min (j.nby - 1, (pl.height - j.yoff) / j.ybsep);
+      j.mv_shift_x = hs;
+      j.mv_shift_y = vs;
+      j.prec = pl.mv_precision;
+      j.wbits = pl.picture_weight_bits;
+      j.w1 = pl.picture_weight_1;
+      j.w2 = pl.picture_weight_2;
+      j.comp = pl.component;
+      j.mvs = (const uint8_t *) pl.mvs;
+      j.ref[0] = pl.ref1;
+      j.ref_stride[0] = pl.ref1_stride;
+      j.ref[1] = pl.ref2 ? pl.ref2 : pl.ref1;
+      j.ref_stride[1] = pl.ref2 ? pl.ref2_stride : pl.ref1_stride;
+      j.residual = pl.residual;
+      j.residual_stride = pl.residual_stride;
+      j.res_bpp = pl.residual_bpp;
+      j.out = pl.out;
+      j.out_stride = pl.out_stride;
+      j.w = pl.width;
+      j.h = pl.height;
+      j.tiles_x = div_up (pl.width, tw);
+      j.tile_base = tile_base;
+      tile_base += j.tiles_x * div_up (pl.height, th);
+      jobs.push_back (j);
+    }
+    void *d_jobs;
+    int r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
+    if (r)
+      return r;
+    {
+      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
+      r = launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec,
+          simple);
+    }
+    if (r)
+      return r;
+  }
+  return 0;
+}
+
+// ---- frame layer -----------------------------------------------------------------
+
+static int
+format_bpp (int format)
+{
+  switch (SCHRO_HIP_FORMAT_DEPTH (format)) {
+    case SCHRO_HIP_FORMAT_DEPTH_U8:
+      return 1;
+    case SCHRO_HIP_FORMAT_DEPTH_S16:
+      return 2;
+    case SCHRO_HIP_FORMAT_DEPTH_S32:
+      return 4;
+  }
+  return 0;
+}
+
+SchroHipFrame *
+schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int height,
+    int upsampled)
+{
+  int bpp = format_bpp (format);
+  if (!ctx || !bpp || width <= 0 || height <= 0 || (format & 0x100) || (upsampled && bpp != 1)) {
+    set_error (SCHRO_HIP_EINVAL, "frame_new_and_alloc: bad arguments");
+    return nullptr;
+  }
+  SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+  f->refcount = 1;
+  f->domain = ctx;
+  f->format = format;
+  f->width = width;
+  f->height = height;
+  f->is_upsampled = upsampled;
+  int h_shift = SCHRO_HIP_FORMAT_H_SHIFT (format), v_shift = SCHRO_HIP_FORMAT_V_SHIFT (format);
+  // chroma size rounds up, schroframe.c:95-96
+  int cw = (width + (1 << h_shift) - 1) >> h_shift, ch = (height + (1 << v_shift) - 1) >> v_shift;
+  size_t total = 0;
+  for (int k = 0; k < 3; k++) {
+    SchroHipFrameData *c = &f->components[k];
+    c->format = format;
+    c->width = k ? cw : width;
+    c->height = k ? ch : height;
+    c->h_shift = k ? h_shift : 0;
+    c->v_shift = k ? v_shift : 0;
+    int mul = upsampled ? 2 : 1;
+    c->stride = (int) round_up ((size_t) c->width * mul * bpp, 64);
+    c->length = c->stride * c->height * mul;
+    total += round_up ((size_t) c->length, 256);
+  }
+  void *base = schro_hip_domain_alloc (ctx, total);
+  if (!base) {
+    free (f);
+    return nullptr;
+  }
+  f->regions[0] = base;
+  size_t off = 0;
+  for (int k = 0; k < 3; k++) {
+    f->components[k].data = (char *) base + off;
+    off += round_up ((size_t) f->components[k].length, 256);
+  }
+  return f;
+}
+
+SchroHipFrame *
+schro_hip_frame_ref (SchroHipFrame * frame)
+{
+  if (frame)
+    frame->refcount++;
+  return frame;
+}
+
+void
+schro_hip_frame_unref (SchroHipFrame * frame)
+{
+  if (!frame)
+    return;
+  if (--frame->refcount > 0)
+    return;
+  if (frame->domain && frame->regions[0])
+    schro_hip_domain_free (frame->domain, frame->regions[0]);
+  free (frame);
+}
+
+static int
+copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src,
+    hipMemcpyKind kind)
+{
+  int bpp = format_bpp (src->format);
+  SCHRO_HIP_REQUIRE (bpp && format_bpp (dest->format) == bpp, "frame copy: depth mismatch");
+  (void) hipSetDevice (ctx->device);
+  for (int k = 0; k < 3; k++) {
+    const SchroHipFrameData *s = &src->components[k];
+    SchroHipFrameData *d = &dest->components[k];
+    int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
+    if (w <= 0 || h <= 0)
+      continue;
+    SCHRO_HIP_CHECK (hipMemcpy2DAsync (d->data, d->stride, s->data, s->stride, (size_t) w * bpp, h,
+            kind, ctx->stream));
+  }
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+int
+schro_frame_to_hip (SchroHipFrame * dest, const SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && dest->domain && !src->domain,
+      "frame_to_hip: dest must be a device frame and src a host frame");
+  return copy_frame (dest->domain, dest, src, hipMemcpyHostToDevice);
+}
+
+int
+schro_hipframe_to_cpu (SchroHipFrame * dest, const SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && src->domain && !dest->domain,
+      "hipframe_to_cpu: src must be a device frame and dest a host frame");
+  return copy_frame (src->domain, dest, src, hipMemcpyDeviceToHost);
+}
+
+int
+schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
+    const SchroHipFrame * transform_frame, const SchroHipParams * params)
+{
+  SCHRO_HIP_REQUIRE (frame && transform_frame && params && frame->domain,
+      "inverse_iwt_transform: bad arguments");
+  SchroHipContext *ctx = frame->domain;
+  int bpp = format_bpp (frame->format);
+  SCHRO_HIP_REQUIRE ((bpp == 2 || bpp == 4) && format_bpp (transform_frame->format) == bpp,
+      "inverse_iwt_transform: frames must both be s16 or both s32");
+
+  // host coefficients are staged on the device first (the H2D step of
+  // schro_frame_inverse_iwt_transform_cuda, schrogpuframe.c:584-599)
+  SchroHipFrame *staged = nullptr;
+  const SchroHipFrame *src = transform_frame;
+  if (!transform_frame->domain) {
+    staged = schro_hip_frame_new_and_alloc (ctx, transform_frame->format, transform_frame->width,
+        transform_frame->height, 0);
+    if (!staged)
+      return SCHRO_HIP_ENOMEM;
+    int r = schro_frame_to_hip (staged, transform_frame);
+    if (r) {
+      schro_hip_frame_unref (staged);
+      return r;
+    }
+    src = staged;
+  }
+  SchroHipIwtPlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    planes[k].src = src->components[k].data;
+    planes[k].src_stride = src->components[k].stride;
+    planes[k].dst = frame->components[k].data;
+    planes[k].dst_stride = frame->components[k].stride;
+    planes[k].width = k ? params->iwt_chroma_width : params->iwt_luma_width;
+    planes[k].height = k ? params->iwt_chroma_height : params->iwt_luma_height;
+    if (planes[k].width > frame->components[k].width || planes[k].height > frame->components[k].height
+        || planes[k].width > src->components[k].width || planes[k].height > src->components[k].height) {
+      if (staged)
+        schro_hip_frame_unref (staged);
+      return set_error (SCHRO_HIP_EINVAL, "inverse_iwt_transform: component %d smaller than the iwt size", k);
+    }
+  }
+  int r = schro_hip_iiwt_batch (ctx, planes, 3, params->transform_depth,
+      params->wavelet_filter_index, bpp);
+  if (!r)
+    r = schro_hip_synchronize (ctx);
+  if (staged)
+    schro_hip_frame_unref (staged);
+  return r;
+}
+
+int
+schro_upsampled_hipframe_upsample (SchroHipFrame * dest, const SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain
+      && dest->is_upsampled && !src->is_upsampled && format_bpp (src->format) == 1,
+      "upsampled_hipframe_upsample: bad arguments");
+  if (dest->upsample_done)      // schroframe.c:2006-2009
+    return 0;
+  SchroHipUpsamplePlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    SCHRO_HIP_REQUIRE (dest->components[k].width == src->components[k].width
+        && dest->components[k].height == src->components[k].height,
+        "upsampled_hipframe_upsample: size mismatch");
+    planes[k].src = (const uint8_t *) src->components[k].data;
+    planes[k].src_stride = src->components[k].stride;
+    planes[k].dst = (uint8_t *) dest->components[k].data;
+    planes[k].dst_stride = dest->components[k].stride;
+    planes[k].width = src->components[k].width;
+    planes[k].height = src->components[k].height;
+  }
+  int r = schro_hip_upsample_batch (dest->domain, planes, 3);
+  if (!r)
+    r = schro_hip_synchronize (dest->domain);
+  if (!r)
+    dest->upsample_done = 1;
+  return r;
+}
+
+int
+schro_motion_render_hip (const SchroHipMotion * motion, const SchroHipFrame * addframe,
+    SchroHipFrame * output_frame)
+{
+  SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors && addframe
+      && output_frame && output_frame->domain && addframe->domain == output_frame->domain,
+      "motion_render: bad arguments");
+  const SchroHipParams *p = motion->params;
+  if (p->have_global_motion)    // schromotion.c:113-118 routes this to another renderer
+    return set_error (SCHRO_HIP_EUNSUPPORTED, "motion_render: global motion is not supported");
+  SchroHipContext *ctx = output_frame->domain;
+  const int upsampled = p->mv_precision > 0;
+  SCHRO_HIP_REQUIRE (motion->src1->is_upsampled == upsampled
+      && (!motion->src2 || motion->src2->is_upsampled == upsampled),
+      "motion_render: references must be %s for mv_precision %d",
+      upsampled ? "upsampled frames" : "plain frames", p->mv_precision);
+  if (p->num_refs == 1)         // schromotion8.c:711-713
+    SCHRO_HIP_REQUIRE (p->picture_weight_2 == 1, "motion_render: one reference needs picture_weight_2 == 1");
+
+  // SchroMotionVector array -> device (schrogpumotion.c:68-120 did a repack; the
+  // kernel reads the 20-byte records as they are)
+  size_t mv_bytes = (size_t) 20 * p->x_num_blocks * p->y_num_blocks;
+  void *d_mvs = schro_hip_domain_alloc (ctx, round_up (mv_bytes, 256));
+  if (!d_mvs)
+    return SCHRO_HIP_ENOMEM;
+  (void) hipSetDevice (ctx->device);
+  hipError_t e = hipMemcpyAsync (d_mvs, motion->motion_vectors, mv_bytes, hipMemcpyHostToDevice,
+      ctx->stream);
+  if (e != hipSuccess) {
+    schro_hip_domain_free (ctx, d_mvs);
+    return set_error (SCHRO_HIP_EDEVICE, "motion_render: MV upload: %s", hipGetErrorString (e));
+  }
+  SchroHipObmcPlane planes[3];
+  const int res_bpp = format_bpp (addframe->format);
+  for (int k = 0; k < 3; k++) {
+    SchroHipObmcPlane & pl = planes[k];
+    memset (&pl, 0, sizeof (pl));
+    pl.mvs = d_mvs;
+    pl.x_num_blocks = p->x_num_blocks;
+    pl.y_num_blocks = p->y_num_blocks;
+    pl.xblen_luma = p->xblen_luma;
+    pl.yblen_luma = p->yblen_luma;
+    pl.xbsep_luma = p->xbsep_luma;
+    pl.ybsep_luma = p->ybsep_luma;
+    pl.mv_precision = p->mv_precision;
+    pl.picture_weight_bits = p->picture_weight_bits;
+    pl.picture_weight_1 = p->picture_weight_1;
+    pl.picture_weight_2 = p->picture_weight_2;
+    pl.chroma_h_shift = SCHRO_HIP_FORMAT_H_SHIFT (output_frame->format);
+    pl.chroma_v_shift = SCHRO_HIP_FORMAT_V_SHIFT (output_frame->format);
+    pl.component = k;
+    pl.ref1 = (const uint8_t *) motion->src1->components[k].data;
+    pl.ref1_stride = motion->src1->components[k].stride;
+    if (motion->src2) {
+      pl.ref2 = (const uint8_t *) motion->src2->components[k].data;
+      pl.ref2_stride = motion->src2->components[k].stride;
+    }
+    pl.residual = addframe->components[k].data;
+    pl.residual_stride = addframe->components[k].stride;
+    pl.residual_bpp = res_bpp;
+    pl.out = (uint8_t *) output_frame->components[k].data;
+    pl.out_stride = output_frame->components[k].stride;
+    pl.width = output_frame->components[k].width;
+    pl.height = output_frame->components[k].height;
+  }
+  int r = schro_hip_obmc_batch (ctx, planes, 3);
+  int r2 = schro_hip_synchronize (ctx);
+  schro_hip_domain_free (ctx, d_mvs);
+  return r ? r : r2;
+}
+
+int
+schro_hipframe_convert (SchroHipFrame * dest, const SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain,
+      "hipframe_convert: both frames must live in the same device domain");
+  SchroHipContext *ctx = dest->domain;
+  int sb = format_bpp (src->format), db = format_bpp (dest->format);
+  if (db == 1 && (sb == 2 || sb == 4)) {
+    SchroHipConvertPlane planes[3];
+    for (int k = 0; k < 3; k++) {
+      planes[k].src = src->components[k].data;
+      planes[k].src_stride = src->components[k].stride;
+      planes[k].dst = (uint8_t *) dest->components[k].data;
+      planes[k].dst_stride = dest->components[k].stride;
+      planes[k].width = std::min (dest->components[k].width, src->components[k].width);
+      planes[k].height = std::min (dest->components[k].height, src->components[k].height);
+    }
+    int r = schro_hip_convert_u8_batch (ctx, planes, 3, sb);
+    return r ? r : schro_hip_synchronize (ctx);
+  }
+  if (db == sb) {
+    (void) hipSetDevice (ctx->device);
+    for (int k = 0; k < 3; k++) {
+      int w = std::min (dest->components[k].width, src->components[k].width);
+      int h = std::min (dest->components[k].height, src->components[k].height);
+      SCHRO_HIP_CHECK (hipMemcpy2DAsync (dest->components[k].data, dest->components[k].stride,
+              src->components[k].data, src->components[k].stride, (size_t) w * sb, h,
+              hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return schro_hip_synchronize (ctx);
+  }
+  return set_error (SCHRO_HIP_EUNSUPPORTED, "hipframe_convert: depth %d -> %d is not on the decode path",
+      sb, db);
+}
+
+}                               // extern "C"

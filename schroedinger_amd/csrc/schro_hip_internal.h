@@ -1,0 +1,149 @@
+// schro_hip_internal.h -- shared between the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+#include "schro_hip.h"
+
+namespace schro {
+
+int set_error (int code, const char *fmt, ...);
+
+#define SCHRO_HIP_CHECK(expr)                                                  \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess)                                                      \
+      return schro::set_error (SCHRO_HIP_EDEVICE, "%s:%d: %s -> %s", __FILE__, \
+          __LINE__, #expr, hipGetErrorString (_e));                            \
+  } while (0)
+
+#define SCHRO_HIP_REQUIRE(cond, ...)                                           \
+  do {                                                                         \
+    if (!(cond))                                                               \
+      return schro::set_error (SCHRO_HIP_EINVAL, __VA_ARGS__);                 \
+  } while (0)
+
+// ---- job tables handed to the kernels (device memory, one per launch) ------
+
+// One (plane, level) of the inverse wavelet.
+struct IwtJob {
+  const void *sb[4];            // LL, HL, LH, HH: element (0,0) of each sub-band
+  int sb_stride[4];             // bytes between sub-band rows
+  void *dst;
+  int dst_stride;
+  int w, h;                     // output size of this level (sub-bands are w/2 x h/2)
+  int tiles_x;
+  int tile_base;                // first block id of this job
+  int flags;                    // bit0: all sources 8-byte aligned, bit1: dst 16-byte aligned
+  int pad;
+};
+
+struct ConvertJob {
+  const void *src;
+  uint8_t *dst;
+  int src_stride, dst_stride;
+  int w, h;
+  int tiles_x;
+  int tile_base;
+};
+
+struct UpsampleJob {
+  const uint8_t *src;
+  uint8_t *dst;
+  int src_stride, dst_stride;
+  int w, h;
+  int tiles_x;
+  int tile_base;
+};
+
+struct ObmcJob {
+  const uint8_t *mvs;
+  const uint8_t *ref[2];
+  const void *residual;
+  uint8_t *out;
+  int ref_stride[2];
+  int residual_stride;
+  int out_stride;
+  int w, h;
+  int nbx, nby;                 // x_num_blocks, y_num_blocks
+  int xblen, yblen, xbsep, ybsep, xoff, yoff;   // this component's geometry
+  int max_x_blocks, max_y_blocks;       // interior-block limits (schromotion8.c:794-797)
+  int mv_shift_x, mv_shift_y;   // chroma MV scaling (0 for luma)
+  int prec, wbits, w1, w2;
+  int comp;
+  int res_bpp;
+  int tiles_x;
+  int tile_base;
+};
+
+constexpr int kMaxJobs = 256;
+
+// launchers (one per .hip file)
+int launch_iiwt_level (hipStream_t stream, const IwtJob * d_jobs, int njobs,
+    int total_tiles, int filter, int bpp);
+void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
+    int *useful_row_pairs);
+int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,
+    int total_tiles, int bpp);
+void convert_tile_geometry (int *tw, int *th);
+int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
+    int njobs, int total_tiles);
+void upsample_tile_geometry (int *tw, int *th);
+int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
+    int total_tiles, int prec, int simple_weight);
+void obmc_tile_geometry (int *tw, int *th);
+
+}                               // namespace schro
+
+// ---- the context --------------------------------------------------------------
+
+struct SchroHipContext {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev_begin, ev_end;
+
+  // size-keyed allocation cache (schrodomain.c:58-137 semantics)
+  struct Slot {
+    void *ptr;
+    size_t size;
+    bool in_use;
+  };
+  std::vector < Slot > slots;
+  size_t domain_bytes;
+
+  // ring of pinned-host / device staging for job tables
+  char *h_args;
+  char *d_args;
+  size_t args_size;
+  size_t args_off;
+
+  // optional per-kernel event profiling
+  bool profile;
+  struct EvPair {
+    hipEvent_t a, b;
+    int cls;
+  };
+  std::vector < EvPair > ev_pool;
+  size_t ev_used;
+
+  // grow-only scratch for intermediate LL bands
+  void *scratch;
+  size_t scratch_size;
+};
+
+namespace schro {
+// returns device pointer to a copy of [host, host+bytes) valid for the next launch
+int push_args (SchroHipContext * ctx, const void *host, size_t bytes,
+    void **dev);
+int ensure_scratch (SchroHipContext * ctx, size_t bytes);
+// bracket one launch with an event pair when profiling is on
+struct ProfileScope {
+  SchroHipContext *ctx;
+  int idx;
+  ProfileScope (SchroHipContext * c, int cls);
+  ~ProfileScope ();
+};
+}

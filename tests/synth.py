@@ -1,0 +1,81 @@
+"""Synthetic inputs shared by tests/ and bench.py.
+
+LCG x <- x*1103515245 + 12345 (mod 2^32), value = x >> 16.
+"""
+import numpy as np
+
+MV_DTYPE = np.dtype([("flags", "<u4"), ("metric", "<u4"), ("chroma_metric", "<u4"),
+                     ("v", "<i2", (4,))])
+
+_A = np.uint32(1103515245)
+_C = np.uint32(12345)
+
+
+def lcg(n, seed=1):
+    """n successive LCG outputs (x >> 16, 16 bits each) as uint32."""
+    with np.errstate(over="ignore"):
+        apow = np.cumprod(np.full(n, _A, dtype=np.uint32), dtype=np.uint32)      # a^1..a^n
+        geo = np.concatenate(([np.uint32(1)], apow[:-1]))                        # a^0..a^(n-1)
+        s = np.cumsum(geo, dtype=np.uint32)                                      # sum_{k<n} a^k
+        x = apow * np.uint32(seed) + _C * s
+    return (x >> np.uint32(16)).astype(np.uint32)
+
+
+def image_s(h, w, dtype=np.int16, seed=1):
+    """(v & 0xff) - 128 per sample: legal 8-bit residual-like picture."""
+    v = lcg(h * w, seed)
+    return ((v & 0xff).astype(np.int32) - 128).astype(dtype).reshape(h, w)
+
+
+def full_range(h, w, dtype=np.int16, seed=3):
+    """Uniform full-range samples: pins the wrap semantics (parity only)."""
+    v = lcg(2 * h * w, seed).astype(np.uint64)
+    if np.dtype(dtype) == np.int16:
+        return v[: h * w].astype(np.uint16).view(np.int16).reshape(h, w)
+    lo, hi = v[0::2], v[1::2]
+    return ((hi << np.uint64(16)) | lo).astype(np.uint32).view(np.int32).reshape(h, w)
+
+
+def picture_u8(h, w, seed=5, blur=True):
+    """LCG u8 noise, optionally 3x3 box-blurred (reference-frame-like)."""
+    p = (lcg(h * w, seed) & 0xff).astype(np.int32).reshape(h, w)
+    if blur:
+        q = np.pad(p, 1, mode="edge")
+        p = sum(q[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) // 9
+    return p.astype(np.uint8)
+
+
+def num_blocks(width, height, xbsep, ybsep):
+    """schro_params_calculate_mc_sizes, schroparams.c:165-185."""
+    return 4 * -(-width // (4 * xbsep)), 4 * -(-height // (4 * ybsep))
+
+
+def motion_field(nbx, nby, mv_range=64, seed=2, modes=(0.05, 0.45, 0.15, 0.35), global_bits=False):
+    """pred_mode drawn from `modes`, dx/dy uniform in [-mv_range, mv_range],
+    dc uniform in [-128, 127]; split = 2."""
+    n = nbx * nby
+    r = lcg(6 * n, seed).astype(np.int64).reshape(6, n)
+    u = (r[0] % 1000) / 1000.0
+    cum = np.cumsum(modes)
+    mode = np.searchsorted(cum, u, side="right").clip(0, 3).astype(np.uint32)
+    mv = np.zeros(n, MV_DTYPE)
+    mv["flags"] = mode | (2 << 3)
+    span = 2 * mv_range + 1
+    vec = np.stack([r[1] % span - mv_range, r[2] % span - mv_range,
+                    r[3] % span - mv_range, r[4] % span - mv_range], axis=1).astype(np.int16)
+    dc = np.stack([r[1] % 256 - 128, r[2] % 256 - 128, r[3] % 256 - 128,
+                   np.zeros(n, np.int64)], axis=1).astype(np.int16)
+    mv["v"] = np.where((mode == 0)[:, None], dc, vec)
+    mv["metric"] = r[5].astype(np.uint32)
+    return mv
+
+
+def motion_params(width, height, xblen, xbsep, prec, weights=(1, 1, 1), chroma=(1, 1),
+                  yblen=None, ybsep=None):
+    yblen = xblen if yblen is None else yblen
+    ybsep = xbsep if ybsep is None else ybsep
+    nbx, nby = num_blocks(width, height, xbsep, ybsep)
+    return dict(x_num_blocks=nbx, y_num_blocks=nby, xblen_luma=xblen, yblen_luma=yblen,
+                xbsep_luma=xbsep, ybsep_luma=ybsep, mv_precision=prec,
+                picture_weight_bits=weights[2], picture_weight_1=weights[0],
+                picture_weight_2=weights[1], chroma_h_shift=chroma[0], chroma_v_shift=chroma[1])

@@ -1,0 +1,75 @@
+"""GPU parity: half-pel upsample and s16/s32 -> u8 convert vs the CPU oracle.
+
+Upsample follows testsuite/upsample.c's design (sizes 1..20 squared, all
+planes) with the oracle's exact restatement of schroframe.c as the reference.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_upsample(ctx, pic):
+    h, w = pic.shape
+    src = ctx.upload(pic)
+    dst = ctx.plane(2 * h, 2 * w, np.uint8).fill(0xa5)
+    ctx.upsample_batch([(src, dst)])
+    hp = dst.download()
+    src.free()
+    dst.free()
+    return hp
+
+
+def check_planes(hp, up):
+    assert np.array_equal(hp[0::2, 0::2], up.plane(0))
+    assert np.array_equal(hp[0::2, 1::2], up.plane(1))
+    assert np.array_equal(hp[1::2, 0::2], up.plane(2))
+    assert np.array_equal(hp[1::2, 1::2], up.plane(3))
+
+
+def test_upsample_small_sizes(ctx):
+    for h in list(range(1, 21)) + [33, 40]:
+        for w in (1, 2, 3, 7, 8, 9, 16, 20, 63, 64, 65, 96):
+            pic = synth.picture_u8(h, w, seed=h * 97 + w, blur=False)
+            check_planes(gpu_upsample(ctx, pic), O.UpComp(pic))
+
+
+@pytest.mark.parametrize("h,w", [(240, 320), (240, 160), (1080, 1920), (2160, 3840)])
+def test_upsample_picture_sizes(ctx, h, w):
+    pic = synth.picture_u8(h, w, seed=4)
+    check_planes(gpu_upsample(ctx, pic), O.UpComp(pic))
+
+
+def test_upsample_extremes(ctx):
+    # saturating inputs: checkerboards and steps drive the 8-tap sum past 0..255
+    h, w = 24, 40
+    yy, xx = np.mgrid[0:h, 0:w]
+    for pic in (((yy + xx) & 1) * 255, (xx > 20) * 255, (yy > 11) * 255, np.full((h, w), 255)):
+        pic = pic.astype(np.uint8)
+        check_planes(gpu_upsample(ctx, pic), O.UpComp(pic))
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_convert_crop_and_saturate(ctx, dtype):
+    # iwt-padded 64x48 source, 61x45 picture: crop as schrovirtframe.c:1853 does
+    src_np = synth.full_range(48, 64, dtype, seed=8)
+    src_np[0, :8] = [-129, -128, -127, 0, 126, 127, 128, 32767 if dtype == np.int16 else 2**31 - 1]
+    src = ctx.upload(src_np)
+    dst = ctx.plane(45, 61, np.uint8).fill(7)
+    ctx.convert_u8_batch([(src, dst)])
+    assert np.array_equal(dst.download(), O.convert_u8(src_np, 61, 45))
+    src.free()
+    dst.free()
+
+
+def test_convert_picture_size(ctx):
+    src_np = (synth.image_s(1088, 1920, np.int16, seed=3).astype(np.int32) * 3).astype(np.int16)
+    src = ctx.upload(src_np)
+    dst = ctx.plane(1080, 1920, np.uint8)
+    ctx.convert_u8_batch([(src, dst)])
+    assert np.array_equal(dst.download(), O.convert_u8(src_np, 1920, 1080))
+    src.free()
+    dst.free()

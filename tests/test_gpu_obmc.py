@@ -1,0 +1,100 @@
+"""GPU parity: OBMC + residual add + clamp (HIP gather kernel, through the C ABI)
+vs the CPU oracle's restatement of schro_motion_render_u8 (block scatter, edge /
+interior split, aprons).  The reference asserts nothing about OBMC output
+(testsuite/motion.c prints cycles only), so the case matrix follows SURVEY.md
+Appendix C: chroma formats x block sets x mv_precision x weights x MV range.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import synth
+
+pytestmark = pytest.mark.gpu
+
+BLOCK_SETS = [(8, 4), (12, 8), (16, 12), (24, 16)]      # schroparams.c:192-198
+
+
+def comp_size(w, h, k, chroma):
+    if k == 0:
+        return w, h
+    return -(-w // (1 << chroma[0])), -(-h // (1 << chroma[1]))
+
+
+def run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, mv_range, seed, res_dtype=np.int16,
+             modes=(0.05, 0.45, 0.15, 0.35)):
+    P = synth.motion_params(w, h, xblen, xbsep, prec, weights, chroma)
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], mv_range, seed, modes)
+    op = O.MotionParams(**P)
+    d_mv = ctx.upload_bytes(mv)
+    jobs, keep, want = [], [], []
+    for k in range(3):
+        cw, ch = comp_size(w, h, k, chroma)
+        r1 = synth.picture_u8(ch, cw, seed=seed + 10 + k)
+        r2 = synth.picture_u8(ch, cw, seed=seed + 20 + k)
+        res = (synth.image_s(ch + 8, cw + 16, res_dtype, seed=seed + 30 + k).astype(np.int64) * 2
+               ).astype(res_dtype)       # residual lives in the iwt-padded frame
+        u1, u2 = O.UpComp(r1, upsample=prec > 0), O.UpComp(r2, upsample=prec > 0)
+        want.append(O.motion_render(mv, op, k, u1, u2, res, cw, ch))
+        if prec == 0:
+            g1, g2 = ctx.upload(r1), ctx.upload(r2)
+        else:
+            p1, p2 = ctx.upload(r1), ctx.upload(r2)
+            g1, g2 = ctx.plane(2 * ch, 2 * cw, np.uint8), ctx.plane(2 * ch, 2 * cw, np.uint8)
+            ctx.upsample_batch([(p1, g1), (p2, g2)])
+            keep += [p1, p2]
+        d_res = ctx.upload(res)
+        out = ctx.plane(ch, cw, np.uint8).fill(0x33)
+        jobs.append(sa.obmc_plane(d_mv, P, k, g1, g2, d_res, out))
+        keep += [g1, g2, d_res, out]
+        want[-1] = (want[-1], out)
+    ctx.obmc_batch(jobs)
+    for k, (ref, out) in enumerate(want):
+        got = out.download()
+        if not np.array_equal(got, ref):
+            bad = np.argwhere(got != ref)
+            raise AssertionError("component %d: %d mismatches, first at (y,x)=%s got %d want %d" % (
+                k, len(bad), tuple(bad[0]), got[tuple(bad[0])], ref[tuple(bad[0])]))
+    for p in keep + [d_mv]:
+        p.free()
+
+
+@pytest.mark.parametrize("chroma", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("prec", [0, 1, 2, 3])
+@pytest.mark.parametrize("blk", BLOCK_SETS)
+def test_default_weights(ctx, blk, prec, chroma):
+    for mv_range, seed in ((3 << prec, 2), (80 << prec, 3)):     # near, and far beyond the apron
+        run_case(ctx, 96, 64, blk[0], blk[1], prec, (1, 1, 1), chroma, mv_range, seed)
+
+
+@pytest.mark.parametrize("weights", [(3, 5, 3), (1, 2, 2), (2, 3, 1), (3, -1, 1), (5, 3, 2)])
+@pytest.mark.parametrize("prec", [0, 2, 3])
+def test_weighted_prediction(ctx, weights, prec):
+    # includes gain > 1 and a negative weight: the edge (u8) and interior (s16) block
+    # arithmetic of the reference differ there and both must be reproduced
+    for blk in ((12, 8), (16, 12)):
+        run_case(ctx, 96, 64, blk[0], blk[1], prec, weights, (1, 1), 24 << prec, 5)
+
+
+def test_ragged_sizes(ctx):
+    # picture sizes that are not multiples of the block separation, and a tile edge
+    for (w, h) in [(100, 70), (97, 61), (64, 36), (130, 18), (72, 132)]:
+        for prec in (0, 2):
+            run_case(ctx, w, h, 12, 8, prec, (1, 1, 1), (1, 1), 40, 7)
+
+
+def test_all_modes_and_s32_residual(ctx):
+    for modes in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)):
+        run_case(ctx, 96, 64, 12, 8, 2, (1, 1, 1), (1, 1), 64, 11, modes=modes)
+    run_case(ctx, 96, 64, 12, 8, 2, (1, 1, 1), (1, 0), 64, 12, res_dtype=np.int32)
+
+
+def test_test_stream_geometry(ctx):
+    # BASELINE config 2 geometry: 320x240 4:2:2, 12x12/8x8 blocks, full-pel, 40x32 blocks
+    run_case(ctx, 320, 240, 12, 8, 0, (1, 1, 1), (1, 0), 16, 21)
+
+
+def test_2160p_config(ctx):
+    # BASELINE config 3: 3840x2160 4:2:0, 12x12/8x8, quarter-pel, MVs +-64 quarter-pels
+    run_case(ctx, 3840, 2160, 12, 8, 2, (1, 1, 1), (1, 1), 64, 2)
