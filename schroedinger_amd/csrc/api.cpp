@@ -526,9 +526,6 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs,
       "obmc_batch: bad arguments");
   (void) hipSetDevice (ctx->device);
-  int tw, th;
-  obmc_tile_geometry (&tw, &th);
-
   // one launch per (precision class, simple-weight) group, keeping plane order
   std::vector < char >done (nplanes, 0);
   for (int first = 0; first < nplanes; first++) {
@@ -539,6 +536,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         && planes[first].picture_weight_bits == 1;
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
+    int tw, th;
+    obmc_tile_geometry (simple, &tw, &th);
     for (int p = first; p < nplanes; p++) {
       const SchroHipObmcPlane & pl = planes[p];
       const int psimple = pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1

@@ -282,37 +282,47 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
 
   // ---- stage the four sub-bands of the region in LDS ----------------------
   if (job.flags & 1) {
-    constexpr int NIT = 4 * RP * NG / kThreads;
-    uint2 v[NIT];
+    // sub-band index and LDS half are compile-time per load (no runtime-indexed
+    // job fields), all loads are issued before the first LDS write
+    constexpr int NPS = RP * NG / kThreads;     // loads per thread per sub-band
+    uint2 v[4][NPS];
 #pragma unroll
-    for (int n = 0; n < NIT; n++) {
-      int it = tid + n * kThreads;
-      int g = it % NG;
-      int rp = (it / NG) % RP;
-      int sb = it / (NG * RP);
-      int r = clampi (r0 + rp, 0, nr - 1);
-      int c = clampi (c0 + g * VL, 0, nc - VL);
-      const char *p = (const char *) job.sb[sb] + (size_t) r * job.sb_stride[sb]
-          + (size_t) c * sizeof (T);
-      v[n] = *reinterpret_cast < const uint2 * >(p);
+    for (int sb = 0; sb < 4; sb++) {
+      const char *base = (const char *) job.sb[sb];
+      const int stride = job.sb_stride[sb];
+#pragma unroll
+      for (int n = 0; n < NPS; n++) {
+        int it = tid + n * kThreads;
+        int g = it % NG;
+        int rp = it / NG;
+        int r = clampi (r0 + rp, 0, nr - 1);
+        int c = clampi (c0 + g * VL, 0, nc - VL);
+        v[sb][n] = *reinterpret_cast < const uint2 * >(base + (size_t) r * stride
+            + (size_t) c * sizeof (T));
+      }
     }
 #pragma unroll
-    for (int n = 0; n < NIT; n++) {
-      int it = tid + n * kThreads;
-      int g = it % NG;
-      int rp = (it / NG) % RP;
-      int sb = it / (NG * RP);
-      *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[n];
+    for (int sb = 0; sb < 4; sb++) {
+#pragma unroll
+      for (int n = 0; n < NPS; n++) {
+        int it = tid + n * kThreads;
+        int g = it % NG;
+        int rp = it / NG;
+        *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[sb][n];
+      }
     }
   } else {
-    for (int it = tid; it < 4 * RP * RC; it += kThreads) {
-      int c = it % RC;
-      int rp = (it / RC) % RP;
-      int sb = it / (RC * RP);
-      int r = r0 + rp, cc = c0 + c;
-      if (r >= 0 && r < nr && cc >= 0 && cc < nc) {
-        const T *p = (const T *) ((const char *) job.sb[sb] + (size_t) r * job.sb_stride[sb]);
-        lds[2 * rp + (sb >> 1)][(sb & 1) * RC + c] = p[cc];
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) {
+      const char *base = (const char *) job.sb[sb];
+      const int stride = job.sb_stride[sb];
+      for (int it = tid; it < RP * RC; it += kThreads) {
+        int c = it % RC;
+        int rp = it / RC;
+        int r = r0 + rp, cc = c0 + c;
+        if (r >= 0 && r < nr && cc >= 0 && cc < nc)
+          lds[2 * rp + (sb >> 1)][(sb & 1) * RC + c] =
+              ((const T *) (base + (size_t) r * stride))[cc];
       }
     }
   }

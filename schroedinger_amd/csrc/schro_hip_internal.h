@@ -94,7 +94,7 @@ int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
 void upsample_tile_geometry (int *tw, int *th);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int simple_weight);
-void obmc_tile_geometry (int *tw, int *th);
+void obmc_tile_geometry (int simple_weight, int *tw, int *th);
 
 }                               // namespace schro
 
