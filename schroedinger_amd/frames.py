@@ -1,0 +1,86 @@
+"""SchroFrame-shaped views for the stage-level C ABI (include/schro_hip.h, frame layer).
+
+HostFrame wraps three numpy planes as a SchroHipFrame with domain == NULL (what a
+patched schrodecoder.c would fill from its SchroFrame); DeviceFrame owns a frame
+allocated by schro_hip_frame_new_and_alloc in the context's memory domain."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+_DEPTH = {np.dtype(np.uint8): 0x00, np.dtype(np.int16): 0x04, np.dtype(np.int32): 0x08}
+_DTYPE = {0x00: np.uint8, 0x04: np.int16, 0x08: np.int32}
+
+
+def frame_format(dtype, h_shift, v_shift):
+    """SchroFrameFormat (schroframe.h:22-35) from depth and chroma shifts."""
+    return _DEPTH[np.dtype(dtype)] | (1 if h_shift else 0) | (2 if v_shift else 0)
+
+
+class HostFrame:
+    def __init__(self, planes, h_shift, v_shift):
+        self.planes = [np.ascontiguousarray(p) for p in planes]
+        self.c = _lib.Frame()
+        f = self.c
+        f.refcount, f.domain = 1, None
+        f.format = frame_format(self.planes[0].dtype, h_shift, v_shift)
+        f.height, f.width = self.planes[0].shape
+        for k, p in enumerate(self.planes):
+            d = f.components[k]
+            d.format, d.data, d.stride = f.format, p.ctypes.data, p.strides[0]
+            d.height, d.width = p.shape
+            d.length = p.strides[0] * p.shape[0]
+            d.h_shift, d.v_shift = (h_shift, v_shift) if k else (0, 0)
+
+    def ptr(self):
+        return C.byref(self.c)
+
+
+class DeviceFrame:
+    def __init__(self, ctx, fmt, width, height, upsampled=False):
+        self.ctx = ctx
+        self.p = ctx.lib.schro_hip_frame_new_and_alloc(ctx.h, fmt, width, height, 1 if upsampled else 0)
+        if not self.p:
+            raise _lib.SchroHipError(ctx.lib.schro_hip_last_error().decode())
+
+    @property
+    def c(self):
+        return self.p.contents
+
+    def ptr(self):
+        return self.p
+
+    def upload(self, host):
+        check(self.ctx.lib.schro_frame_to_hip(self.p, host.ptr()))
+        return self
+
+    def download(self):
+        f = self.c
+        dt = _DTYPE[f.format & 0xc]
+        mul = 2 if f.is_upsampled else 1
+        planes = [np.zeros((f.components[k].height * mul, f.components[k].width * mul), dt)
+                  for k in range(3)]
+        host = HostFrame(planes, f.format & 1, (f.format >> 1) & 1)
+        if f.is_upsampled:      # copy the full half-pel images
+            for k in range(3):
+                comp = f.components[k]
+                check(self.ctx.lib.schro_hip_download_2d(
+                    self.ctx.h, planes[k].ctypes.data_as(C.c_void_p), planes[k].strides[0],
+                    comp.data, comp.stride, comp.width * 2, comp.height * 2))
+            return planes
+        check(self.ctx.lib.schro_hipframe_to_cpu(host.ptr(), self.p))
+        return host.planes
+
+    def unref(self):
+        if self.p:
+            self.ctx.lib.schro_hip_frame_unref(self.p)
+            self.p = None
+
+
+def make_params(**kw):
+    p = _lib.Params()
+    for k, v in kw.items():
+        setattr(p, k, int(v))
+    return p
