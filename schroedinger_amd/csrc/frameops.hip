@@ -60,8 +60,9 @@ template < typename T >
 __global__ __launch_bounds__ (kThreads)
 void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
 {
-  const ConvertJob job = jobs[find_job (jobs, njobs, blockIdx.x)];
-  const int t = blockIdx.x - job.tile_base;
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const ConvertJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
   const int x = tx * kCvtTW + (threadIdx.x % 64) * 8;
   const int y = ty * kCvtTH + threadIdx.x / 64;
@@ -110,8 +111,9 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   __shared__ uint8_t p0[kUpTH + 7][kUpLW];      // integer pels, rows y0-3 .. y0+TH+3
   __shared__ uint8_t p2[kUpTH][kUpLW];          // v-half, cols x0-3 .. x0+TW+3
 
-  const UpsampleJob job = jobs[find_job (jobs, njobs, blockIdx.x)];
-  const int t = blockIdx.x - job.tile_base;
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
   const int x0 = tx * kUpTW, y0 = ty * kUpTH;
   const int w = job.w, h = job.h;

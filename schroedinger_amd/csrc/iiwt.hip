@@ -267,7 +267,7 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
 
   const int tid = threadIdx.x;
   int j = 0;
-  const int bid = blockIdx.x;
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   while (j + 1 < njobs && bid >= jobs[j + 1].tile_base)
     j++;
   const IwtJob job = jobs[j];

@@ -81,6 +81,22 @@ struct ObmcJob {
 
 constexpr int kMaxJobs = 256;
 
+// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin over
+// the 8 XCDs (each with its own 4 MiB L2), so neighbouring tiles -- which share
+// lifting halos and reference windows -- would land on 8 different L2s and each
+// would fetch its own copy.  This bijection gives every XCD one contiguous run
+// of tile ids instead (speed only; any placement is correct).
+#ifdef __HIPCC__
+__device__ __forceinline__ int
+xcd_tile_id (int bid, int nblocks)
+{
+  constexpr int kXcd = 8;
+  const int q = nblocks / kXcd, r = nblocks % kXcd;
+  const int x = bid % kXcd, k = bid / kXcd;
+  return x * q + (x < r ? x : r) + k;
+}
+#endif
+
 // launchers (one per .hip file)
 int launch_iiwt_level (hipStream_t stream, const IwtJob * d_jobs, int njobs,
     int total_tiles, int filter, int bpp);
