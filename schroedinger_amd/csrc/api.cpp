@@ -526,23 +526,23 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs,
       "obmc_batch: bad arguments");
   (void) hipSetDevice (ctx->device);
-  // one launch per (precision class, simple-weight) group, keeping plane order
+  // kernel variant per plane: default weights (1,1,bits 1) run the LDS-accumulate
+  // tile kernel, everything else the exact per-pixel kernel
+  auto variant_of = [](const SchroHipObmcPlane & pl) {
+    return (pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1 && pl.picture_weight_bits == 1) ? 1 : 0;
+  };
+  // one launch per (precision class, kernel variant) group, keeping plane order
   std::vector < char >done (nplanes, 0);
   for (int first = 0; first < nplanes; first++) {
     if (done[first])
       continue;
     const int prec = planes[first].mv_precision;
-    const int simple = planes[first].picture_weight_1 == 1 && planes[first].picture_weight_2 == 1
-        && planes[first].picture_weight_bits == 1;
+    const int variant = variant_of (planes[first]);
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
-    int tw, th;
-    obmc_tile_geometry (simple, &tw, &th);
     for (int p = first; p < nplanes; p++) {
       const SchroHipObmcPlane & pl = planes[p];
-      const int psimple = pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1
-          && pl.picture_weight_bits == 1;
-      if (done[p] || pl.mv_precision != prec || psimple != simple)
+      if (done[p] || pl.mv_precision != prec || variant_of (pl) != variant)
         continue;
       done[p] = 1;
       SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
@@ -593,9 +593,10 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       j.out_stride = pl.out_stride;
       j.w = pl.width;
       j.h = pl.height;
-      j.tiles_x = div_up (pl.width, tw);
+      int tiles_y;
+      obmc_tiles (variant, pl.width, pl.height, j.xoff, &j.tiles_x, &tiles_y);
       j.tile_base = tile_base;
-      tile_base += j.tiles_x * div_up (pl.height, th);
+      tile_base += j.tiles_x * tiles_y;
       jobs.push_back (j);
     }
     void *d_jobs;
@@ -605,7 +606,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
       r = launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec,
-          simple);
+          variant);
     }
     if (r)
       return r;

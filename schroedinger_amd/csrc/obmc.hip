@@ -667,11 +667,11 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   }
 }
 
-template < int PC, bool SIMPLE >
+template < int PC >
 int
-launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles)
+launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant)
 {
-  if constexpr (SIMPLE)
+  if (variant == 1)
     hipLaunchKernelGGL ((obmc_tile_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), 0, stream,
         d_jobs, njobs);
   else
@@ -685,30 +685,29 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 
 }                               // namespace
 
-// default weights run the 64x32 tile kernel, anything else the per-pixel one
+// variant 0: per-pixel kernel (any weights), 64x4 tiles
+// variant 1: LDS-accumulate tile kernel (default weights), 64x64 tiles
 void
-obmc_tile_geometry (int simple_weight, int *tw, int *th)
+obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 {
-  *tw = simple_weight ? kFTW : kTW;
-  *th = simple_weight ? kFTH : kTH;
+  (void) xoff;
+  if (variant == 1) {
+    *tiles_x = (w + kFTW - 1) / kFTW;
+    *tiles_y = (h + kFTH - 1) / kFTH;
+  } else {
+    *tiles_x = (w + kTW - 1) / kTW;
+    *tiles_y = (h + kTH - 1) / kTH;
+  }
 }
 
 int
 launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec,
-    int simple_weight)
+    int variant)
 {
-  int pc = prec == 0 ? 0 : (prec == 1 ? 1 : 2);
-  if (simple_weight) {
-    switch (pc) {
-      case 0: return launch_one < 0, true > (stream, d_jobs, njobs, total_tiles);
-      case 1: return launch_one < 1, true > (stream, d_jobs, njobs, total_tiles);
-      default: return launch_one < 2, true > (stream, d_jobs, njobs, total_tiles);
-    }
-  }
-  switch (pc) {
-    case 0: return launch_one < 0, false > (stream, d_jobs, njobs, total_tiles);
-    case 1: return launch_one < 1, false > (stream, d_jobs, njobs, total_tiles);
-    default: return launch_one < 2, false > (stream, d_jobs, njobs, total_tiles);
+  switch (prec == 0 ? 0 : (prec == 1 ? 1 : 2)) {
+    case 0: return launch_one < 0 > (stream, d_jobs, njobs, total_tiles, variant);
+    case 1: return launch_one < 1 > (stream, d_jobs, njobs, total_tiles, variant);
+    default: return launch_one < 2 > (stream, d_jobs, njobs, total_tiles, variant);
   }
 }
 

@@ -109,8 +109,8 @@ int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);
 void upsample_tile_geometry (int *tw, int *th);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
-    int total_tiles, int prec, int simple_weight);
-void obmc_tile_geometry (int simple_weight, int *tw, int *th);
+    int total_tiles, int prec, int variant);
+void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
 
 }                               // namespace schro
 
