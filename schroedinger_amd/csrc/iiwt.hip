@@ -184,11 +184,14 @@ lift_apply (T d, const T * s)
 
 template < typename T, int F > struct Geo {
   static constexpr int RP = 32;                         // region row pairs
-  static constexpr int RC = sizeof (T) == 2 ? 128 : 64; // region columns per half
   static constexpr int H = filter_halo (F);
   static constexpr int HC = (H + 3) & ~3;               // keeps 8-byte alignment of loads
+  // useful columns per half per tile: a tile row of output is 2*UC samples and must be
+  // whole 128-byte lines, otherwise neighbouring tiles (on other XCDs) each write a
+  // partial line
+  static constexpr int UC = sizeof (T) == 2 ? 128 : 64;
+  static constexpr int RC = UC + 2 * HC;                // region columns per half
   static constexpr int UR = RP - 2 * H;                 // useful row pairs per tile
-  static constexpr int UC = RC - 2 * HC;                // useful columns per half per tile
 };
 
 __device__ __forceinline__ int
@@ -199,59 +202,176 @@ clampi (int x, int lo, int hi)
 
 constexpr int kThreads = 256;
 
-template < typename T, int F, int K, int RP, int RC >
+constexpr int
+cmax (int a, int b)
+{
+  return a > b ? a : b;
+}
+
+// ---- vertical lifting step: 4 columns (one 64/128-bit LDS access) per item ----
+// CLAMP == false: the region lies inside the picture, neighbour rows are taken as
+// they are and only rows whose taps stay inside the region are computed (the
+// skipped rows are halo whose values no useful output depends on).
+template < typename T, int F, int K, int RP, int RC, bool CLAMP >
 __device__ __forceinline__ void
 vertical_step (T (*lds)[2 * RC], int tid, int vlo, int vhi)
 {
-  typedef typename Ar < T >::T2 T2;
+  struct __attribute__ ((aligned (4 * sizeof (T)))) T4 { T v[4]; };
   constexpr Step st = filter_step (F, K);
   constexpr int NT = kind_ntaps (st.kind);
-#pragma unroll 4
-  for (int it = tid; it < RP * RC; it += kThreads) {
-    int cp = it % RC;
-    int rp = it / RC;
-    if (rp < vlo || rp > vhi)
+  constexpr int IPR = 2 * RC / 4;       // items per row
+  constexpr int LO = cmax (0, -st.off), HI = RP - 1 - cmax (0, st.off + NT - 1);
+#pragma unroll 2
+  for (int it = tid; it < RP * IPR; it += kThreads) {
+    const int cp = it % IPR;
+    const int rp = it / IPR;
+    if (CLAMP ? (rp < vlo || rp > vhi) : (rp < LO || rp > HI))
       continue;
-    T sx[NT], sy[NT];
+    T4 tap[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      int rr = clampi (rp + st.off + t, vlo, vhi);
-      T2 v = reinterpret_cast < const T2 * >(&lds[2 * rr + 1 - st.target][0])[cp];
-      sx[t] = v.x;
-      sy[t] = v.y;
+      const int rr = CLAMP ? clampi (rp + st.off + t, vlo, vhi) : rp + st.off + t;
+      tap[t] = reinterpret_cast < const T4 * >(&lds[2 * rr + 1 - st.target][0])[cp];
     }
-    T2 *dp = reinterpret_cast < T2 * >(&lds[2 * rp + st.target][0]) + cp;
-    T2 d = *dp;
-    d.x = lift_apply < T, F, K > (d.x, sx);
-    d.y = lift_apply < T, F, K > (d.y, sy);
+    T4 *dp = reinterpret_cast < T4 * >(&lds[2 * rp + st.target][0]) + cp;
+    T4 d = *dp;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      T s[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        s[t] = tap[t].v[e];
+      d.v[e] = lift_apply < T, F, K > (d.v[e], s);
+    }
     *dp = d;
   }
 }
 
-template < typename T, int F, int K, int RP, int RC, int H, int UR >
-__device__ __forceinline__ void
-horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here)
+template < typename T, int SH >
+__device__ __forceinline__ T
+out_round (T a)
 {
+  typedef Ar < T > A;
+  if constexpr (SH == 1)
+    return (T) (A::wrap (A::add32 (a, 1)) >> 1);        // orc_interleave2_rrshift1_*: add wraps
+  else if constexpr (SH == 2)
+    return A::avg (a, 0);                               // orc_haar_synth_rrshift1_int_*: avgs
+  else
+    return a;
+}
+
+constexpr int
+floor4 (int a)
+{
+  return a >= 0 ? a / 4 * 4 : -((-a + 3) / 4 * 4);
+}
+
+// ---- horizontal lifting step on sample quads (i .. i+3), i a multiple of 4 -------
+// CLAMP == false: the region lies inside the picture; every quad of the row is
+// computed from 64/128-bit LDS reads.  Taps that fall off the region at its two
+// ends read neighbouring LDS words (always inside the array: rows 2H.. are never
+// the first or last row) and only spoil halo samples no useful output depends on.
+// LAST == true: the filter's final step; the updated quad and its partner quad
+// from the other half are interleaved, rounded and stored straight to memory
+// (no LDS write-back, no separate output pass).
+template < typename T, int F, int K, int RP, int RC, int H, int HC, int UR, bool CLAMP, bool LAST >
+__device__ __forceinline__ void
+horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, const IwtJob & job,
+    int y0, int c0, int nc)
+{
+  struct __attribute__ ((aligned (4 * sizeof (T)))) T4 { T v[4]; };
   constexpr Step st = filter_step (F, K);
   constexpr int NT = kind_ntaps (st.kind);
-  constexpr int PAIRS = RC / 2;
+  constexpr int SH = filter_shift (F);
+  constexpr int QLO = LAST ? HC / 4 : 0;
+  constexpr int QHI = LAST ? (RC - HC) / 4 - 1 : RC / 4 - 1;
+  constexpr int NQ = QHI - QLO + 1;
+  // neighbour window: samples i+off .. i+off+NT+2, fetched as aligned 4-sample words
+  constexpr int FIRST = floor4 (st.off);
+  constexpr int NW = (st.off + NT + 2 - FIRST) / 4 + 1;
+  static_assert (RC % 4 == 0 && HC % 4 == 0, "quads need 4-aligned halves");
 #pragma unroll 2
-  for (int it = tid; it < 2 * UR * PAIRS; it += kThreads) {
-    int p = it % PAIRS;
-    int yy = it / PAIRS;
-    int i = 2 * p;
-    if (yy >= rows_here || i > hhi || i + 1 < hlo)
+  for (int it = tid; it < 2 * UR * NQ; it += kThreads) {
+    const int q = QLO + it % NQ;
+    const int yy = it / NQ;
+    const int i = 4 * q;
+    if (yy >= rows_here)
+      continue;
+    if (CLAMP && (i > hhi || i + 3 < hlo))
       continue;
     T *row = &lds[2 * H + yy][0];
     T *d = row + (st.target ? RC : 0);
     const T *o = row + (st.target ? 0 : RC);
-    T s[NT + 1];
+    T s[NT + 3];
+    if constexpr (CLAMP) {
 #pragma unroll
-    for (int t = 0; t < NT + 1; t++)
-      s[t] = o[clampi (i + st.off + t, hlo, hhi)];
-    d[i] = lift_apply < T, F, K > (d[i], s);
-    d[i + 1] = lift_apply < T, F, K > (d[i + 1], s + 1);
+      for (int t = 0; t < NT + 3; t++)
+        s[t] = o[clampi (i + st.off + t, hlo, hhi)];
+    } else {
+      T4 w[NW];
+#pragma unroll
+      for (int m = 0; m < NW; m++)
+        w[m] = reinterpret_cast < const T4 * >(o + i + FIRST)[m];
+#pragma unroll
+      for (int t = 0; t < NT + 3; t++) {
+        const int e = t + st.off - FIRST;
+        s[t] = w[e >> 2].v[e & 3];
+      }
+    }
+    T4 dv = *reinterpret_cast < const T4 * >(d + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      dv.v[k] = lift_apply < T, F, K > (dv.v[k], s + k);
+    if constexpr (!LAST) {
+      *reinterpret_cast < T4 * >(d + i) = dv;
+    } else {
+      const int c = c0 + i;
+      if (c >= nc || c + 3 < 0)
+        continue;
+      // the partner quad o[i..i+3] lies inside the neighbour window for every filter
+      static_assert (-st.off >= 0 && -st.off <= NT - 1, "partner quad outside the tap window");
+      T out[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const T ov = s[k - st.off];
+        out[2 * k] = out_round < T, SH > (st.target ? ov : dv.v[k]);
+        out[2 * k + 1] = out_round < T, SH > (st.target ? dv.v[k] : ov);
+      }
+      T *dst = (T *) ((char *) job.dst + (size_t) (y0 + yy) * job.dst_stride) + 2 * c;
+      if ((job.flags & 2) && c >= 0 && c + 4 <= nc) {
+        if constexpr (sizeof (T) == 2) {
+          uint4 pk;
+          pk.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
+          pk.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
+          pk.z = (uint16_t) out[4] | ((uint32_t) (uint16_t) out[5] << 16);
+          pk.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
+          *reinterpret_cast < uint4 * >(dst) = pk;
+        } else {
+          reinterpret_cast < int4 * >(dst)[0] = make_int4 (out[0], out[1], out[2], out[3]);
+          reinterpret_cast < int4 * >(dst)[1] = make_int4 (out[4], out[5], out[6], out[7]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (c + k >= 0 && c + k < nc) {
+            dst[2 * k] = out[2 * k];
+            dst[2 * k + 1] = out[2 * k + 1];
+          }
+      }
+    }
   }
+}
+
+template < typename T, int F, int K, bool CLAMP, typename LDS >
+__device__ __forceinline__ void
+hstep (LDS lds, int tid, int hlo, int hhi, int rows_here, const IwtJob & job, int y0, int c0, int nc)
+{
+  typedef Geo < T, F > G;
+  constexpr bool LAST = K == filter_nsteps (F) - 1;
+  horizontal_step < T, F, K, G::RP, G::RC, G::H, G::HC, G::UR, CLAMP, LAST > (lds, tid, hlo, hhi,
+      rows_here, job, y0, c0, nc);
+  if constexpr (!LAST)
+    __syncthreads ();
 }
 
 template < typename T, int F >
@@ -259,7 +379,6 @@ __global__ __launch_bounds__ (kThreads)
 void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
 {
   typedef Geo < T, F > G;
-  typedef Ar < T > A;
   constexpr int RP = G::RP, RC = G::RC, H = G::H, HC = G::HC, UR = G::UR, UC = G::UC;
   constexpr int VL = 8 / sizeof (T);    // samples per 8-byte vector
   constexpr int NG = RC / VL;           // 8-byte groups per half row
@@ -284,7 +403,7 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
   if (job.flags & 1) {
     // sub-band index and LDS half are compile-time per load (no runtime-indexed
     // job fields), all loads are issued before the first LDS write
-    constexpr int NPS = RP * NG / kThreads;     // loads per thread per sub-band
+    constexpr int NPS = (RP * NG + kThreads - 1) / kThreads;    // loads per thread per sub-band
     uint2 v[4][NPS];
 #pragma unroll
     for (int sb = 0; sb < 4; sb++) {
@@ -292,7 +411,7 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
       const int stride = job.sb_stride[sb];
 #pragma unroll
       for (int n = 0; n < NPS; n++) {
-        int it = tid + n * kThreads;
+        int it = min (tid + n * kThreads, RP * NG - 1);
         int g = it % NG;
         int rp = it / NG;
         int r = clampi (r0 + rp, 0, nr - 1);
@@ -306,9 +425,11 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
 #pragma unroll
       for (int n = 0; n < NPS; n++) {
         int it = tid + n * kThreads;
-        int g = it % NG;
-        int rp = it / NG;
-        *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[sb][n];
+        if (it < RP * NG) {
+          int g = it % NG;
+          int rp = it / NG;
+          *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[sb][n];
+        }
       }
     }
   } else {
@@ -329,76 +450,47 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
   __syncthreads ();
 
   // ---- vertical lifting steps (A = even rows, B = odd rows) ----------------
-  vertical_step < T, F, 0, RP, RC > (lds, tid, vlo, vhi);
-  __syncthreads ();
-  vertical_step < T, F, 1, RP, RC > (lds, tid, vlo, vhi);
-  __syncthreads ();
-  if constexpr (filter_nsteps (F) == 4) {
-    vertical_step < T, F, 2, RP, RC > (lds, tid, vlo, vhi);
+  if (vlo > 0 || vhi < RP - 1) {        // region sticks out of the picture: clamp rows
+    vertical_step < T, F, 0, RP, RC, true > (lds, tid, vlo, vhi);
     __syncthreads ();
-    vertical_step < T, F, 3, RP, RC > (lds, tid, vlo, vhi);
+    vertical_step < T, F, 1, RP, RC, true > (lds, tid, vlo, vhi);
     __syncthreads ();
+    if constexpr (filter_nsteps (F) == 4) {
+      vertical_step < T, F, 2, RP, RC, true > (lds, tid, vlo, vhi);
+      __syncthreads ();
+      vertical_step < T, F, 3, RP, RC, true > (lds, tid, vlo, vhi);
+      __syncthreads ();
+    }
+  } else {
+    vertical_step < T, F, 0, RP, RC, false > (lds, tid, vlo, vhi);
+    __syncthreads ();
+    vertical_step < T, F, 1, RP, RC, false > (lds, tid, vlo, vhi);
+    __syncthreads ();
+    if constexpr (filter_nsteps (F) == 4) {
+      vertical_step < T, F, 2, RP, RC, false > (lds, tid, vlo, vhi);
+      __syncthreads ();
+      vertical_step < T, F, 3, RP, RC, false > (lds, tid, vlo, vhi);
+      __syncthreads ();
+    }
   }
 
-  // ---- horizontal lifting steps on the rows this tile outputs --------------
+  // ---- horizontal lifting steps on the rows this tile outputs; the last one
+  // interleaves, rounds and stores ---------------------------------------------
   const int y0 = 2 * (r0 + H);  // first output row of the tile
   const int rows_here = min (2 * UR, job.h - y0);
-  horizontal_step < T, F, 0, RP, RC, H, UR > (lds, tid, hlo, hhi, rows_here);
-  __syncthreads ();
-  horizontal_step < T, F, 1, RP, RC, H, UR > (lds, tid, hlo, hhi, rows_here);
-  __syncthreads ();
-  if constexpr (filter_nsteps (F) == 4) {
-    horizontal_step < T, F, 2, RP, RC, H, UR > (lds, tid, hlo, hhi, rows_here);
-    __syncthreads ();
-    horizontal_step < T, F, 3, RP, RC, H, UR > (lds, tid, hlo, hhi, rows_here);
-    __syncthreads ();
-  }
-
-  // ---- interleave + output rounding + store --------------------------------
-  constexpr int OG = UC / 4;    // groups of 4 sub-band columns = 8 output samples
-  constexpr int SH = filter_shift (F);
-  for (int it = tid; it < 2 * UR * OG; it += kThreads) {
-    int g = it % OG;
-    int yy = it / OG;
-    int cl = HC + 4 * g;        // region-local sub-band column
-    int c = c0 + cl;
-    if (yy >= rows_here || c >= nc)
-      continue;
-    const T *row = &lds[2 * H + yy][0];
-    T o[8];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      T a = row[cl + e], b = row[RC + cl + e];
-      if constexpr (SH == 1) {
-        a = (T) (A::wrap (A::add32 (a, 1)) >> 1);
-        b = (T) (A::wrap (A::add32 (b, 1)) >> 1);
-      } else if constexpr (SH == 2) {
-        a = A::avg (a, 0);
-        b = A::avg (b, 0);
-      }
-      o[2 * e] = a;
-      o[2 * e + 1] = b;
+  if (hlo > 0 || hhi < RC - 1) {
+    hstep < T, F, 0, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    hstep < T, F, 1, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    if constexpr (filter_nsteps (F) == 4) {
+      hstep < T, F, 2, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+      hstep < T, F, 3, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
     }
-    T *dst = (T *) ((char *) job.dst + (size_t) (y0 + yy) * job.dst_stride) + 2 * c;
-    if ((job.flags & 2) && c + 4 <= nc) {
-      if constexpr (sizeof (T) == 2) {
-        uint4 pk;
-        pk.x = (uint16_t) o[0] | ((uint32_t) (uint16_t) o[1] << 16);
-        pk.y = (uint16_t) o[2] | ((uint32_t) (uint16_t) o[3] << 16);
-        pk.z = (uint16_t) o[4] | ((uint32_t) (uint16_t) o[5] << 16);
-        pk.w = (uint16_t) o[6] | ((uint32_t) (uint16_t) o[7] << 16);
-        *reinterpret_cast < uint4 * >(dst) = pk;
-      } else {
-        reinterpret_cast < int4 * >(dst)[0] = make_int4 (o[0], o[1], o[2], o[3]);
-        reinterpret_cast < int4 * >(dst)[1] = make_int4 (o[4], o[5], o[6], o[7]);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        if (c + e < nc) {
-          dst[2 * e] = o[2 * e];
-          dst[2 * e + 1] = o[2 * e + 1];
-        }
+  } else {
+    hstep < T, F, 0, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    hstep < T, F, 1, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    if constexpr (filter_nsteps (F) == 4) {
+      hstep < T, F, 2, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+      hstep < T, F, 3, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
     }
   }
 }
