@@ -268,7 +268,7 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 // once per tile instead of once per pixel.  The finish pass reads the residual
 // (8-byte loads), rounds, adds, clamps and stores 4 pixels per lane.
 
-constexpr int kFTW = 64, kFTH = 64;
+constexpr int kFTW = 128, kFTH = 32;
 
 struct __attribute__ ((packed)) U64u { uint64_t v; };
 struct __attribute__ ((packed)) U32u { uint32_t v; };
@@ -280,7 +280,7 @@ floor_div (int a, int b)
   return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-constexpr int kAccStride = 77;  // odd: block rows land on different LDS banks
+constexpr int kAccStride = 141; // odd: block rows land on different LDS banks
 constexpr int kBlkCap = 256;    // decoded blocks held in LDS per chunk
 
 // One decoded block.  Everything that is uniform over the block's pixels is
@@ -686,7 +686,7 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 }                               // namespace
 
 // variant 0: per-pixel kernel (any weights), 64x4 tiles
-// variant 1: LDS-accumulate tile kernel (default weights), 64x64 tiles
+// variant 1: LDS-accumulate tile kernel (default weights), 128x32 tiles
 void
 obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 {
