@@ -93,23 +93,71 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
 }
 
 // ---- upsample ----------------------------------------------------------------
+// 128x16 pixel tile, one lane = 4 horizontally adjacent pixels (one dword of the
+// integer-pel plane).  Integer pels (+3/+4 halo, as whole dwords) are staged in
+// LDS with picture coordinates clamped on the way in, which is the index clamp
+// of mas8_u8_edgeextend / the CLAMP (i + j - 3, 0, height - 1) row list.  The
+// vertical 8-tap runs on packed 16-bit lanes (v_pk_*), the horizontal 8-tap as
+// four v_dot4_u32_u8 per sample (positive and negative taps separately) on
+// byte windows cut out with v_alignbyte_b32.
 
-constexpr int kUpTW = 64, kUpTH = 16;
-constexpr int kUpLW = kUpTW + 8;        // 7 halo columns, padded
+constexpr int kUpTW = 128, kUpTH = 16;
+constexpr int kUpDW = kUpTW / 4 + 2;    // LDS dwords per row: pixels x0-4 .. x0+TW+3
 
-__device__ __forceinline__ int
-mas8 (const int *s)
+typedef short short2v __attribute__ ((ext_vector_type (2)));
+
+__device__ __forceinline__ short2v
+lo_pair (uint32_t d)
 {
-  // taps {-1, 3, -7, 21, 21, -7, 3, -1}, (x + 16) >> 5, clamp
-  int x = 21 * (s[3] + s[4]) - 7 * (s[2] + s[5]) + 3 * (s[1] + s[6]) - (s[0] + s[7]);
-  return clampi ((x + 16) >> 5, 0, 255);
+  short2v r = { (short) (d & 0xff), (short) ((d >> 8) & 0xff) };
+  return r;
+}
+
+__device__ __forceinline__ short2v
+hi_pair (uint32_t d)
+{
+  short2v r = { (short) ((d >> 16) & 0xff), (short) (d >> 24) };
+  return r;
+}
+
+// taps {-1, 3, -7, 21, 21, -7, 3, -1}, clamp ((sum + 16) >> 5, 0, 255) on two lanes
+__device__ __forceinline__ short2v
+mas8_pk (const short2v * r)
+{
+  short2v x = (r[3] + r[4]) * (short) 21 - (r[2] + r[5]) * (short) 7 + (r[1] + r[6]) * (short) 3
+      - (r[0] + r[7]);
+  x = (x + (short) 16) >> 5;
+  x = __builtin_elementwise_max (x, (short2v) { 0, 0 });
+  x = __builtin_elementwise_min (x, (short2v) { 255, 255 });
+  return x;
+}
+
+// the same filter on 8 consecutive bytes: lo4 = samples 0..3, hi4 = samples 4..7
+__device__ __forceinline__ int
+mas8_bytes (uint32_t lo4, uint32_t hi4)
+{
+  uint32_t pos = __builtin_amdgcn_udot4 (lo4, 0x15000300u, 16u, false);        // +3, +21 (+16)
+  pos = __builtin_amdgcn_udot4 (hi4, 0x00030015u, pos, false);                  // +21, +3
+  uint32_t neg = __builtin_amdgcn_udot4 (lo4, 0x00070001u, 0u, false);          // 1, 7
+  neg = __builtin_amdgcn_udot4 (hi4, 0x01000700u, neg, false);                  // 7, 1
+  return clampi (((int) (pos - neg)) >> 5, 0, 255);
+}
+
+// horizontal half-pel samples of the 4 pixels in dword d1 (d0 / d2: the dwords left / right)
+__device__ __forceinline__ void
+mas8_row4 (uint32_t d0, uint32_t d1, uint32_t d2, int *out)
+{
+  out[0] = mas8_bytes (__builtin_amdgcn_alignbyte (d1, d0, 1), __builtin_amdgcn_alignbyte (d2, d1, 1));
+  out[1] = mas8_bytes (__builtin_amdgcn_alignbyte (d1, d0, 2), __builtin_amdgcn_alignbyte (d2, d1, 2));
+  out[2] = mas8_bytes (__builtin_amdgcn_alignbyte (d1, d0, 3), __builtin_amdgcn_alignbyte (d2, d1, 3));
+  out[3] = mas8_bytes (d1, d2);
 }
 
 __global__ __launch_bounds__ (kThreads)
 void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
 {
-  __shared__ uint8_t p0[kUpTH + 7][kUpLW];      // integer pels, rows y0-3 .. y0+TH+3
-  __shared__ uint8_t p2[kUpTH][kUpLW];          // v-half, cols x0-3 .. x0+TW+3
+  __shared__ uint32_t s0[kUpTH + 7][kUpDW];     // integer pels, rows y0-3 .. y0+TH+3
+  __shared__ uint32_t s2[kUpTH][kUpDW];         // v-half
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
@@ -118,72 +166,90 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   const int x0 = tx * kUpTW, y0 = ty * kUpTH;
   const int w = job.w, h = job.h;
   const int tid = threadIdx.x;
+  const bool src_al = ((((uintptr_t) job.src) | job.src_stride) & 3) == 0;
 
-  // picture coordinates are clamped on the way in, which is the index clamp
-  // of mas8_u8_edgeextend / the CLAMP (i + j - 3, 0, height - 1) row list
-  for (int it = tid; it < (kUpTH + 7) * (kUpTW + 7); it += kThreads) {
-    int lx = it % (kUpTW + 7), ly = it / (kUpTW + 7);
-    int gx = clampi (x0 - 3 + lx, 0, w - 1);
-    int gy = clampi (y0 - 3 + ly, 0, h - 1);
-    p0[ly][lx] = job.src[(size_t) gy * job.src_stride + gx];
-  }
-  __syncthreads ();
-
-  for (int it = tid; it < kUpTH * (kUpTW + 7); it += kThreads) {
-    int lx = it % (kUpTW + 7), ly = it / (kUpTW + 7);
-    int gy = y0 + ly;
-    int s[8];
+  for (int it = tid; it < (kUpTH + 7) * kUpDW; it += kThreads) {
+    const int g = it % kUpDW, ly = it / kUpDW;
+    const int gy = clampi (y0 - 3 + ly, 0, h - 1);
+    const int gx = x0 - 4 + 4 * g;
+    const uint8_t *row = job.src + (size_t) gy * job.src_stride;
+    uint32_t d;
+    if (src_al && gx >= 0 && gx + 4 <= w) {
+      d = *reinterpret_cast < const uint32_t * >(row + gx);
+    } else {
+      d = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      s[k] = p0[ly + k][lx];
-    // last row of the v-half is a copy of the source row (schroframe.c:1642-1644)
-    p2[ly][lx] = (gy >= h - 1) ? p0[ly + 3][lx] : (uint8_t) mas8 (s);
-  }
-  __syncthreads ();
-
-  const int lx4 = (tid % 16) * 4;       // 4 pixels per thread
-  const int ly = tid / 16;
-  const int gy = y0 + ly;
-  if (gy >= h)
-    return;
-  uint8_t row_e[8], row_o[8];           // HP rows 2*gy and 2*gy+1
-  int valid = 0;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    int lx = lx4 + e;
-    int gx = x0 + lx;
-    if (gx >= w)
-      break;
-    valid = e + 1;
-    int s0[8], s2[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      s0[k] = p0[ly + 3][lx + k];
-      s2[k] = p2[ly][lx + k];
+      for (int k = 0; k < 4; k++)
+        d |= (uint32_t) row[clampi (gx + k, 0, w - 1)] << (8 * k);
     }
-    int c0 = s0[3], c2 = s2[3];
-    // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the
-    // following schro_frame_mc_edgeextend_horiz overwrites it the same way)
-    int c1 = (gx >= w - 1) ? c0 : mas8 (s0);
-    int c3 = (gx >= w - 1) ? c2 : mas8 (s2);
-    if (gy >= h - 1)
-      c3 = c1;                  // last row of hv-half comes from the h-half (schroframe.c:2028)
-    row_e[2 * e] = (uint8_t) c0;
-    row_e[2 * e + 1] = (uint8_t) c1;
-    row_o[2 * e] = (uint8_t) c2;
-    row_o[2 * e + 1] = (uint8_t) c3;
+    s0[ly][g] = d;
   }
-  if (!valid)
+  __syncthreads ();
+
+  for (int it = tid; it < kUpTH * kUpDW; it += kThreads) {
+    const int g = it % kUpDW, ly = it / kUpDW;
+    uint32_t out;
+    if (y0 + ly >= h - 1) {
+      out = s0[ly + 3][g];      // last row of the v-half is a copy (schroframe.c:1642-1644)
+    } else {
+      short2v lo[8], hi[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t d = s0[ly + k][g];
+        lo[k] = lo_pair (d);
+        hi[k] = hi_pair (d);
+      }
+      const short2v a = mas8_pk (lo), b = mas8_pk (hi);
+      out = (uint32_t) (uint16_t) a.x | ((uint32_t) (uint16_t) a.y << 8)
+          | ((uint32_t) (uint16_t) b.x << 16) | ((uint32_t) (uint16_t) b.y << 24);
+    }
+    s2[ly][g] = out;
+  }
+  __syncthreads ();
+
+  const int g = tid % (kUpTW / 4);      // pixel group: pixels x0 + 4g .. +3 (LDS dword g + 1)
+  const int gx = x0 + 4 * g;
+  if (gx >= w)
     return;
-  uint8_t *de = job.dst + (size_t) (2 * gy) * job.dst_stride + 2 * (x0 + lx4);
-  uint8_t *dod = de + job.dst_stride;
-  if (valid == 4 && (((uintptr_t) de | (uintptr_t) dod) & 7) == 0) {
-    *reinterpret_cast < uint2 * >(de) = *reinterpret_cast < const uint2 * >(row_e);
-    *reinterpret_cast < uint2 * >(dod) = *reinterpret_cast < const uint2 * >(row_o);
-  } else {
-    for (int e = 0; e < 2 * valid; e++) {
-      de[e] = row_e[e];
-      dod[e] = row_o[e];
+#pragma unroll
+  for (int half = 0; half < kUpTH / 8; half++) {
+    const int ly = tid / (kUpTW / 4) + 8 * half;
+    const int gy = y0 + ly;
+    if (gy >= h)
+      continue;
+    const uint32_t c0 = s0[ly + 3][g + 1], c2 = s2[ly][g + 1];
+    int p1[4], p3[4];
+    mas8_row4 (s0[ly + 3][g], c0, s0[ly + 3][g + 2], p1);
+    mas8_row4 (s2[ly][g], c2, s2[ly][g + 2], p3);
+    uint32_t d1 = 0, d3 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
+      // schro_frame_mc_edgeextend_horiz overwrites it the same way)
+      const bool lastcol = gx + e >= w - 1;
+      int v1 = lastcol ? (int) ((c0 >> (8 * e)) & 0xff) : p1[e];
+      int v3 = lastcol ? (int) ((c2 >> (8 * e)) & 0xff) : p3[e];
+      if (gy >= h - 1)
+        v3 = v1;                // last row of the hv-half comes from the h-half (schroframe.c:2028)
+      d1 |= (uint32_t) v1 << (8 * e);
+      d3 |= (uint32_t) v3 << (8 * e);
+    }
+    // interleave: even HP row = (integer, h-half) pairs, odd row = (v-half, hv-half)
+    const uint2 even = make_uint2 (__builtin_amdgcn_perm (d1, c0, 0x05010400u),
+        __builtin_amdgcn_perm (d1, c0, 0x07030602u));
+    const uint2 odd = make_uint2 (__builtin_amdgcn_perm (d3, c2, 0x05010400u),
+        __builtin_amdgcn_perm (d3, c2, 0x07030602u));
+    uint8_t *de = job.dst + (size_t) (2 * gy) * job.dst_stride + 2 * gx;
+    uint8_t *dod = de + job.dst_stride;
+    if (gx + 4 <= w && (((uintptr_t) de | (uintptr_t) dod) & 7) == 0) {
+      *reinterpret_cast < uint2 * >(de) = even;
+      *reinterpret_cast < uint2 * >(dod) = odd;
+    } else {
+      const uint64_t ev = even.x | ((uint64_t) even.y << 32), ov = odd.x | ((uint64_t) odd.y << 32);
+      for (int e = 0; e < 8 && gx + e / 2 < w; e++) {
+        de[e] = (uint8_t) (ev >> (8 * e));
+        dod[e] = (uint8_t) (ov >> (8 * e));
+      }
     }
   }
 }
