@@ -177,11 +177,16 @@ def main():
         # dominant kernel = the class with the largest summed event time
         dom = max(prof, key=lambda k: prof[k][0])
         samples = args.frames * (W * H * 3 // 2)            # 4:2:0 samples per launch
+        # references used per block, from the actual motion field (mode 1/2: one, mode 3: two)
+        modes = np.concatenate([m["flags"] & 3 for m in wl.mv_np])
+        refs_per_px = float(((modes == 1) | (modes == 2)).mean() + 2 * (modes == 3).mean())
         alg_bytes = {
             "iiwt_finest": 4 * samples,                     # 2 B read + 2 B written per sample
-            "iiwt_coarse": 4 * (samples // 4),
-            "obmc": int((2 + 1 + 1.6) * samples) + 20 * args.frames * wl.P["x_num_blocks"]
-                    * wl.P["y_num_blocks"],                 # residual + out + ~1.6 refs/px + MVs
+            # levels 1 and 2 are one launch each; the average launch moves (1/4 + 1/16) / 2
+            "iiwt_coarse": int(4 * samples * (0.25 + 0.0625) / 2),
+            # residual 2 B + output 1 B + 1 B per reference used + 20 B per block
+            "obmc": int((2 + 1 + refs_per_px) * samples) + 20 * args.frames
+                    * wl.P["x_num_blocks"] * wl.P["y_num_blocks"],
             "upsample": 2 * (W * H * 3 // 2) * 5,           # 1 B read + 4 B written, two refs
             "convert": 3 * samples,
         }
@@ -193,6 +198,18 @@ def main():
                               "alg_GBs": round(alg_bytes[k] / (avg * 1e-3) / 1e9, 1)}
         d_avg = prof[dom][0] / max(prof[dom][1], 1)
         achieved = alg_bytes[dom] / (d_avg * 1e-3) / 1e9
+        # the whole 3-level transform (north_star's figure): 4 B per sample of the plane,
+        # independent of depth, over the summed time of its launches in one step
+        iiwt_ms = (prof["iiwt_finest"][0] + prof["iiwt_coarse"][0]) / args.steps
+        kernels["iiwt_3_levels"] = {"avg_ms": round(iiwt_ms, 4), "launches": args.steps,
+                                    "alg_GBs": round(4 * samples / (iiwt_ms * 1e-3) / 1e9, 1),
+                                    "frac_of_8TBs": round(4 * samples / (iiwt_ms * 1e-3) / 1e9
+                                                          / HBM_PEAK_GBS, 4)}
+        # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/, collected offline)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
         out = {
             "metric": "Mpix/s IIWT+OBMC decode, 2160p s16",
             "value": round(value, 1), "unit": "Mpix/s",
@@ -206,7 +223,7 @@ def main():
                        "sharding": "pictures across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_ms": round(d_avg, 4)},
             "kernels": kernels,
         }

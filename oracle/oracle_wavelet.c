@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define ORACLE_RESTRICT __restrict__
+
 enum {
   K_ADD2_22,                    /* (s0+s1+2)>>2, every add wraps       orc_add2_rshift_{add,sub}_*_22 (schroorc.orc:4-73) */
   K_AVG11,                      /* (s0+s1+1)>>1 without wrap           orc_add2_rshift_{add,sub}_*_11 (:76-134) */

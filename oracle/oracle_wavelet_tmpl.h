@@ -57,46 +57,88 @@ FN (lift_term) (const Step * st, const T * s)
   return 0;
 }
 
-/* d[x] +/-= term(src rows) for a whole row; dir = +1 inverse, -1 forward */
+/* d[x] +/-= term(src rows) for a whole row; dir = +1 inverse, -1 forward.
+ * One plain loop per step kind so that the compiler can vectorise it (this file
+ * is also the CPU baseline bench.py prints next to the GPU number). */
+#define ROW_LOOP(EXPR)                                                        \
+  do {                                                                        \
+    if (sign > 0)                                                             \
+      for (x = 0; x < n; x++) { T t = (EXPR); d[x] = WRAP (WADD32 (d[x], t)); } \
+    else                                                                      \
+      for (x = 0; x < n; x++) { T t = (EXPR);                                 \
+        d[x] = WRAP ((int32_t) ((uint32_t) (int32_t) d[x] - (uint32_t) (int32_t) t)); } \
+  } while (0)
+
 static void
-FN (lift_row) (const Step * st, int dir, T * d, const T * const *src, int n)
+FN (lift_row) (const Step * st, int dir, T * ORACLE_RESTRICT d, const T * const *src, int n)
 {
-  int nt = ntaps (st->kind);
   int sign = st->sign * dir;
-  int x, k;
-  T s[8];
-  for (x = 0; x < n; x++) {
-    T t;
-    for (k = 0; k < nt; k++)
-      s[k] = src[k][x];
-    t = FN (lift_term) (st, s);
-    if (sign > 0)
-      d[x] = WRAP (WADD32 (d[x], t));
-    else
-      d[x] = WRAP ((int32_t) ((uint32_t) (int32_t) d[x] - (uint32_t) (int32_t) t));
+  int x;
+  const T *s0 = src[0], *s1 = src[1], *s2 = src[2], *s3 = src[3];
+  switch (st->kind) {
+    case K_ADD2_22:
+      ROW_LOOP ((T) (WRAP (WADD32 (WRAP (WADD32 (s0[x], s1[x])), 2)) >> 2));
+      break;
+    case K_AVG11:
+      ROW_LOOP ((T) AVG (s0[x], s1[x]));
+      break;
+    case K_MAS4:{
+      const int rnd = st->rnd, sh = st->sh;
+      ROW_LOOP (WRAP (WADD32 ((int32_t) ((uint32_t) WMUL (WRAP (WADD32 (s1[x], s2[x])), 9)
+                      - (uint32_t) (int32_t) WRAP (WADD32 (s0[x], s3[x]))), rnd) >> sh));
+      break;
+    }
+    case K_HAAR_HALF:
+      ROW_LOOP ((T) AVG (s0[x], 0));
+      break;
+    case K_HAAR_FULL:
+      ROW_LOOP (s0[x]);
+      break;
+    case K_MAS2:{
+      const int c = st->c, rnd = st->rnd, sh = st->sh;
+      ROW_LOOP (WRAP (WADD32 (WMUL (WRAP (WADD32 (s0[x], s1[x])), c), rnd) >> sh));
+      break;
+    }
+    default:{                  /* K_MAS8 */
+      T s[8];
+      int k;
+      for (x = 0; x < n; x++) {
+        T t;
+        for (k = 0; k < 8; k++)
+          s[k] = src[k][x];
+        t = FN (lift_term) (st, s);
+        if (sign > 0)
+          d[x] = WRAP (WADD32 (d[x], t));
+        else
+          d[x] = WRAP ((int32_t) ((uint32_t) (int32_t) d[x] - (uint32_t) (int32_t) t));
+      }
+      break;
+    }
   }
 }
 
-/* one lifting step over two 1-D arrays A[n], B[n] (horizontal direction) */
+#undef ROW_LOOP
+
+/* one lifting step over two 1-D arrays A[n], B[n] (horizontal direction): the
+ * other array is copied with 8 replicated samples on both sides (what extend_N_M
+ * does, schrowaveletorc.c:192-269) and the row kernel above runs on shifted views */
 static void
-FN (lift_1d) (const Step * st, int dir, T * A, T * B, int n)
+FN (lift_1d) (const Step * st, int dir, T * A, T * B, int n, T * pad)
 {
   int nt = ntaps (st->kind);
-  int sign = st->sign * dir;
   T *d = st->target ? B : A;
   const T *o = st->target ? A : B;
-  int i, k;
-  T s[8];
-  for (i = 0; i < n; i++) {
-    T t;
-    for (k = 0; k < nt; k++)
-      s[k] = o[clampi (i + st->off + k, 0, n - 1)];
-    t = FN (lift_term) (st, s);
-    if (sign > 0)
-      d[i] = WRAP (WADD32 (d[i], t));
-    else
-      d[i] = WRAP ((int32_t) ((uint32_t) (int32_t) d[i] - (uint32_t) (int32_t) t));
+  const T *src[8];
+  int k;
+  T *e = pad + 8;
+  memcpy (e, o, sizeof (T) * (size_t) n);
+  for (k = 1; k <= 8; k++) {
+    e[-k] = o[0];
+    e[n - 1 + k] = o[n - 1];
   }
+  for (k = 0; k < 8; k++)
+    src[k] = e + st->off + (k < nt ? k : 0);
+  FN (lift_row) (st, dir, d, src, n);
 }
 
 /* one lifting step vertically: A = even rows, B = odd rows of the view */
@@ -110,8 +152,8 @@ FN (lift_vert) (const Step * st, int dir, T * data, int stride, int width,
   const T *src[8];
   for (r = 0; r < n; r++) {
     T *d = (T *) ((char *) data + (size_t) stride * (2 * r + st->target));
-    for (k = 0; k < nt; k++) {
-      int rr = clampi (r + st->off + k, 0, n - 1);
+    for (k = 0; k < 8; k++) {
+      int rr = clampi (r + st->off + (k < nt ? k : 0), 0, n - 1);
       src[k] = (const T *) ((const char *) data +
           (size_t) stride * (2 * rr + (1 - st->target)));
     }
@@ -124,8 +166,9 @@ FN (iiwt_2d) (T * data, int stride, int width, int height, const Filter * f)
 {
   int k, y, i;
   int n = width / 2;
-  T *A = (T *) malloc (sizeof (T) * (size_t) width);
+  T *A = (T *) malloc (sizeof (T) * ((size_t) width + n + 16));
   T *B = A + n;
+  T *pad = A + width;
 
   for (k = 0; k < f->nsteps; k++)
     FN (lift_vert) (&f->steps[k], +1, data, stride, width, height);
@@ -135,7 +178,7 @@ FN (iiwt_2d) (T * data, int stride, int width, int height, const Filter * f)
     memcpy (A, line, sizeof (T) * (size_t) n);
     memcpy (B, line + n, sizeof (T) * (size_t) n);
     for (k = 0; k < f->nsteps; k++)
-      FN (lift_1d) (&f->steps[k], +1, A, B, n);
+      FN (lift_1d) (&f->steps[k], +1, A, B, n, pad);
     /* orc_interleave2_rrshift1_* (schroorc.orc:770-781,1866-1877): add wraps;
      * orc_haar_synth_rrshift1_int_* (:1000-1013): avgs*, no wrap;
      * orc_interleave2_* / orc_haar_synth_int_*: no shift. */
@@ -160,8 +203,9 @@ FN (iwt_2d) (T * data, int stride, int width, int height, const Filter * f)
 {
   int k, y, i;
   int n = width / 2;
-  T *A = (T *) malloc (sizeof (T) * (size_t) width);
+  T *A = (T *) malloc (sizeof (T) * ((size_t) width + n + 16));
   T *B = A + n;
+  T *pad = A + width;
 
   /* horizontal first (wavelet_iwt_*_horiz, e.g. schrowaveletorc.c:288-301):
    * orc_deinterleave2_lshift1_* for the filters with an output shift */
@@ -177,7 +221,7 @@ FN (iwt_2d) (T * data, int stride, int width, int height, const Filter * f)
       B[i] = b;
     }
     for (k = f->nsteps - 1; k >= 0; k--)
-      FN (lift_1d) (&f->steps[k], -1, A, B, n);
+      FN (lift_1d) (&f->steps[k], -1, A, B, n, pad);
     memcpy (line, A, sizeof (T) * (size_t) n);
     memcpy (line + n, B, sizeof (T) * (size_t) n);
   }
