@@ -391,8 +391,31 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
 
   int uc, ur;
   iiwt_tile_geometry (filter, bpp, &uc, &ur);
+
+  // SCHRO_HIP_IIWT_FUSE=2|3 runs the finest 2 or 3 levels as one fused launch when
+  // every plane allows aligned 8-byte sub-band loads at those levels; deeper levels,
+  // and everything by default, go level by level.  (Measured on 8x2160p the fused
+  // kernel is 10 % slower than three launches -- lower occupancy from its LDS -- so it
+  // is opt-in; it saves two launches on small pictures.)
+  int nl = 0;
+  {
+    const char *env = getenv ("SCHRO_HIP_IIWT_FUSE");
+    int want = env ? atoi (env) : 0;
+    nl = std::min (std::min (want, depth), iiwt_fused_max_levels (filter, bpp));
+    const int vl = 8 / bpp;
+    for (int p = 0; p < nplanes && nl >= 2; p++) {
+      const SchroHipIwtPlane & pl = planes[p];
+      if ((((uintptr_t) pl.src | (uintptr_t) pl.src_stride) & 7) != 0)
+        nl = 0;
+      while (nl >= 2 && (((pl.width >> nl) % vl) != 0 || (pl.width >> nl) < vl))
+        nl--;
+    }
+    if (nl < 2)
+      nl = 0;
+  }
+
   std::vector < IwtJob > jobs (nplanes);
-  for (int level = depth - 1; level >= 0; level--) {
+  for (int level = depth - 1; level >= nl; level--) {
     int tile_base = 0;
     for (int p = 0; p < nplanes; p++) {
       const SchroHipIwtPlane & pl = planes[p];
@@ -444,6 +467,35 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     {
       ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
       r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, nplanes, tile_base, filter, bpp);
+    }
+    if (r)
+      return r;
+  }
+
+  if (nl) {
+    const size_t jsz = iiwt_fused_job_size ();
+    std::vector < char >fj (jsz * nplanes);
+    int tile_base = 0;
+    for (int p = 0; p < nplanes; p++) {
+      const SchroHipIwtPlane & pl = planes[p];
+      const void *ll = pl.src;
+      int ll_stride = (pl.src_stride << (nl - 1)) * 2;
+      if (nl < depth) {
+        ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + nl];
+        ll_stride = scratch_stride[(size_t) p * depth + nl];
+      }
+      int tiles_x = div_up (pl.width / 2, uc);
+      iiwt_fused_job_fill (fj.data () + jsz * p, pl.src, pl.src_stride, bpp, nl, ll, ll_stride,
+          pl.dst, pl.dst_stride, pl.width, pl.height, tiles_x, tile_base);
+      tile_base += tiles_x * div_up (pl.height / 2, ur);
+    }
+    void *d_jobs;
+    int r = push_args (ctx, fj.data (), fj.size (), &d_jobs);
+    if (r)
+      return r;
+    {
+      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
+      r = launch_iiwt_fused (ctx->stream, d_jobs, nplanes, tile_base, filter, bpp, nl);
     }
     if (r)
       return r;

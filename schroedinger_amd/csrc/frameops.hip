@@ -28,16 +28,6 @@ clampi (int x, int lo, int hi)
   return min (max (x, lo), hi);
 }
 
-template < typename JOB >
-__device__ __forceinline__ int
-find_job (const JOB * jobs, int njobs, int bid)
-{
-  int j = 0;
-  while (j + 1 < njobs && bid >= jobs[j + 1].tile_base)
-    j++;
-  return j;
-}
-
 // ---- convert ---------------------------------------------------------------
 
 constexpr int kCvtTW = 512, kCvtTH = 4;

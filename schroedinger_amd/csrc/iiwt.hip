@@ -266,30 +266,113 @@ floor4 (int a)
   return a >= 0 ? a / 4 * 4 : -((-a + 3) / 4 * 4);
 }
 
+constexpr int
+ceil4 (int a)
+{
+  return -floor4 (-a);
+}
+
+__device__ __forceinline__ int
+floor_div2 (int a)
+{
+  return a >> 1;                // arithmetic shift: floor for negatives too
+}
+
+// ---- where the last lifting step puts its interleaved, rounded output ------------
+// to memory (the level's destination image)
+template < typename T > struct GlobalSink {
+  char *dst;
+  int dst_stride;               // bytes
+  int y0;                       // output row of tile row 0
+  int c0;                       // sub-band column of region column 0
+  int nc;                       // sub-band columns of the level
+  bool vec;                     // destination rows are 16-byte aligned
+
+  __device__ __forceinline__ void store (int yy, int i, const T * out) const
+  {
+    const int c = c0 + i;
+    if (c >= nc || c + 3 < 0)
+      return;
+    T *p = (T *) (dst + (size_t) (y0 + yy) * dst_stride) + 2 * c;
+    if (vec && c >= 0 && c + 4 <= nc) {
+      if constexpr (sizeof (T) == 2) {
+        uint4 pk;
+        pk.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
+        pk.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
+        pk.z = (uint16_t) out[4] | ((uint32_t) (uint16_t) out[5] << 16);
+        pk.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
+        *reinterpret_cast < uint4 * >(p) = pk;
+      } else {
+        reinterpret_cast < int4 * >(p)[0] = make_int4 (out[0], out[1], out[2], out[3]);
+        reinterpret_cast < int4 * >(p)[1] = make_int4 (out[4], out[5], out[6], out[7]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (c + k >= 0 && c + k < nc) {
+          p[2 * k] = out[2 * k];
+          p[2 * k + 1] = out[2 * k + 1];
+        }
+    }
+  }
+};
+
+// into the LL quadrant of the next finer level's LDS region (fused levels): output
+// sample (y, x) of this level is LL (row y, column x) of the finer level, which
+// lives at finer_lds[2 * (y - y_org)][x - x_org]
+template < typename T > struct LdsSink {
+  T *base;                      // &finer_lds[0][0]
+  int row_stride;               // elements between two LL rows (2 LDS rows)
+  int y_org, x_org;             // finer region origin (sub-band row pair / column)
+  int y_lo, y_hi, x_lo, x_hi;   // LL samples the finer region holds and the picture has
+  int y0, c0;                   // this level: output row of tile row 0, region column origin
+
+  __device__ __forceinline__ void store (int yy, int i, const T * out) const
+  {
+    const int y = y0 + yy;
+    if (y < y_lo || y >= y_hi)
+      return;
+    const int x0 = 2 * (c0 + i);
+    T *p = base + (y - y_org) * row_stride + (x0 - x_org);
+    if (x0 >= x_lo && x0 + 8 <= x_hi) {
+      struct __attribute__ ((aligned (4 * sizeof (T)))) T4 { T v[4]; };
+      T4 a = { {out[0], out[1], out[2], out[3]} }, b = { {out[4], out[5], out[6], out[7]} };
+      reinterpret_cast < T4 * >(p)[0] = a;
+      reinterpret_cast < T4 * >(p)[1] = b;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (x0 + k >= x_lo && x0 + k < x_hi)
+          p[k] = out[k];
+    }
+  }
+};
+
 // ---- horizontal lifting step on sample quads (i .. i+3), i a multiple of 4 -------
 // CLAMP == false: the region lies inside the picture; every quad of the row is
 // computed from 64/128-bit LDS reads.  Taps that fall off the region at its two
-// ends read neighbouring LDS words (always inside the array: rows 2H.. are never
-// the first or last row) and only spoil halo samples no useful output depends on.
+// ends read neighbouring LDS words and only spoil halo samples no useful output
+// depends on.
 // LAST == true: the filter's final step; the updated quad and its partner quad
-// from the other half are interleaved, rounded and stored straight to memory
-// (no LDS write-back, no separate output pass).
-template < typename T, int F, int K, int RP, int RC, int H, int HC, int UR, bool CLAMP, bool LAST >
+// from the other half are interleaved, rounded and handed to the sink (no LDS
+// write-back, no separate output pass); only quads QLO..QHI are visited.
+template < typename T, int F, int K, int RP, int RC, int H, int QLO_LAST, int QHI_LAST, bool CLAMP,
+    bool LAST, typename SINK >
 __device__ __forceinline__ void
-horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, const IwtJob & job,
-    int y0, int c0, int nc)
+horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, const SINK & sink)
 {
   struct __attribute__ ((aligned (4 * sizeof (T)))) T4 { T v[4]; };
   constexpr Step st = filter_step (F, K);
   constexpr int NT = kind_ntaps (st.kind);
   constexpr int SH = filter_shift (F);
-  constexpr int QLO = LAST ? HC / 4 : 0;
-  constexpr int QHI = LAST ? (RC - HC) / 4 - 1 : RC / 4 - 1;
+  constexpr int UR = RP - 2 * H;
+  constexpr int QLO = LAST ? QLO_LAST : 0;
+  constexpr int QHI = LAST ? QHI_LAST : RC / 4 - 1;
   constexpr int NQ = QHI - QLO + 1;
   // neighbour window: samples i+off .. i+off+NT+2, fetched as aligned 4-sample words
   constexpr int FIRST = floor4 (st.off);
   constexpr int NW = (st.off + NT + 2 - FIRST) / 4 + 1;
-  static_assert (RC % 4 == 0 && HC % 4 == 0, "quads need 4-aligned halves");
+  static_assert (RC % 4 == 0, "quads need 4-aligned halves");
 #pragma unroll 2
   for (int it = tid; it < 2 * UR * NQ; it += kThreads) {
     const int q = QLO + it % NQ;
@@ -325,9 +408,6 @@ horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, con
     if constexpr (!LAST) {
       *reinterpret_cast < T4 * >(d + i) = dv;
     } else {
-      const int c = c0 + i;
-      if (c >= nc || c + 3 < 0)
-        continue;
       // the partner quad o[i..i+3] lies inside the neighbour window for every filter
       static_assert (-st.off >= 0 && -st.off <= NT - 1, "partner quad outside the tap window");
       T out[8];
@@ -337,119 +417,35 @@ horizontal_step (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, con
         out[2 * k] = out_round < T, SH > (st.target ? ov : dv.v[k]);
         out[2 * k + 1] = out_round < T, SH > (st.target ? dv.v[k] : ov);
       }
-      T *dst = (T *) ((char *) job.dst + (size_t) (y0 + yy) * job.dst_stride) + 2 * c;
-      if ((job.flags & 2) && c >= 0 && c + 4 <= nc) {
-        if constexpr (sizeof (T) == 2) {
-          uint4 pk;
-          pk.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
-          pk.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
-          pk.z = (uint16_t) out[4] | ((uint32_t) (uint16_t) out[5] << 16);
-          pk.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
-          *reinterpret_cast < uint4 * >(dst) = pk;
-        } else {
-          reinterpret_cast < int4 * >(dst)[0] = make_int4 (out[0], out[1], out[2], out[3]);
-          reinterpret_cast < int4 * >(dst)[1] = make_int4 (out[4], out[5], out[6], out[7]);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (c + k >= 0 && c + k < nc) {
-            dst[2 * k] = out[2 * k];
-            dst[2 * k + 1] = out[2 * k + 1];
-          }
-      }
+      sink.store (yy, i, out);
     }
   }
 }
 
-template < typename T, int F, int K, bool CLAMP, typename LDS >
+template < typename T, int F, int K, int RP, int RC, int H, int QLO, int QHI, bool CLAMP, typename SINK >
 __device__ __forceinline__ void
-hstep (LDS lds, int tid, int hlo, int hhi, int rows_here, const IwtJob & job, int y0, int c0, int nc)
+hstep (T (*lds)[2 * RC], int tid, int hlo, int hhi, int rows_here, const SINK & sink)
 {
-  typedef Geo < T, F > G;
   constexpr bool LAST = K == filter_nsteps (F) - 1;
-  horizontal_step < T, F, K, G::RP, G::RC, G::H, G::HC, G::UR, CLAMP, LAST > (lds, tid, hlo, hhi,
-      rows_here, job, y0, c0, nc);
+  horizontal_step < T, F, K, RP, RC, H, QLO, QHI, CLAMP, LAST, SINK > (lds, tid, hlo, hhi,
+      rows_here, sink);
   if constexpr (!LAST)
     __syncthreads ();
 }
 
-template < typename T, int F >
-__global__ __launch_bounds__ (kThreads)
-void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
+// All lifting passes of one level on a staged region: vertical steps in place,
+// horizontal steps on the rows whose vertical result is valid, the last one
+// feeding the sink.  (r0, c0): sub-band row pair / column of the region origin.
+template < typename T, int F, int RP, int RC, int QLO, int QHI, typename SINK >
+__device__ __forceinline__ void
+lift_region (T (*lds)[2 * RC], int tid, int r0, int c0, int nr, int nc, const SINK & sink)
 {
-  typedef Geo < T, F > G;
-  constexpr int RP = G::RP, RC = G::RC, H = G::H, HC = G::HC, UR = G::UR, UC = G::UC;
-  constexpr int VL = 8 / sizeof (T);    // samples per 8-byte vector
-  constexpr int NG = RC / VL;           // 8-byte groups per half row
-  __shared__ __attribute__ ((aligned (16))) T lds[2 * RP][2 * RC];
-
-  const int tid = threadIdx.x;
-  int j = 0;
-  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  while (j + 1 < njobs && bid >= jobs[j + 1].tile_base)
-    j++;
-  const IwtJob job = jobs[j];
-  const int t = bid - job.tile_base;
-  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
-  const int nr = job.h >> 1, nc = job.w >> 1;
-  const int r0 = ty * UR - H;   // sub-band row of region row pair 0
-  const int c0 = tx * UC - HC;  // sub-band column of region column 0
+  constexpr int H = filter_halo (F);
+  constexpr int UR = RP - 2 * H;
   // region-local index range that exists in the picture
   const int vlo = max (0, -r0), vhi = min (RP - 1, nr - 1 - r0);
   const int hlo = max (0, -c0), hhi = min (RC - 1, nc - 1 - c0);
 
-  // ---- stage the four sub-bands of the region in LDS ----------------------
-  if (job.flags & 1) {
-    // sub-band index and LDS half are compile-time per load (no runtime-indexed
-    // job fields), all loads are issued before the first LDS write
-    constexpr int NPS = (RP * NG + kThreads - 1) / kThreads;    // loads per thread per sub-band
-    uint2 v[4][NPS];
-#pragma unroll
-    for (int sb = 0; sb < 4; sb++) {
-      const char *base = (const char *) job.sb[sb];
-      const int stride = job.sb_stride[sb];
-#pragma unroll
-      for (int n = 0; n < NPS; n++) {
-        int it = min (tid + n * kThreads, RP * NG - 1);
-        int g = it % NG;
-        int rp = it / NG;
-        int r = clampi (r0 + rp, 0, nr - 1);
-        int c = clampi (c0 + g * VL, 0, nc - VL);
-        v[sb][n] = *reinterpret_cast < const uint2 * >(base + (size_t) r * stride
-            + (size_t) c * sizeof (T));
-      }
-    }
-#pragma unroll
-    for (int sb = 0; sb < 4; sb++) {
-#pragma unroll
-      for (int n = 0; n < NPS; n++) {
-        int it = tid + n * kThreads;
-        if (it < RP * NG) {
-          int g = it % NG;
-          int rp = it / NG;
-          *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[sb][n];
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int sb = 0; sb < 4; sb++) {
-      const char *base = (const char *) job.sb[sb];
-      const int stride = job.sb_stride[sb];
-      for (int it = tid; it < RP * RC; it += kThreads) {
-        int c = it % RC;
-        int rp = it / RC;
-        int r = r0 + rp, cc = c0 + c;
-        if (r >= 0 && r < nr && cc >= 0 && cc < nc)
-          lds[2 * rp + (sb >> 1)][(sb & 1) * RC + c] =
-              ((const T *) (base + (size_t) r * stride))[cc];
-      }
-    }
-  }
-  __syncthreads ();
-
-  // ---- vertical lifting steps (A = even rows, B = odd rows) ----------------
   if (vlo > 0 || vhi < RP - 1) {        // region sticks out of the picture: clamp rows
     vertical_step < T, F, 0, RP, RC, true > (lds, tid, vlo, vhi);
     __syncthreads ();
@@ -474,25 +470,264 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
     }
   }
 
-  // ---- horizontal lifting steps on the rows this tile outputs; the last one
-  // interleaves, rounds and stores ---------------------------------------------
-  const int y0 = 2 * (r0 + H);  // first output row of the tile
-  const int rows_here = min (2 * UR, job.h - y0);
+  const int rows_here = min (2 * UR, 2 * nr - 2 * (r0 + H));    // rows inside the picture
   if (hlo > 0 || hhi < RC - 1) {
-    hstep < T, F, 0, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
-    hstep < T, F, 1, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    hstep < T, F, 0, RP, RC, H, QLO, QHI, true > (lds, tid, hlo, hhi, rows_here, sink);
+    hstep < T, F, 1, RP, RC, H, QLO, QHI, true > (lds, tid, hlo, hhi, rows_here, sink);
     if constexpr (filter_nsteps (F) == 4) {
-      hstep < T, F, 2, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
-      hstep < T, F, 3, true > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+      hstep < T, F, 2, RP, RC, H, QLO, QHI, true > (lds, tid, hlo, hhi, rows_here, sink);
+      hstep < T, F, 3, RP, RC, H, QLO, QHI, true > (lds, tid, hlo, hhi, rows_here, sink);
     }
   } else {
-    hstep < T, F, 0, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
-    hstep < T, F, 1, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+    hstep < T, F, 0, RP, RC, H, QLO, QHI, false > (lds, tid, hlo, hhi, rows_here, sink);
+    hstep < T, F, 1, RP, RC, H, QLO, QHI, false > (lds, tid, hlo, hhi, rows_here, sink);
     if constexpr (filter_nsteps (F) == 4) {
-      hstep < T, F, 2, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
-      hstep < T, F, 3, false > (lds, tid, hlo, hhi, rows_here, job, y0, c0, nc);
+      hstep < T, F, 2, RP, RC, H, QLO, QHI, false > (lds, tid, hlo, hhi, rows_here, sink);
+      hstep < T, F, 3, RP, RC, H, QLO, QHI, false > (lds, tid, hlo, hhi, rows_here, sink);
     }
   }
+}
+
+// Issue the 8-byte loads of one sub-band of a region (coordinates clamped into the
+// picture; cells outside it are never read back) and, later, put them in LDS.
+template < typename T, int RP, int RC, int NPS >
+__device__ __forceinline__ void
+band_load (uint2 * v, const void *base_, int stride, int tid, int r0, int c0, int nr, int nc)
+{
+  constexpr int VL = 8 / sizeof (T), NG = RC / VL;
+  const char *base = (const char *) base_;
+#pragma unroll
+  for (int n = 0; n < NPS; n++) {
+    int it = min (tid + n * kThreads, RP * NG - 1);
+    int g = it % NG;
+    int rp = it / NG;
+    int rr = clampi (r0 + rp, 0, nr - 1);
+    int c = clampi (c0 + g * VL, 0, nc - VL);
+    v[n] = *reinterpret_cast < const uint2 * >(base + (size_t) rr * stride + (size_t) c * sizeof (T));
+  }
+}
+
+template < typename T, int RP, int RC, int NPS >
+__device__ __forceinline__ void
+band_store (T (*lds)[2 * RC], const uint2 * v, int sb, int tid)
+{
+  constexpr int VL = 8 / sizeof (T), NG = RC / VL;
+#pragma unroll
+  for (int n = 0; n < NPS; n++) {
+    int it = tid + n * kThreads;
+    if (it < RP * NG) {
+      int g = it % NG;
+      int rp = it / NG;
+      *reinterpret_cast < uint2 * >(&lds[2 * rp + (sb >> 1)][(sb & 1) * RC + g * VL]) = v[n];
+    }
+  }
+}
+
+template < typename T, int RP, int RC >
+constexpr int
+band_nps ()
+{
+  return (RP * (RC / (8 / (int) sizeof (T))) + kThreads - 1) / kThreads;
+}
+
+template < typename T, int F >
+__global__ __launch_bounds__ (kThreads)
+void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
+{
+  typedef Geo < T, F > G;
+  constexpr int RP = G::RP, RC = G::RC, H = G::H, HC = G::HC, UR = G::UR, UC = G::UC;
+  constexpr int NPS = band_nps < T, RP, RC > ();
+  __shared__ __attribute__ ((aligned (16))) T lds[2 * RP][2 * RC];
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const IwtJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  const int nr = job.h >> 1, nc = job.w >> 1;
+  const int r0 = ty * UR - H;   // sub-band row of region row pair 0
+  const int c0 = tx * UC - HC;  // sub-band column of region column 0
+
+  // ---- stage the four sub-bands of the region in LDS ----------------------
+  if (job.flags & 1) {
+    // all loads are issued before the first LDS write
+    uint2 v[4][NPS];
+    band_load < T, RP, RC, NPS > (v[0], job.sb[0], job.sb_stride[0], tid, r0, c0, nr, nc);
+    band_load < T, RP, RC, NPS > (v[1], job.sb[1], job.sb_stride[1], tid, r0, c0, nr, nc);
+    band_load < T, RP, RC, NPS > (v[2], job.sb[2], job.sb_stride[2], tid, r0, c0, nr, nc);
+    band_load < T, RP, RC, NPS > (v[3], job.sb[3], job.sb_stride[3], tid, r0, c0, nr, nc);
+    band_store < T, RP, RC, NPS > (lds, v[0], 0, tid);
+    band_store < T, RP, RC, NPS > (lds, v[1], 1, tid);
+    band_store < T, RP, RC, NPS > (lds, v[2], 2, tid);
+    band_store < T, RP, RC, NPS > (lds, v[3], 3, tid);
+  } else {
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) {
+      const char *base = (const char *) job.sb[sb];
+      const int stride = job.sb_stride[sb];
+      for (int it = tid; it < RP * RC; it += kThreads) {
+        int c = it % RC;
+        int rp = it / RC;
+        int r = r0 + rp, cc = c0 + c;
+        if (r >= 0 && r < nr && cc >= 0 && cc < nc)
+          lds[2 * rp + (sb >> 1)][(sb & 1) * RC + c] =
+              ((const T *) (base + (size_t) r * stride))[cc];
+      }
+    }
+  }
+  __syncthreads ();
+
+  GlobalSink < T > sink;
+  sink.dst = (char *) job.dst;
+  sink.dst_stride = job.dst_stride;
+  sink.y0 = 2 * (r0 + H);
+  sink.c0 = c0;
+  sink.nc = nc;
+  sink.vec = (job.flags & 2) != 0;
+  lift_region < T, F, RP, RC, HC / 4, (RC - HC) / 4 - 1 > (lds, tid, r0, c0, nr, nc, sink);
+}
+
+// ---- fused levels ---------------------------------------------------------------
+// One workgroup produces a level-0 tile from the sub-bands of NL levels: the coarser
+// levels are computed for exactly the LL region (plus lifting halo) the next finer
+// level's region needs and land directly in that region's LL quadrant in LDS.  The LL
+// images of the fused levels never exist in memory, and NL launches become one.
+// Region geometry per fused level L (0 = finest), all compile-time:
+//   rows:    RP_L = RP_{L-1}/2 + 1 + 2H row pairs, origin floor (r0_{L-1} / 2) - H
+//   columns: origin tx * (UC0 >> L) + O_L with O_L a multiple of 4 (8-byte loads stay
+//            aligned) far enough left for the halo, RC_L columns up to the halo on the right
+template < typename T, int F, int L > struct FGeo {
+  typedef FGeo < T, F, L - 1 > P;
+  static constexpr int H = filter_halo (F);
+  static constexpr int RP = P::RP / 2 + 1 + 2 * H;
+  static constexpr int CB = P::CB / 2;                  // column pitch of tiles at this level
+  static constexpr int S = P::O / 2;                    // first LL column the finer region needs
+  static constexpr int O = floor4 (S - H);
+  static constexpr int RC = ceil4 (S + P::RC / 2 + H - O);
+};
+template < typename T, int F > struct FGeo < T, F, 0 > {
+  typedef Geo < T, F > G;
+  static constexpr int H = G::H;
+  static constexpr int RP = G::RP;
+  static constexpr int CB = G::UC;
+  static constexpr int O = -G::HC;
+  static constexpr int RC = G::RC;
+};
+
+struct IwtFusedJob {
+  const void *band[3][3];       // [level][HL, LH, HH]: element (0,0) of each sub-band
+  int bstride[3];               // bytes between sub-band rows, per level
+  int ll_stride;
+  const void *ll;               // LL of the coarsest fused level
+  void *dst;
+  int dst_stride;
+  int w, h;                     // level-0 output size
+  int tiles_x;
+  int tile_base;
+  int flags;                    // bit1: dst 16-byte aligned
+};
+
+template < typename T, int F, int NL >
+__global__ __launch_bounds__ (kThreads)
+void iiwt_fused_kernel (const IwtFusedJob * __restrict__ jobs, int njobs)
+{
+  typedef FGeo < T, F, 0 > G0;
+  typedef FGeo < T, F, 1 > G1;
+  typedef FGeo < T, F, NL == 3 ? 2 : 1 > G2;    // only used when NL == 3
+  constexpr int H = G0::H, UR0 = G0::RP - 2 * H;
+  constexpr int NPS0 = band_nps < T, G0::RP, G0::RC > ();
+  constexpr int NPS1 = band_nps < T, G1::RP, G1::RC > ();
+  constexpr int NPS2 = band_nps < T, G2::RP, G2::RC > ();
+  __shared__ __attribute__ ((aligned (16))) T lds0[2 * G0::RP][2 * G0::RC];
+  __shared__ __attribute__ ((aligned (16))) T lds1[2 * G1::RP][2 * G1::RC];
+  __shared__ __attribute__ ((aligned (16))) T lds2[NL == 3 ? 2 * G2::RP : 1][2 * G2::RC];
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const IwtFusedJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  // per level: sub-band rows / columns of the picture, region origin
+  const int nr0 = job.h >> 1, nc0 = job.w >> 1;
+  const int nr1 = job.h >> 2, nc1 = job.w >> 2;
+  const int nr2 = job.h >> 3, nc2 = job.w >> 3;
+  const int r00 = ty * UR0 - H, c00 = tx * G0::CB + G0::O;
+  const int r01 = floor_div2 (r00) - H, c01 = tx * G1::CB + G1::O;
+  const int r02 = floor_div2 (r01) - H, c02 = tx * G2::CB + G2::O;
+
+  // ---- every sub-band load of all fused levels goes out first ------------------
+  uint2 v0[3][NPS0], v1[3][NPS1], v2[4][NPS2];
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    band_load < T, G0::RP, G0::RC, NPS0 > (v0[b], job.band[0][b], job.bstride[0], tid, r00, c00, nr0, nc0);
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    band_load < T, G1::RP, G1::RC, NPS1 > (v1[b], job.band[1][b], job.bstride[1], tid, r01, c01, nr1, nc1);
+  if constexpr (NL == 3) {
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+      band_load < T, G2::RP, G2::RC, NPS2 > (v2[b + 1], job.band[2][b], job.bstride[2], tid, r02, c02, nr2, nc2);
+    band_load < T, G2::RP, G2::RC, NPS2 > (v2[0], job.ll, job.ll_stride, tid, r02, c02, nr2, nc2);
+  } else {
+    band_load < T, G1::RP, G1::RC, NPS1 > (v2[0], job.ll, job.ll_stride, tid, r01, c01, nr1, nc1);
+  }
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    band_store < T, G0::RP, G0::RC, NPS0 > (lds0, v0[b], b + 1, tid);
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    band_store < T, G1::RP, G1::RC, NPS1 > (lds1, v1[b], b + 1, tid);
+  if constexpr (NL == 3) {
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      band_store < T, G2::RP, G2::RC, NPS2 > (lds2, v2[b], b, tid);
+  } else {
+    static_assert (NPS2 == NPS1 || NL == 3, "LL staging of the 2-level form reuses v2[0]");
+    band_store < T, G1::RP, G1::RC, NPS1 > (lds1, v2[0], 0, tid);
+  }
+  __syncthreads ();
+
+  if constexpr (NL == 3) {
+    // level 2 -> LL quadrant of the level-1 region
+    LdsSink < T > s2;
+    s2.base = &lds1[0][0];
+    s2.row_stride = 2 * 2 * G1::RC;
+    s2.y_org = r01;
+    s2.x_org = c01;
+    s2.y_lo = max (r01, 0);
+    s2.y_hi = min (r01 + G1::RP, nr1);
+    s2.x_lo = max (c01, 0);
+    s2.x_hi = min (c01 + G1::RC, nc1);
+    s2.y0 = 2 * (r02 + H);
+    s2.c0 = c02;
+    lift_region < T, F, G2::RP, G2::RC, 0, G2::RC / 4 - 1 > (lds2, tid, r02, c02, nr2, nc2, s2);
+    __syncthreads ();
+  }
+  {
+    // level 1 -> LL quadrant of the level-0 region
+    LdsSink < T > s1;
+    s1.base = &lds0[0][0];
+    s1.row_stride = 2 * 2 * G0::RC;
+    s1.y_org = r00;
+    s1.x_org = c00;
+    s1.y_lo = max (r00, 0);
+    s1.y_hi = min (r00 + G0::RP, nr0);
+    s1.x_lo = max (c00, 0);
+    s1.x_hi = min (c00 + G0::RC, nc0);
+    s1.y0 = 2 * (r01 + H);
+    s1.c0 = c01;
+    lift_region < T, F, G1::RP, G1::RC, 0, G1::RC / 4 - 1 > (lds1, tid, r01, c01, nr1, nc1, s1);
+    __syncthreads ();
+  }
+  GlobalSink < T > sink;
+  sink.dst = (char *) job.dst;
+  sink.dst_stride = job.dst_stride;
+  sink.y0 = 2 * (r00 + H);
+  sink.c0 = c00;
+  sink.nc = nc0;
+  sink.vec = (job.flags & 2) != 0;
+  constexpr int HC0 = -G0::O;
+  lift_region < T, F, G0::RP, G0::RC, HC0 / 4, (G0::RC - HC0) / 4 - 1 > (lds0, tid, r00, c00, nr0, nc0, sink);
 }
 
 template < typename T, int F >
@@ -504,6 +739,76 @@ launch_one (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tile
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "iiwt launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+template < typename T, int F, int NL >
+constexpr size_t
+fused_lds_bytes ()
+{
+  size_t b = sizeof (T) * 4 * FGeo < T, F, 0 >::RP * FGeo < T, F, 0 >::RC
+      + sizeof (T) * 4 * FGeo < T, F, 1 >::RP * FGeo < T, F, 1 >::RC;
+  if (NL == 3)
+    b += sizeof (T) * 4 * FGeo < T, F, 2 >::RP * FGeo < T, F, 2 >::RC;
+  return b;
+}
+
+// how many of the finest levels one launch can fuse for this filter / sample type:
+// bounded by the 64 KB of LDS a workgroup may declare; the 8-tap fidelity filter's
+// halo of 7 makes the coarse regions mostly halo, so it is never fused
+template < typename T, int F >
+constexpr int
+fused_max_levels ()
+{
+  if (F == 5)
+    return 0;
+  if (fused_lds_bytes < T, F, 3 > () <= 65536)
+    return 3;
+  if (fused_lds_bytes < T, F, 2 > () <= 65536)
+    return 2;
+  return 0;
+}
+
+template < typename T, int F >
+int
+launch_fused_one (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles, int nl)
+{
+  constexpr int MAXL = fused_max_levels < T, F > ();
+  bool launched = false;
+  if constexpr (MAXL >= 3) {
+    if (nl == 3) {
+      hipLaunchKernelGGL ((iiwt_fused_kernel < T, F, 3 >), dim3 (total_tiles), dim3 (kThreads), 0,
+          stream, (const IwtFusedJob *) d_jobs, njobs);
+      launched = true;
+    }
+  }
+  if constexpr (MAXL >= 2) {
+    if (nl == 2) {
+      hipLaunchKernelGGL ((iiwt_fused_kernel < T, F, 2 >), dim3 (total_tiles), dim3 (kThreads), 0,
+          stream, (const IwtFusedJob *) d_jobs, njobs);
+      launched = true;
+    }
+  }
+  if (!launched)
+    return set_error (SCHRO_HIP_EINVAL, "fused iiwt: %d levels not available for filter %d", nl, F);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "fused iiwt launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+template < typename T >
+int
+fused_levels_of (int filter)
+{
+  switch (filter) {
+    case 0: return fused_max_levels < T, 0 > ();
+    case 1: return fused_max_levels < T, 1 > ();
+    case 2: return fused_max_levels < T, 2 > ();
+    case 3: return fused_max_levels < T, 3 > ();
+    case 4: return fused_max_levels < T, 4 > ();
+    case 6: return fused_max_levels < T, 6 > ();
+  }
   return 0;
 }
 
@@ -519,6 +824,22 @@ launch_filter (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_t
     case 4: return launch_one < T, 4 > (stream, d_jobs, njobs, total_tiles);
     case 5: return launch_one < T, 5 > (stream, d_jobs, njobs, total_tiles);
     case 6: return launch_one < T, 6 > (stream, d_jobs, njobs, total_tiles);
+  }
+  return set_error (SCHRO_HIP_EINVAL, "wavelet filter index %d out of range", filter);
+}
+
+template < typename T >
+int
+launch_fused_filter (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles, int filter, int nl)
+{
+  switch (filter) {
+    case 0: return launch_fused_one < T, 0 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 1: return launch_fused_one < T, 1 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 2: return launch_fused_one < T, 2 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 3: return launch_fused_one < T, 3 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 4: return launch_fused_one < T, 4 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 5: return launch_fused_one < T, 5 > (stream, d_jobs, njobs, total_tiles, nl);
+    case 6: return launch_fused_one < T, 6 > (stream, d_jobs, njobs, total_tiles, nl);
   }
   return set_error (SCHRO_HIP_EINVAL, "wavelet filter index %d out of range", filter);
 }
@@ -556,6 +877,56 @@ launch_iiwt_level (hipStream_t stream, const IwtJob * d_jobs, int njobs, int tot
   if (bpp == 2)
     return launch_filter < int16_t > (stream, d_jobs, njobs, total_tiles, filter);
   return launch_filter < int32_t > (stream, d_jobs, njobs, total_tiles, filter);
+}
+
+size_t
+iiwt_fused_job_size (void)
+{
+  return sizeof (IwtFusedJob);
+}
+
+int
+iiwt_fused_max_levels (int filter, int bpp)
+{
+  return bpp == 2 ? fused_levels_of < int16_t > (filter) : fused_levels_of < int32_t > (filter);
+}
+
+// fills one fused job (host side); levels 0 .. nl-1 of `src` are fused, `ll` is the LL
+// image of level nl-1 (the coefficient frame itself when nl == depth)
+void
+iiwt_fused_job_fill (void *job_, const void *src, int src_stride, int bpp, int nl, const void *ll,
+    int ll_stride, void *dst, int dst_stride, int w, int h, int tiles_x, int tile_base)
+{
+  IwtFusedJob *j = (IwtFusedJob *) job_;
+  const char *base = (const char *) src;
+  for (int l = 0; l < 3; l++) {
+    const int lv = l < nl ? l : nl - 1;
+    const int vstride = src_stride << lv;
+    const int wl = w >> lv;
+    // level view {w >> l, h >> l, stride << l}, sub-band positions schroparams.c:319-352
+    j->band[l][0] = base + (size_t) (wl / 2) * bpp;                     // HL
+    j->band[l][1] = base + vstride;                                     // LH
+    j->band[l][2] = base + vstride + (size_t) (wl / 2) * bpp;           // HH
+    j->bstride[l] = vstride * 2;
+  }
+  j->ll = ll;
+  j->ll_stride = ll_stride;
+  j->dst = dst;
+  j->dst_stride = dst_stride;
+  j->w = w;
+  j->h = h;
+  j->tiles_x = tiles_x;
+  j->tile_base = tile_base;
+  j->flags = ((((uintptr_t) dst | (uintptr_t) dst_stride) & 15) == 0) ? 2 : 0;
+}
+
+int
+launch_iiwt_fused (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles, int filter,
+    int bpp, int nl)
+{
+  if (bpp == 2)
+    return launch_fused_filter < int16_t > (stream, d_jobs, njobs, total_tiles, filter, nl);
+  return launch_fused_filter < int32_t > (stream, d_jobs, njobs, total_tiles, filter, nl);
 }
 
 }                               // namespace schro

@@ -99,10 +99,7 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  int j = 0;
-  while (j + 1 < njobs && bid >= jobs[j + 1].tile_base)
-    j++;
-  const ObmcJob job = jobs[j];
+  const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
   const int tid = threadIdx.x;
@@ -458,10 +455,7 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   __shared__ int s_cnt[4];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  int jn = 0;
-  while (jn + 1 < njobs && bid >= jobs[jn + 1].tile_base)
-    jn++;
-  const ObmcJob job = jobs[jn];
+  const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
   const int tid = threadIdx.x;

@@ -95,11 +95,38 @@ xcd_tile_id (int bid, int nblocks)
   const int x = bid % kXcd, k = bid / kXcd;
   return x * q + (x < r ? x : r) + k;
 }
+
+// Which job owns workgroup tile `bid`: the jobs' tile_base values ascend from 0, so the
+// answer is (number of jobs with tile_base <= bid) - 1.  The lanes of the wave probe 64
+// jobs at a time (one memory round trip instead of a chain of dependent scalar loads,
+// which cost ~6.6k cycles per workgroup for the 24 planes of 8 pictures).
+template < typename JOB >
+__device__ __forceinline__ int
+find_job (const JOB * jobs, int njobs, int bid)
+{
+  const int lane = threadIdx.x & 63;
+  int n = 0;
+  for (int base = 0; base < njobs; base += 64) {
+    const int idx = base + lane;
+    const bool le = idx < njobs && jobs[idx].tile_base <= bid;
+    n += __popcll (__ballot (le));
+  }
+  return __builtin_amdgcn_readfirstlane (n - 1);
+}
 #endif
 
 // launchers (one per .hip file)
 int launch_iiwt_level (hipStream_t stream, const IwtJob * d_jobs, int njobs,
     int total_tiles, int filter, int bpp);
+
+// fused finest levels (iiwt.hip): one launch runs levels nl-1 .. 0
+size_t iiwt_fused_job_size (void);
+int iiwt_fused_max_levels (int filter, int bpp);
+void iiwt_fused_job_fill (void *job, const void *src, int src_stride, int bpp, int nl,
+    const void *ll, int ll_stride, void *dst, int dst_stride, int w, int h, int tiles_x,
+    int tile_base);
+int launch_iiwt_fused (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles,
+    int filter, int bpp, int nl);
 void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
     int *useful_row_pairs);
 int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,

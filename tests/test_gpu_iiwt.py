@@ -70,6 +70,20 @@ def test_baseline_sizes_s16(ctx, filt, depth, h, w):
     assert np.array_equal(got, img)
 
 
+@pytest.mark.parametrize("fuse", ["2", "3"])
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 6])
+def test_fused_levels(ctx, filt, dtype, fuse, monkeypatch):
+    # SCHRO_HIP_IIWT_FUSE: the finest 2 / 3 levels in one launch; same answer
+    monkeypatch.setenv("SCHRO_HIP_IIWT_FUSE", fuse)
+    for (h, w, depth) in [(48, 64, 3), (240, 320, 4), (136, 248, 3), (272, 480, 2), (544, 960, 3)]:
+        img = synth.image_s(h, w, dtype, seed=17)
+        co = O.forward_iwt(img, depth, filt)
+        assert np.array_equal(gpu_iiwt(ctx, co, depth, filt), O.inverse_iwt(co, depth, filt)), (h, w, depth)
+        fr = synth.full_range(h, w, dtype, seed=19)
+        assert np.array_equal(gpu_iiwt(ctx, fr, depth, filt), O.inverse_iwt(fr, depth, filt))
+
+
 def test_baseline_size_s32_haar0(ctx):
     # BASELINE config 4 shape class: s32, Haar (no shift), 4:2:2 chroma plane 3840x4320 is
     # large for the CPU oracle; one 3840x2160 s32 plane pins the kernel, the full-size case is
