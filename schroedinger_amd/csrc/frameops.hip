@@ -64,10 +64,10 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
   if (vec) {
     T v[8];
     if constexpr (sizeof (T) == 2) {
-      *reinterpret_cast < uint4 * >(v) = *reinterpret_cast < const uint4 * >(s);
+      *reinterpret_cast < u32x4 * >(v) = gload < u32x4 > (s);
     } else {
-      reinterpret_cast < uint4 * >(v)[0] = reinterpret_cast < const uint4 * >(s)[0];
-      reinterpret_cast < uint4 * >(v)[1] = reinterpret_cast < const uint4 * >(s)[1];
+      reinterpret_cast < u32x4 * >(v)[0] = gload < u32x4 > (s);
+      reinterpret_cast < u32x4 * >(v)[1] = gload < u32x4 > (s + 4);
     }
     uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -75,10 +75,10 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
       lo |= (uint32_t) offsetconvert < T > (v[e]) << (8 * e);
       hi |= (uint32_t) offsetconvert < T > (v[4 + e]) << (8 * e);
     }
-    *reinterpret_cast < uint2 * >(d) = make_uint2 (lo, hi);
+    gstore < u32x2 > (d, (u32x2) { lo, hi });
   } else {
     for (int e = 0; e < 8 && x + e < job.w; e++)
-      d[e] = offsetconvert < T > (s[e]);
+      gstore < uint8_t > (d + e, offsetconvert < T > (gload < T > (s + e)));
   }
 }
 
@@ -165,12 +165,12 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     const uint8_t *row = job.src + (size_t) gy * job.src_stride;
     uint32_t d;
     if (src_al && gx >= 0 && gx + 4 <= w) {
-      d = *reinterpret_cast < const uint32_t * >(row + gx);
+      d = gload < uint32_t > (row + gx);
     } else {
       d = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        d |= (uint32_t) row[clampi (gx + k, 0, w - 1)] << (8 * k);
+        d |= (uint32_t) gload < uint8_t > (row + clampi (gx + k, 0, w - 1)) << (8 * k);
     }
     s0[ly][g] = d;
   }
@@ -232,13 +232,13 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     uint8_t *de = job.dst + (size_t) (2 * gy) * job.dst_stride + 2 * gx;
     uint8_t *dod = de + job.dst_stride;
     if (gx + 4 <= w && (((uintptr_t) de | (uintptr_t) dod) & 7) == 0) {
-      *reinterpret_cast < uint2 * >(de) = even;
-      *reinterpret_cast < uint2 * >(dod) = odd;
+      gstore < u32x2 > (de, (u32x2) { even.x, even.y });
+      gstore < u32x2 > (dod, (u32x2) { odd.x, odd.y });
     } else {
       const uint64_t ev = even.x | ((uint64_t) even.y << 32), ov = odd.x | ((uint64_t) odd.y << 32);
       for (int e = 0; e < 8 && gx + e / 2 < w; e++) {
-        de[e] = (uint8_t) (ev >> (8 * e));
-        dod[e] = (uint8_t) (ov >> (8 * e));
+        gstore < uint8_t > (de + e, (uint8_t) (ev >> (8 * e)));
+        gstore < uint8_t > (dod + e, (uint8_t) (ov >> (8 * e)));
       }
     }
   }

@@ -296,22 +296,22 @@ template < typename T > struct GlobalSink {
     T *p = (T *) (dst + (size_t) (y0 + yy) * dst_stride) + 2 * c;
     if (vec && c >= 0 && c + 4 <= nc) {
       if constexpr (sizeof (T) == 2) {
-        uint4 pk;
+        u32x4 pk;
         pk.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
         pk.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
         pk.z = (uint16_t) out[4] | ((uint32_t) (uint16_t) out[5] << 16);
         pk.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
-        *reinterpret_cast < uint4 * >(p) = pk;
+        gstore < u32x4 > (p, pk);
       } else {
-        reinterpret_cast < int4 * >(p)[0] = make_int4 (out[0], out[1], out[2], out[3]);
-        reinterpret_cast < int4 * >(p)[1] = make_int4 (out[4], out[5], out[6], out[7]);
+        gstore < u32x4 > (p, (u32x4) { (uint32_t) out[0], (uint32_t) out[1], (uint32_t) out[2], (uint32_t) out[3] });
+        gstore < u32x4 > (p + 4, (u32x4) { (uint32_t) out[4], (uint32_t) out[5], (uint32_t) out[6], (uint32_t) out[7] });
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; k++)
         if (c + k >= 0 && c + k < nc) {
-          p[2 * k] = out[2 * k];
-          p[2 * k + 1] = out[2 * k + 1];
+          gstore < T > (p + 2 * k, out[2 * k]);
+          gstore < T > (p + 2 * k + 1, out[2 * k + 1]);
         }
     }
   }
@@ -503,7 +503,8 @@ band_load (uint2 * v, const void *base_, int stride, int tid, int r0, int c0, in
     int rp = it / NG;
     int rr = clampi (r0 + rp, 0, nr - 1);
     int c = clampi (c0 + g * VL, 0, nc - VL);
-    v[n] = *reinterpret_cast < const uint2 * >(base + (size_t) rr * stride + (size_t) c * sizeof (T));
+    const u32x2 q = gload < u32x2 > (base + (size_t) rr * stride + (size_t) c * sizeof (T));
+    v[n] = make_uint2 (q.x, q.y);
   }
 }
 
@@ -571,7 +572,7 @@ void iiwt_level_kernel (const IwtJob * __restrict__ jobs, int njobs)
         int r = r0 + rp, cc = c0 + c;
         if (r >= 0 && r < nr && cc >= 0 && cc < nc)
           lds[2 * rp + (sb >> 1)][(sb & 1) * RC + c] =
-              ((const T *) (base + (size_t) r * stride))[cc];
+              gload < T > ((const T *) (base + (size_t) r * stride) + cc);
       }
     }
   }

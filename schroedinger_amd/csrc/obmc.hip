@@ -76,17 +76,18 @@ fetch_ref (const uint8_t * __restrict__ ref, int stride, int w, int h, int sx, i
 {
   if constexpr (PC == 0) {
     int X = clampi (sx, 0, w - 1), Y = clampi (sy, 0, h - 1);
-    return ref[(size_t) Y * stride + X];
+    return gload < uint8_t > (ref + (size_t) Y * stride + X);
   } else if constexpr (PC == 1) {
     int X = clampi (sx, 0, 2 * w - 2), Y = clampi (sy, 0, 2 * h - 2);
-    return ref[(size_t) Y * stride + X];
+    return gload < uint8_t > (ref + (size_t) Y * stride + X);
   } else {
     int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
     int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
     int X0 = clampi (hx, 0, 2 * w - 2), X1 = clampi (hx + 1, 0, 2 * w - 2);
     int Y0 = clampi (hy, 0, 2 * h - 2), Y1 = clampi (hy + 1, 0, 2 * h - 2);
     const uint8_t *r0 = ref + (size_t) Y0 * stride, *r1 = ref + (size_t) Y1 * stride;
-    int p00 = r0[X0], p01 = r0[X1], p10 = r1[X0], p11 = r1[X1];
+    int p00 = gload < uint8_t > (r0 + X0), p01 = gload < uint8_t > (r0 + X1);
+    int p10 = gload < uint8_t > (r1 + X0), p11 = gload < uint8_t > (r1 + X1);
     int v = (4 - ry) * ((4 - rx) * p00 + rx * p01) + ry * ((4 - rx) * p10 + rx * p11);
     return (v + 8) >> 4;
   }
@@ -166,9 +167,9 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
     for (int a = 0; a < nx; a++) {
       const int i = bi[a], jj = bj[b];
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
-      const uint32_t flags = *reinterpret_cast < const uint32_t * >(mvp);
-      const uint32_t v01 = *reinterpret_cast < const uint32_t * >(mvp + 12);
-      const uint32_t v23 = *reinterpret_cast < const uint32_t * >(mvp + 16);
+      const uint32_t flags = gload < uint32_t > (mvp);
+      const uint32_t v01 = gload < uint32_t > (mvp + 12);
+      const uint32_t v23 = gload < uint32_t > (mvp + 16);
       const int mode = flags & 3;
       const bool interior = i >= 1 && i < job.max_x_blocks && jj >= 1 && jj < job.max_y_blocks;
       const int bx = job.xbsep * i - job.xoff, by = job.ybsep * jj - job.yoff;
@@ -241,12 +242,13 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   t1 = (int16_t) (t1 >> 6);
   int16_t res;
   if (job.res_bpp == 2)
-    res = ((const int16_t *) ((const char *) job.residual + (size_t) py * job.residual_stride))[px];
+    res = gload < int16_t > ((const int16_t *) ((const char *) job.residual
+            + (size_t) py * job.residual_stride) + px);
   else
-    res = (int16_t) ((const int32_t *) ((const char *) job.residual +
-            (size_t) py * job.residual_stride))[px];
+    res = (int16_t) gload < int32_t > ((const int32_t *) ((const char *) job.residual
+            + (size_t) py * job.residual_stride) + px);
   t1 = (int16_t) (res + t1);
-  job.out[(size_t) py * job.out_stride + px] = (uint8_t) clampi (t1, 0, 255);
+  gstore < uint8_t > (job.out + (size_t) py * job.out_stride + px, (uint8_t) clampi (t1, 0, 255));
 }
 
 // ---------------------------------------------------------------------------
@@ -267,8 +269,6 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 
 constexpr int kFTW = 128, kFTH = 32;
 
-struct __attribute__ ((packed)) U64u { uint64_t v; };
-struct __attribute__ ((packed)) U32u { uint32_t v; };
 
 __device__ __forceinline__ int
 floor_div (int a, int b)
@@ -300,22 +300,21 @@ __device__ __forceinline__ void
 fetch4_inside (const uint8_t * __restrict__ p, int stride, uint32_t wpk, int *val)
 {
   if constexpr (PC == 0) {
-    uint32_t v = reinterpret_cast < const U32u * >(p)->v;
+    uint32_t v = gload < u32_u > (p);
     val[0] = v & 0xff;
     val[1] = (v >> 8) & 0xff;
     val[2] = (v >> 16) & 0xff;
     val[3] = v >> 24;
   } else if constexpr (PC == 1) {
-    uint64_t v = reinterpret_cast < const U64u * >(p)->v;
+    const u32x2 q = gload < u32x2_u > (p);
+    const uint64_t v = q.x | ((uint64_t) q.y << 32);
     val[0] = (int) (v & 0xff);
     val[1] = (int) ((v >> 16) & 0xff);
     val[2] = (int) ((v >> 32) & 0xff);
     val[3] = (int) ((v >> 48) & 0xff);
   } else {
-    uint64_t a = reinterpret_cast < const U64u * >(p)->v;
-    uint64_t b = reinterpret_cast < const U64u * >(p + stride)->v;
-    const uint32_t alo = (uint32_t) a, ahi = (uint32_t) (a >> 32);
-    const uint32_t blo = (uint32_t) b, bhi = (uint32_t) (b >> 32);
+    const u32x2 a = gload < u32x2_u > (p), b = gload < u32x2_u > (p + stride);
+    const uint32_t alo = a.x, ahi = a.y, blo = b.x, bhi = b.y;
     val[0] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x05040100u), wpk, 8u, false) >> 4);
     val[1] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x07060302u), wpk, 8u, false) >> 4);
     val[2] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x05040100u), wpk, 8u, false) >> 4);
@@ -445,6 +444,52 @@ obmc_item (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const Tile
   }
 }
 
+// out = sat_u8 (residual + ((acc + 32) >> 6)) for one tile, 4 pixels per lane
+__device__ __forceinline__ void
+obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, int x_hi, int y_hi)
+{
+  // orc_rrshift6_add_s16_2d / _s32_2d on 4 pixels per lane
+  for (int it = tid; it < kFTH * kFTW / 4; it += kThreads) {
+    const int g = it % (kFTW / 4), yy = it / (kFTW / 4);
+    const int x = x_lo + 4 * g, y = y_lo + yy;
+    if (y >= y_hi || x >= x_hi)
+      continue;
+    const int *ap = acc + yy * kAccStride + kAccMargin + 4 * g;
+    const int av[4] = { ap[0], ap[1], ap[2], ap[3] };
+    const char *rrow = (const char *) job.residual + (size_t) y * job.residual_stride;
+    uint8_t *orow = job.out + (size_t) y * job.out_stride + x;
+    __attribute__ ((aligned (8))) int16_t res[4];
+    const bool full = x + 4 <= job.w;
+    if (job.res_bpp == 2) {
+      const int16_t *rp = (const int16_t *) rrow + x;
+      if (full && (((uintptr_t) rp) & 7) == 0) {
+        *reinterpret_cast < u32x2 * >(res) = gload < u32x2 > (rp);
+      } else {
+        for (int e = 0; e < 4; e++)
+          res[e] = x + e < job.w ? gload < int16_t > (rp + e) : (int16_t) 0;
+      }
+    } else {
+      const int32_t *rp = (const int32_t *) rrow + x;
+      for (int e = 0; e < 4; e++)
+        res[e] = x + e < job.w ? (int16_t) gload < int32_t > (rp + e) : (int16_t) 0;   // convlw
+    }
+    uint32_t pk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      int16_t t1 = (int16_t) ((int16_t) av[e] + 32);
+      t1 = (int16_t) (t1 >> 6);
+      t1 = (int16_t) (res[e] + t1);
+      pk |= (uint32_t) clampi (t1, 0, 255) << (8 * e);
+    }
+    if (full && (((uintptr_t) orow) & 3) == 0) {
+      gstore < uint32_t > (orow, pk);
+    } else {
+      for (int e = 0; e < 4 && x + e < job.w; e++)
+        gstore < uint8_t > (orow + e, (uint8_t) (pk >> (8 * e)));
+    }
+  }
+}
+
 template < int PC >
 __global__ __launch_bounds__ (kThreads)
 void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
@@ -533,9 +578,9 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       const int bj = blk / nbi;
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
-      const uint32_t flags = *reinterpret_cast < const uint32_t * >(mvp);
-      const uint32_t v01 = *reinterpret_cast < const uint32_t * >(mvp + 12);
-      const uint32_t v23 = *reinterpret_cast < const uint32_t * >(mvp + 16);
+      const uint32_t flags = gload < uint32_t > (mvp);
+      const uint32_t v01 = gload < uint32_t > (mvp + 12);
+      const uint32_t v23 = gload < uint32_t > (mvp + 16);
       info.bx = xbsep * i - xoff;
       info.by = ybsep * jj - yoff;
       const int mode = flags & 3;
@@ -619,46 +664,7 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   }
   __syncthreads ();
 
-  // orc_rrshift6_add_s16_2d / _s32_2d on 4 pixels per lane
-  for (int it = tid; it < kFTH * kFTW / 4; it += kThreads) {
-    const int g = it % (kFTW / 4), yy = it / (kFTW / 4);
-    const int x = x_lo + 4 * g, y = y_lo + yy;
-    if (y >= y_hi || x >= x_hi)
-      continue;
-    const int *ap = acc + yy * kAccStride + kAccMargin + 4 * g;
-    const int av[4] = { ap[0], ap[1], ap[2], ap[3] };
-    const char *rrow = (const char *) job.residual + (size_t) y * job.residual_stride;
-    uint8_t *orow = job.out + (size_t) y * job.out_stride + x;
-    int16_t res[4];
-    const bool full = x + 4 <= job.w;
-    if (job.res_bpp == 2) {
-      const int16_t *rp = (const int16_t *) rrow + x;
-      if (full && (((uintptr_t) rp) & 7) == 0) {
-        *reinterpret_cast < uint2 * >(res) = *reinterpret_cast < const uint2 * >(rp);
-      } else {
-        for (int e = 0; e < 4; e++)
-          res[e] = x + e < job.w ? rp[e] : (int16_t) 0;
-      }
-    } else {
-      const int32_t *rp = (const int32_t *) rrow + x;
-      for (int e = 0; e < 4; e++)
-        res[e] = x + e < job.w ? (int16_t) rp[e] : (int16_t) 0;       // convlw
-    }
-    uint32_t pk = 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      int16_t t1 = (int16_t) ((int16_t) av[e] + 32);
-      t1 = (int16_t) (t1 >> 6);
-      t1 = (int16_t) (res[e] + t1);
-      pk |= (uint32_t) clampi (t1, 0, 255) << (8 * e);
-    }
-    if (full && (((uintptr_t) orow) & 3) == 0) {
-      *reinterpret_cast < uint32_t * >(orow) = pk;
-    } else {
-      for (int e = 0; e < 4 && x + e < job.w; e++)
-        orow[e] = (uint8_t) (pk >> (8 * e));
-    }
-  }
+  obmc_finish (job, acc, tid, x_lo, y_lo, x_hi, y_hi);
 }
 
 template < int PC >

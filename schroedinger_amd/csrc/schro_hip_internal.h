@@ -87,6 +87,32 @@ constexpr int kMaxJobs = 256;
 // would fetch its own copy.  This bijection gives every XCD one contiguous run
 // of tile ids instead (speed only; any placement is correct).
 #ifdef __HIPCC__
+// Device pointers reach the kernels inside job structs, so the compiler only knows them
+// as generic pointers and would emit flat_load / flat_store: those count on vmcnt AND
+// lgkmcnt and return out of order, which forces s_waitcnt 0 before any LDS result is
+// used and serialises a software-pipelined load with the work it should overlap.
+// gload / gstore say "this is global memory" at the access (global_load / global_store).
+// Native vector types only: a class type such as uint2 would be copied through a generic
+// reference and fall back to flat.
+#define SCHRO_GLOBAL __attribute__ ((address_space (1)))
+typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+typedef uint32_t u32_u __attribute__ ((aligned (1)));         // byte-aligned forms
+typedef u32x2 u32x2_u __attribute__ ((aligned (1)));
+typedef u32x4 u32x4_u __attribute__ ((aligned (1)));
+
+template < typename V, typename P > __device__ __forceinline__ V
+gload (const P * p)
+{
+  return *(const SCHRO_GLOBAL V *) p;
+}
+
+template < typename V, typename P > __device__ __forceinline__ void
+gstore (P * p, V v)
+{
+  *(SCHRO_GLOBAL V *) p = v;
+}
+
 __device__ __forceinline__ int
 xcd_tile_id (int bid, int nblocks)
 {
@@ -108,7 +134,7 @@ find_job (const JOB * jobs, int njobs, int bid)
   int n = 0;
   for (int base = 0; base < njobs; base += 64) {
     const int idx = base + lane;
-    const bool le = idx < njobs && jobs[idx].tile_base <= bid;
+    const bool le = idx < njobs && gload < int > (&jobs[idx].tile_base) <= bid;
     n += __popcll (__ballot (le));
   }
   return __builtin_amdgcn_readfirstlane (n - 1);
