@@ -414,12 +414,21 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       nl = 0;
   }
 
-  std::vector < IwtJob > jobs (nplanes);
+  // per level: planes that allow it run the register form (iiwt_reg.hip), the rest the
+  // LDS tile kernel; SCHRO_HIP_IIWT_REG=0 keeps everything on the LDS kernel
+  const bool use_reg = iiwt_reg_supported (filter, bpp)
+      && !(getenv ("SCHRO_HIP_IIWT_REG") && atoi (getenv ("SCHRO_HIP_IIWT_REG")) == 0);
+  int ruc = 0, rur = 0, rmin = 0;
+  if (use_reg)
+    iiwt_reg_geometry (filter, &ruc, &rur, &rmin);
+  std::vector < IwtJob > jobs, rjobs;
   for (int level = depth - 1; level >= nl; level--) {
-    int tile_base = 0;
+    int tile_base = 0, rtile_base = 0;
+    jobs.clear ();
+    rjobs.clear ();
     for (int p = 0; p < nplanes; p++) {
       const SchroHipIwtPlane & pl = planes[p];
-      IwtJob & j = jobs[p];
+      IwtJob j;
       int w = pl.width >> level, h = pl.height >> level;
       // level view of the coefficient frame: {w, h, stride << level}
       // (schrodecoder.c:1834-1845); sub-band positions schroparams.c:319-352
@@ -449,9 +458,6 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       j.w = w;
       j.h = h;
       int nc = w / 2, nr = h / 2;
-      j.tiles_x = div_up (nc, uc);
-      j.tile_base = tile_base;
-      tile_base += j.tiles_x * div_up (nr, ur);
       int vl = 8 / bpp;
       bool src_al = (nc % vl) == 0 && nc >= vl;
       for (int s = 0; s < 4; s++)
@@ -459,17 +465,36 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
       j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
       j.pad = 0;
+      if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= rmin) {
+        j.tiles_x = div_up (nc, ruc);
+        j.tile_base = rtile_base;
+        rtile_base += j.tiles_x * div_up (nr, rur);
+        rjobs.push_back (j);
+      } else {
+        j.tiles_x = div_up (nc, uc);
+        j.tile_base = tile_base;
+        tile_base += j.tiles_x * div_up (nr, ur);
+        jobs.push_back (j);
+      }
     }
-    void *d_jobs;
-    int r = push_args (ctx, jobs.data (), sizeof (IwtJob) * nplanes, &d_jobs);
-    if (r)
-      return r;
-    {
-      ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
-      r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, nplanes, tile_base, filter, bpp);
+    const int cls = level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE;
+    ProfileScope ps (ctx, cls);
+    if (!rjobs.empty ()) {
+      void *d_jobs;
+      int r = push_args (ctx, rjobs.data (), sizeof (IwtJob) * rjobs.size (), &d_jobs);
+      if (!r)
+        r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_jobs, (int) rjobs.size (), rtile_base, filter);
+      if (r)
+        return r;
     }
-    if (r)
-      return r;
+    if (!jobs.empty ()) {
+      void *d_jobs;
+      int r = push_args (ctx, jobs.data (), sizeof (IwtJob) * jobs.size (), &d_jobs);
+      if (!r)
+        r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, (int) jobs.size (), tile_base, filter, bpp);
+      if (r)
+        return r;
+    }
   }
 
   if (nl) {

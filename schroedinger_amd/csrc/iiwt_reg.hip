@@ -1,0 +1,419 @@
+// iiwt_reg.hip -- one level of the 2-D inverse lifting wavelet on s16 coefficients with
+// the whole tile in registers: no LDS, no workgroup barrier.
+//
+// What it computes: the same as iiwt.hip (schro_wavelet_inverse_transform_2d,
+// schroedinger/schrowaveletorc.c:121-188, s16 kernels of schroorc.orc) for the filters
+// whose lifting halo is small: DD(9,7), LeGall(5,3), DD(13,7), Haar0/1, Daub(9,7).
+//
+// Why a second form: stamped timelines of the LDS kernel (profiles/r01_pmc_notes.md)
+// show a workgroup spending half of its life in LDS lifting passes that four waves per
+// SIMD execute at VALU issue rate, with its loads long finished and the next
+// workgroup's not yet issued.  Here
+//   * one WAVE owns a tile of 248 sub-band columns x (12 - 2H) row pairs plus halo;
+//     lane l holds, for each of the 12 region row pairs, four adjacent columns of all
+//     four sub-bands: 8 packed dwords per row pair, 96 VGPRs, loaded with 48
+//     independent 8-byte global loads that are all in flight together;
+//   * vertical lifting is lane-local on packed 16-bit pairs (v_pk_add_u16,
+//     v_pk_ashrrev_i16, v_pk_mad_u16: exactly the Orc programs' 16-bit wrap points);
+//     the 9*(b+c) - (a+d) steps, whose products need more than 16 bits, are split as
+//     t = 2^sh * (t >> sh) + (t & (2^sh - 1)) so that each half stays inside 16 bits
+//     and the result is the exact 32-bit value;
+//   * horizontal lifting takes its neighbours from the adjacent lanes with DPP
+//     wave shifts (one v_mov_b32_dpp per neighbour dword) and v_alignbit_b32 for the
+//     odd sample offsets; lane 0 and lane 63 are the column halo;
+//   * picture edges: the reference clamps neighbour indices inside the same array at
+//     every step.  Rows: the top tile starts H row pairs above the picture and a tile at
+//     the bottom has 1 .. H row pairs below it; each case is its own instantiation, so
+//     the clamp is a compile-time register choice.  Columns: the first / last lane
+//     inside the picture substitutes its own edge sample for the neighbour dwords (two
+//     v_cndmask per fetched dword, only in the tiles that touch an edge);
+//   * the finished rows are rounded, interleaved (v_perm_b32) and stored as 16 bytes
+//     per lane, 992 contiguous bytes per wave and row.
+// Waves are independent, so while one computes the others' loads and stores keep the
+// memory pipe busy: that overlap is what the barrier-phased kernel lacked.
+//
+// Bound: HBM.  Algorithmic bytes per output sample: 2 B read + 2 B written; the row
+// halo (2H of 12 row pairs) is re-read through L2.
+
+#include "schro_hip_internal.h"
+#include "iiwt_steps.h"
+
+namespace schro {
+namespace {
+
+typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+typedef uint32_t P;             // two packed s16 samples
+
+constexpr int kRegRP = 12;      // region row pairs held by a wave
+constexpr int kRegUC = 4 * 62;  // useful columns per half per wave (lanes 1 .. 62)
+constexpr int kRegThreads = 256;
+
+__device__ __forceinline__ s16x2 S (P x) { return __builtin_bit_cast (s16x2, x); }
+__device__ __forceinline__ P U (s16x2 x) { return __builtin_bit_cast (P, x); }
+
+// value from the lane below / above (wave-wide shift; lane 0 / 63 get 0)
+__device__ __forceinline__ P lane_prev (P x) { return __builtin_amdgcn_update_dpp (0u, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ P lane_next (P x) { return __builtin_amdgcn_update_dpp (0u, x, 0x130, 0xf, 0xf, false); }
+
+__device__ __forceinline__ int
+clampi (int x, int lo, int hi)
+{
+  return min (max (x, lo), hi);
+}
+
+constexpr int
+cmin (int a, int b)
+{
+  return a < b ? a : b;
+}
+
+constexpr int
+cmax (int a, int b)
+{
+  return a > b ? a : b;
+}
+
+// d +/- term (taps), two samples at once, with the s16 wrap points of schroorc.orc
+template < int F, int K >
+__device__ __forceinline__ P
+lift_apply_pk (P d, const P * s)
+{
+  constexpr Step st = filter_step (F, K);
+  s16x2 term;
+  if constexpr (st.kind == K_ADD2_22) {
+    term = ((S (s[0]) + S (s[1])) + (short) 2) >> 2;
+  } else if constexpr (st.kind == K_AVG11) {
+    // (a + b + 1) >> 1 without overflow
+    term = (S (s[0]) | S (s[1])) - ((S (s[0]) ^ S (s[1])) >> 1);
+  } else if constexpr (st.kind == K_MAS4) {
+    // (9 * t1 - t2 + rnd) >> sh with t = 2^sh * a + b: 9 a1 - a2 + ((9 b1 - b2 + rnd) >> sh)
+    constexpr uint32_t M = ((1u << st.sh) - 1) * 0x00010001u;
+    const s16x2 t1 = S (s[1]) + S (s[2]), t2 = S (s[0]) + S (s[3]);
+    const s16x2 a1 = t1 >> st.sh, a2 = t2 >> st.sh;
+    const s16x2 b1 = S (U (t1) & M), b2 = S (U (t2) & M);
+    const s16x2 q = (b1 * (short) 9 + (short) st.rnd - b2) >> st.sh;
+    term = a1 * (short) 9 + q - a2;
+  } else if constexpr (st.kind == K_HAAR_HALF) {
+    term = S (s[0]) - (S (s[0]) >> 1);  // (a + 1) >> 1 without overflow
+  } else if constexpr (st.kind == K_HAAR_FULL) {
+    term = S (s[0]);
+  } else {
+    static_assert (st.kind == K_MAS2, "the 8-tap fidelity filter is not built in this form");
+    // the product needs 32 bits: unpack, multiply, repack
+    const P t = U (S (s[0]) + S (s[1]));
+    const int lo = (int) (int16_t) (t & 0xffff), hi = (int) t >> 16;
+    const int rl = (lo * st.c + st.rnd) >> st.sh, rh = (hi * st.c + st.rnd) >> st.sh;
+    term = S (((uint32_t) rl & 0xffffu) | ((uint32_t) rh << 16));
+  }
+  if constexpr (st.sign > 0)
+    return U (S (d) + term);
+  else
+    return U (S (d) - term);
+}
+
+struct Rng { int lo, hi; };
+
+// Rows of step k's target array that have to be computed so that rows [H, RP - H) of
+// both arrays are final after the last step; LO..HI are the rows that exist.
+template < int F, int RP, int LO, int HI >
+constexpr Rng
+vert_rows (int k)
+{
+  constexpr int H = filter_halo (F);
+  Rng need[2] = { {H, RP - H - 1}, {H, RP - H - 1} };
+  for (int s = filter_nsteps (F) - 1; s >= 0; s--) {
+    const Step st = filter_step (F, s);
+    const int X = st.target, Y = 1 - X;
+    const Rng rx = need[X];
+    if (s == k)
+      return rx;
+    const int lo = cmax (LO, rx.lo + st.off), hi = cmin (HI, rx.hi + st.off + kind_ntaps (st.kind) - 1);
+    need[Y] = Rng { cmin (need[Y].lo, lo), cmax (need[Y].hi, hi) };
+  }
+  return Rng { 0, -1 };
+}
+
+// rows of array `which` (0 even rows, 1 odd rows) that are read at all
+template < int F, int RP, int LO, int HI >
+constexpr Rng
+load_rows (int which)
+{
+  constexpr int H = filter_halo (F);
+  Rng need[2] = { {H, RP - H - 1}, {H, RP - H - 1} };
+  for (int s = filter_nsteps (F) - 1; s >= 0; s--) {
+    const Step st = filter_step (F, s);
+    const int X = st.target, Y = 1 - X;
+    const Rng rx = need[X];
+    const int lo = cmax (LO, rx.lo + st.off), hi = cmin (HI, rx.hi + st.off + kind_ntaps (st.kind) - 1);
+    need[Y] = Rng { cmin (need[Y].lo, lo), cmax (need[Y].hi, hi) };
+  }
+  return need[which];
+}
+
+// one vertical lifting step on the register tile: E = even rows (LL | HL), O = odd rows
+template < int F, int K, int RP, int LO, int HI >
+__device__ __forceinline__ void
+vstep (P (&E)[RP][4], P (&O)[RP][4])
+{
+  constexpr Step st = filter_step (F, K);
+  constexpr int NT = kind_ntaps (st.kind);
+  constexpr Rng rg = vert_rows < F, RP, LO, HI > (K);
+#pragma unroll
+  for (int i = 0; i < RP; i++) {
+    if (i < rg.lo || i > rg.hi)
+      continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      P s[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const int idx = cmin (cmax (i + st.off + t, LO), HI);
+        s[t] = st.target ? E[idx][j] : O[idx][j];
+      }
+      if (st.target)
+        O[i][j] = lift_apply_pk < F, K > (O[i][j], s);
+      else
+        E[i][j] = lift_apply_pk < F, K > (E[i][j], s);
+    }
+  }
+}
+
+// the pair of samples starting at sample p of the window W = dwords of samples -4 .. 7
+template < int p >
+__device__ __forceinline__ P
+pair_at (const P * W)
+{
+  constexpr int idx = p + 4;
+  static_assert (idx >= 0 && idx + 1 <= 11, "tap outside the neighbour window");
+  if constexpr (idx % 2 == 0)
+    return W[idx / 2];
+  else
+    return __builtin_amdgcn_alignbit (W[(idx + 1) / 2], W[(idx - 1) / 2], 16);
+}
+
+template < int F, int K, int Q, int T, int NT >
+__device__ __forceinline__ void
+gather_taps (const P * W, P * s)
+{
+  if constexpr (T < NT) {
+    constexpr Step st = filter_step (F, K);
+    s[T] = pair_at < 2 * Q + st.off + T > (W);
+    gather_taps < F, K, Q, T + 1, NT > (W, s);
+  }
+}
+
+// one horizontal lifting step on one row: row[0..1] = low half samples 0..3 of this lane,
+// row[2..3] = high half; neighbours come from the adjacent lanes
+template < int F, int K, bool HEDGE >
+__device__ __forceinline__ void
+hstep (P (&row)[4], bool is_first, bool is_last)
+{
+  constexpr Step st = filter_step (F, K);
+  constexpr int NT = kind_ntaps (st.kind);
+  const P y0 = st.target ? row[0] : row[2], y1 = st.target ? row[1] : row[3];
+  P p0 = lane_prev (y0), p1 = lane_prev (y1), n0 = lane_next (y0), n1 = lane_next (y1);
+  if constexpr (HEDGE) {
+    // index clamp of the reference: beyond the picture the neighbour is the edge sample
+    const P lo = __builtin_amdgcn_perm (y0, y0, 0x01000100u), hi = __builtin_amdgcn_perm (y1, y1, 0x03020302u);
+    p0 = is_first ? lo : p0;
+    p1 = is_first ? lo : p1;
+    n0 = is_last ? hi : n0;
+    n1 = is_last ? hi : n1;
+  }
+  const P W[6] = { p0, p1, y0, y1, n0, n1 };
+  P s[NT];
+  gather_taps < F, K, 0, 0, NT > (W, s);
+  const P x0 = lift_apply_pk < F, K > (st.target ? row[2] : row[0], s);
+  gather_taps < F, K, 1, 0, NT > (W, s);
+  const P x1 = lift_apply_pk < F, K > (st.target ? row[3] : row[1], s);
+  if (st.target) {
+    row[2] = x0;
+    row[3] = x1;
+  } else {
+    row[0] = x0;
+    row[1] = x1;
+  }
+}
+
+template < int SH >
+__device__ __forceinline__ P
+out_round_pk (P x)
+{
+  if constexpr (SH == 1)
+    return U ((S (x) + (short) 1) >> 1);        // orc_interleave2_rrshift1_s16: the add wraps
+  else if constexpr (SH == 2)
+    return U (S (x) - (S (x) >> 1));            // orc_haar_synth_rrshift1_int_s16: avgsw, no wrap
+  else
+    return x;
+}
+
+// all horizontal steps of one row, then round + interleave + one 16-byte store
+template < int F, bool HEDGE >
+__device__ __forceinline__ void
+finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst)
+{
+  hstep < F, 0, HEDGE > (row, is_first, is_last);
+  hstep < F, 1, HEDGE > (row, is_first, is_last);
+  if constexpr (filter_nsteps (F) == 4) {
+    hstep < F, 2, HEDGE > (row, is_first, is_last);
+    hstep < F, 3, HEDGE > (row, is_first, is_last);
+  }
+  constexpr int SH = filter_shift (F);
+  const P a0 = out_round_pk < SH > (row[0]), a1 = out_round_pk < SH > (row[1]);
+  const P b0 = out_round_pk < SH > (row[2]), b1 = out_round_pk < SH > (row[3]);
+  u32x4 o;
+  o.x = __builtin_amdgcn_perm (b0, a0, 0x05040100u);
+  o.y = __builtin_amdgcn_perm (b0, a0, 0x07060302u);
+  o.z = __builtin_amdgcn_perm (b1, a1, 0x05040100u);
+  o.w = __builtin_amdgcn_perm (b1, a1, 0x07060302u);
+  if (store_lane)
+    gstore < u32x4 > (dst, o);
+}
+
+// LO..HI: region row pairs that exist in the picture (compile-time: see the header)
+template < int F, int LO, int HI, bool HEDGE >
+__device__ __forceinline__ void
+reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
+{
+  constexpr int RP = kRegRP, H = filter_halo (F);
+  P E[RP][4], O[RP][4];
+
+  const int cl = c0 + 4 * lane;
+  const uint32_t voff = (uint32_t) clampi (cl, 0, nc - 4) * 2u;
+  constexpr Rng le = load_rows < F, RP, LO, HI > (0), lo = load_rows < F, RP, LO, HI > (1);
+#pragma unroll
+  for (int k = 0; k < RP; k++) {
+    const int r = clampi (r0 + k, 0, nr - 1);
+    if (k >= le.lo && k <= le.hi) {
+      const u32x2 ll = gload < u32x2 > ((const char *) job.sb[0] + (size_t) r * job.sb_stride[0] + voff);
+      const u32x2 hl = gload < u32x2 > ((const char *) job.sb[1] + (size_t) r * job.sb_stride[1] + voff);
+      E[k][0] = ll.x;
+      E[k][1] = ll.y;
+      E[k][2] = hl.x;
+      E[k][3] = hl.y;
+    }
+    if (k >= lo.lo && k <= lo.hi) {
+      const u32x2 lh = gload < u32x2 > ((const char *) job.sb[2] + (size_t) r * job.sb_stride[2] + voff);
+      const u32x2 hh = gload < u32x2 > ((const char *) job.sb[3] + (size_t) r * job.sb_stride[3] + voff);
+      O[k][0] = lh.x;
+      O[k][1] = lh.y;
+      O[k][2] = hh.x;
+      O[k][3] = hh.y;
+    }
+  }
+
+  vstep < F, 0, RP, LO, HI > (E, O);
+  vstep < F, 1, RP, LO, HI > (E, O);
+  if constexpr (filter_nsteps (F) == 4) {
+    vstep < F, 2, RP, LO, HI > (E, O);
+    vstep < F, 3, RP, LO, HI > (E, O);
+  }
+
+  // lanes inside the picture: first / last substitute their edge sample for the neighbour
+  const int l_lo = (max (0, -c0) + 3) >> 2, l_hi = min (63, ((nc - c0) >> 2) - 1);
+  const bool is_first = lane == l_lo, is_last = lane == l_hi;
+  const bool store_lane = lane >= max (l_lo, 1) && lane <= min (l_hi, 62);
+  char *dst = (char *) job.dst + (size_t) (2 * (r0 + H)) * job.dst_stride + (size_t) cl * 4;
+#pragma unroll
+  for (int i = H; i < RP - H; i++) {
+    finish_row < F, HEDGE > (E[i], is_first, is_last, store_lane, dst);
+    finish_row < F, HEDGE > (O[i], is_first, is_last, store_lane, dst + job.dst_stride);
+    dst += 2 * (size_t) job.dst_stride;
+  }
+}
+
+// tiles whose last N region row pairs lie below the picture
+template < int F, int N >
+__device__ __forceinline__ void
+reg_tile_bottom (int nout, const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
+{
+  if constexpr (N >= 1) {
+    if (nout == N)
+      reg_tile < F, 0, kRegRP - 1 - N, true > (job, r0, c0, nr, nc, lane);
+    else
+      reg_tile_bottom < F, N - 1 > (nout, job, r0, c0, nr, nc, lane);
+  }
+}
+
+template < int F >
+__global__ __launch_bounds__ (kRegThreads)
+void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)
+{
+  constexpr int RP = kRegRP, H = filter_halo (F), UR = RP - 2 * H;
+  const int wg = xcd_tile_id (blockIdx.x, gridDim.x);
+  const int tile = wg * (kRegThreads / 64) + (threadIdx.x >> 6);
+  if (tile >= total_tiles)
+    return;
+  const int lane = threadIdx.x & 63;
+  const IwtJob job = jobs[find_job (jobs, njobs, tile)];
+  const int t = tile - job.tile_base;
+  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  const int nr = job.h >> 1, nc = job.w >> 1;     // nr >= UR + H (host side)
+  // Row placement: tile ty produces row pairs [ty UR, ty UR + UR); the last one is moved up
+  // to end at the picture's last row pair (it recomputes rows of the tile above: same
+  // values).  The top tile has its H halo row pairs above the picture; a tile near the
+  // bottom has nout = 0 .. H of its row pairs below it.  Both are compile-time cases.
+  int r0 = ty * UR - H;
+  if (r0 + H + UR > nr)
+    r0 = nr - UR - H;
+  const int nout = max (0, r0 + RP - nr);
+  const int c0 = tx * kRegUC - 4;
+  const bool hedge = c0 < 0 || c0 + 256 > nc;
+  if (r0 < 0) {
+    reg_tile < F, H, RP - 1, true > (job, r0, c0, nr, nc, lane);
+  } else if (nout == 0) {
+    if (!hedge)
+      reg_tile < F, 0, RP - 1, false > (job, r0, c0, nr, nc, lane);
+    else
+      reg_tile < F, 0, RP - 1, true > (job, r0, c0, nr, nc, lane);
+  } else {
+    reg_tile_bottom < F, H > (nout, job, r0, c0, nr, nc, lane);
+  }
+}
+
+template < int F >
+int
+launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles)
+{
+  const int wgs = (total_tiles + kRegThreads / 64 - 1) / (kRegThreads / 64);
+  hipLaunchKernelGGL ((iiwt_reg_kernel < F >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
+      njobs, total_tiles);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "iiwt (register form) launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+}                               // namespace
+
+// which (filter, sample size) the register form is built for; tile geometry
+bool
+iiwt_reg_supported (int filter, int bpp)
+{
+  return bpp == 2 && filter != 5 && filter >= 0 && filter <= 6;
+}
+
+// a plane needs at least min_row_pairs sub-band rows (top and bottom edge in different tiles)
+void
+iiwt_reg_geometry (int filter, int *useful_cols, int *useful_row_pairs, int *min_row_pairs)
+{
+  *useful_cols = kRegUC;
+  *useful_row_pairs = kRegRP - 2 * filter_halo (filter);
+  *min_row_pairs = kRegRP - filter_halo (filter);
+}
+
+int
+launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter)
+{
+  switch (filter) {
+    case 0: return launch_reg < 0 > (stream, d_jobs, njobs, total_tiles);
+    case 1: return launch_reg < 1 > (stream, d_jobs, njobs, total_tiles);
+    case 2: return launch_reg < 2 > (stream, d_jobs, njobs, total_tiles);
+    case 3: return launch_reg < 3 > (stream, d_jobs, njobs, total_tiles);
+    case 4: return launch_reg < 4 > (stream, d_jobs, njobs, total_tiles);
+    case 6: return launch_reg < 6 > (stream, d_jobs, njobs, total_tiles);
+  }
+  return set_error (SCHRO_HIP_EINVAL, "iiwt (register form): filter %d not built", filter);
+}
+
+}                               // namespace schro

@@ -84,6 +84,22 @@ def test_fused_levels(ctx, filt, dtype, fuse, monkeypatch):
         assert np.array_equal(gpu_iiwt(ctx, fr, depth, filt), O.inverse_iwt(fr, depth, filt))
 
 
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 6])
+def test_register_form_tile_edges(ctx, filt, monkeypatch):
+    # s16 planes whose sub-band width is a multiple of 4 take the register kernel
+    # (iiwt_reg.hip): one wave = 248 columns x (12 - 2H) row pairs.  Sizes around its tile
+    # borders: single / several column tiles, last lane inside or outside the picture, the
+    # bottom tile moved up (row pairs = k * UR + 1 ...), top and bottom in one tile.
+    for (nr, nc) in [(8, 4), (10, 8), (11, 12), (12, 8), (9, 248), (17, 252), (25, 256), (26, 260), (31, 500), (67, 996)]:
+        h, w = 2 * nr, 2 * nc
+        fr = synth.full_range(h, w, np.int16, seed=nr * 131 + nc)
+        want = O.iiwt_2d(fr, filt)
+        assert np.array_equal(gpu_iiwt(ctx, fr, 1, filt), want), (filt, nr, nc)
+        monkeypatch.setenv("SCHRO_HIP_IIWT_REG", "0")      # and the LDS kernel agrees
+        assert np.array_equal(gpu_iiwt(ctx, fr, 1, filt), want), (filt, nr, nc, "lds")
+        monkeypatch.delenv("SCHRO_HIP_IIWT_REG")
+
+
 def test_baseline_size_s32_haar0(ctx):
     # BASELINE config 4 shape class: s32, Haar (no shift), 4:2:2 chroma plane 3840x4320 is
     # large for the CPU oracle; one 3840x2160 s32 plane pins the kernel, the full-size case is
