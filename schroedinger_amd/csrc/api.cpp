@@ -34,19 +34,49 @@ set_error (int code, const char *fmt, ...)
 int
 push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
 {
-  size_t need = (bytes + 255) & ~(size_t) 255;
-  if (need > ctx->args_size)
-    return set_error (SCHRO_HIP_EINVAL, "job table of %zu bytes exceeds the staging ring", bytes);
-  if (ctx->args_off + need > ctx->args_size) {
-    // wrap: everything enqueued so far must have consumed its table
-    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
-    ctx->args_off = 0;
+  if (bytes == 0 || bytes > SchroHipContext::kArgSlotBytes)
+    return set_error (SCHRO_HIP_EINVAL, "job table of %zu bytes exceeds a table slot", bytes);
+  uint64_t h = 1469598103934665603ull;          // FNV-1a, 8 bytes at a time
+  {
+    const unsigned char *b = (const unsigned char *) host;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+      uint64_t w;
+      memcpy (&w, b + i, 8);
+      h = (h ^ w) * 1099511628211ull;
+    }
+    for (; i < bytes; i++)
+      h = (h ^ b[i]) * 1099511628211ull;
   }
-  memcpy (ctx->h_args + ctx->args_off, host, bytes);
-  SCHRO_HIP_CHECK (hipMemcpyAsync (ctx->d_args + ctx->args_off, ctx->h_args + ctx->args_off,
-          bytes, hipMemcpyHostToDevice, ctx->stream));
-  *dev = ctx->d_args + ctx->args_off;
-  ctx->args_off += need;
+  ctx->arg_clock++;
+  int victim = 0;
+  for (int k = 0; k < SchroHipContext::kArgSlots; k++) {
+    SchroHipContext::ArgSlot & sl = ctx->arg_slots[k];
+    if (sl.bytes == bytes && sl.hash == h
+        && memcmp (ctx->h_args + (size_t) k * SchroHipContext::kArgSlotBytes, host, bytes) == 0) {
+      sl.last_use = ctx->arg_clock;
+      *dev = ctx->d_args + (size_t) k * SchroHipContext::kArgSlotBytes;
+      return 0;
+    }
+    if (sl.last_use < ctx->arg_slots[victim].last_use)
+      victim = k;
+  }
+  SchroHipContext::ArgSlot & sl = ctx->arg_slots[victim];
+  char *hm = ctx->h_args + (size_t) victim * SchroHipContext::kArgSlotBytes;
+  char *dm = ctx->d_args + (size_t) victim * SchroHipContext::kArgSlotBytes;
+  if (sl.copy_pending) {        // the mirror may still be the source of an enqueued copy
+    SCHRO_HIP_CHECK (hipEventSynchronize (sl.copied));
+    sl.copy_pending = false;
+  }
+  memcpy (hm, host, bytes);
+  sl.bytes = 0;
+  SCHRO_HIP_CHECK (hipMemcpyAsync (dm, hm, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SCHRO_HIP_CHECK (hipEventRecord (sl.copied, ctx->stream));
+  sl.copy_pending = true;
+  sl.hash = h;
+  sl.bytes = bytes;
+  sl.last_use = ctx->arg_clock;
+  *dev = dm;
   return 0;
 }
 
@@ -146,8 +176,8 @@ schro_hip_context_new (int device)
   ctx->domain_bytes = 0;
   ctx->scratch = nullptr;
   ctx->scratch_size = 0;
-  ctx->args_size = 4u << 20;
-  ctx->args_off = 0;
+  ctx->arg_clock = 0;
+  memset (ctx->arg_slots, 0, sizeof (ctx->arg_slots));
   ctx->profile = false;
   ctx->ev_used = 0;
   ctx->h_args = nullptr;
@@ -155,8 +185,11 @@ schro_hip_context_new (int device)
   bool ok = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking) == hipSuccess
       && hipEventCreate (&ctx->ev_begin) == hipSuccess
       && hipEventCreate (&ctx->ev_end) == hipSuccess
-      && hipHostMalloc ((void **) &ctx->h_args, ctx->args_size, hipHostMallocDefault) == hipSuccess
-      && hipMalloc ((void **) &ctx->d_args, ctx->args_size) == hipSuccess;
+      && hipHostMalloc ((void **) &ctx->h_args, SchroHipContext::kArgSlots * SchroHipContext::kArgSlotBytes,
+          hipHostMallocDefault) == hipSuccess
+      && hipMalloc ((void **) &ctx->d_args, SchroHipContext::kArgSlots * SchroHipContext::kArgSlotBytes) == hipSuccess;
+  for (int k = 0; ok && k < SchroHipContext::kArgSlots; k++)
+    ok = hipEventCreateWithFlags (&ctx->arg_slots[k].copied, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     set_error (SCHRO_HIP_EDEVICE, "context creation failed on device %d: %s", device,
         hipGetErrorString (hipGetLastError ()));
@@ -177,6 +210,9 @@ schro_hip_context_free (SchroHipContext * ctx)
     (void) hipFree (s.ptr);
   if (ctx->scratch)
     (void) hipFree (ctx->scratch);
+  for (int k = 0; k < SchroHipContext::kArgSlots; k++)
+    if (ctx->arg_slots[k].copied)
+      (void) hipEventDestroy (ctx->arg_slots[k].copied);
   if (ctx->d_args)
     (void) hipFree (ctx->d_args);
   if (ctx->h_args)
@@ -477,24 +513,21 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         jobs.push_back (j);
       }
     }
-    const int cls = level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE;
-    ProfileScope ps (ctx, cls);
-    if (!rjobs.empty ()) {
-      void *d_jobs;
-      int r = push_args (ctx, rjobs.data (), sizeof (IwtJob) * rjobs.size (), &d_jobs);
-      if (!r)
-        r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_jobs, (int) rjobs.size (), rtile_base, filter);
-      if (r)
-        return r;
-    }
-    if (!jobs.empty ()) {
-      void *d_jobs;
-      int r = push_args (ctx, jobs.data (), sizeof (IwtJob) * jobs.size (), &d_jobs);
-      if (!r)
-        r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, (int) jobs.size (), tile_base, filter, bpp);
-      if (r)
-        return r;
-    }
+    void *d_rjobs = nullptr, *d_jobs = nullptr;
+    int r = 0;
+    if (!rjobs.empty ())
+      r = push_args (ctx, rjobs.data (), sizeof (IwtJob) * rjobs.size (), &d_rjobs);
+    if (!r && !jobs.empty ())
+      r = push_args (ctx, jobs.data (), sizeof (IwtJob) * jobs.size (), &d_jobs);
+    if (r)
+      return r;
+    ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
+    if (d_rjobs)
+      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter);
+    if (!r && d_jobs)
+      r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, (int) jobs.size (), tile_base, filter, bpp);
+    if (r)
+      return r;
   }
 
   if (nl) {

@@ -188,11 +188,24 @@ struct SchroHipContext {
   std::vector < Slot > slots;
   size_t domain_bytes;
 
-  // ring of pinned-host / device staging for job tables
-  char *h_args;
+  // Job tables on the device.  A decoder calls the batch entry points with the same few
+  // sets of planes over and over (its frame pool), so tables are kept in a small
+  // content-addressed cache: a repeated table costs a hash + memcmp on the host and no
+  // copy at all; a new one replaces the least recently used slot (one async copy from the
+  // slot's pinned mirror, ordered on the stream behind the kernels that still read it).
+  struct ArgSlot {
+    uint64_t hash;
+    size_t bytes;               // 0: empty
+    uint64_t last_use;
+    hipEvent_t copied;          // the slot's last host -> device copy
+    bool copy_pending;
+  };
+  static constexpr int kArgSlots = 64;
+  static constexpr size_t kArgSlotBytes = 48u << 10;
+  char *h_args;                 // kArgSlots pinned mirrors
   char *d_args;
-  size_t args_size;
-  size_t args_off;
+  ArgSlot arg_slots[kArgSlots];
+  uint64_t arg_clock;
 
   // optional per-kernel event profiling
   bool profile;
@@ -209,7 +222,8 @@ struct SchroHipContext {
 };
 
 namespace schro {
-// returns device pointer to a copy of [host, host+bytes) valid for the next launch
+// returns a device pointer to a copy of [host, host+bytes), valid for launches enqueued
+// on the context's stream before the next 63 distinct tables
 int push_args (SchroHipContext * ctx, const void *host, size_t bytes,
     void **dev);
 int ensure_scratch (SchroHipContext * ctx, size_t bytes);
