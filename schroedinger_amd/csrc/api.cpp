@@ -382,6 +382,45 @@ schro_hip_profile_read (SchroHipContext * ctx, int kernel_class, double *total_m
 
 // ---- plane layer ----------------------------------------------------------------
 
+// levels fb .. fb+nl-1 of every plane in one launch of the fused LDS kernel
+static int
+iiwt_fused_group (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes, int depth,
+    int filter, int bpp, int fb, int nl, const std::vector < size_t > &scratch_off,
+    const std::vector < int >&scratch_stride, int uc, int ur)
+{
+  const size_t jsz = iiwt_fused_job_size ();
+  std::vector < char >fj (jsz * nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipIwtPlane & pl = planes[p];
+    const int top = fb + nl;    // first level above the group
+    const void *ll = pl.src;
+    int ll_stride = (pl.src_stride << (top - 1)) * 2;
+    if (top < depth) {
+      ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + top];
+      ll_stride = scratch_stride[(size_t) p * depth + top];
+    }
+    void *dst = pl.dst;
+    int dst_stride = pl.dst_stride;
+    if (fb > 0) {
+      dst = (char *) ctx->scratch + scratch_off[(size_t) p * depth + fb];
+      dst_stride = scratch_stride[(size_t) p * depth + fb];
+    }
+    const int w = pl.width >> fb, h = pl.height >> fb;
+    int tiles_x = div_up (w / 2, uc);
+    // the level-fb view of the coefficient frame: {w, h, stride << fb}
+    iiwt_fused_job_fill (fj.data () + jsz * p, pl.src, pl.src_stride << fb, bpp, nl, ll, ll_stride,
+        dst, dst_stride, w, h, tiles_x, tile_base);
+    tile_base += tiles_x * div_up (h / 2, ur);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, fj.data (), fj.size (), &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, fb == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
+  return launch_iiwt_fused (ctx->stream, d_jobs, nplanes, tile_base, filter, bpp, nl);
+}
+
 int
 schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes,
     int depth, int filter, int bpp)
@@ -428,28 +467,6 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   int uc, ur;
   iiwt_tile_geometry (filter, bpp, &uc, &ur);
 
-  // SCHRO_HIP_IIWT_FUSE=2|3 runs the finest 2 or 3 levels as one fused launch when
-  // every plane allows aligned 8-byte sub-band loads at those levels; deeper levels,
-  // and everything by default, go level by level.  (Measured on 8x2160p the fused
-  // kernel is 10 % slower than three launches -- lower occupancy from its LDS -- so it
-  // is opt-in; it saves two launches on small pictures.)
-  int nl = 0;
-  {
-    const char *env = getenv ("SCHRO_HIP_IIWT_FUSE");
-    int want = env ? atoi (env) : 0;
-    nl = std::min (std::min (want, depth), iiwt_fused_max_levels (filter, bpp));
-    const int vl = 8 / bpp;
-    for (int p = 0; p < nplanes && nl >= 2; p++) {
-      const SchroHipIwtPlane & pl = planes[p];
-      if ((((uintptr_t) pl.src | (uintptr_t) pl.src_stride) & 7) != 0)
-        nl = 0;
-      while (nl >= 2 && (((pl.width >> nl) % vl) != 0 || (pl.width >> nl) < vl))
-        nl--;
-    }
-    if (nl < 2)
-      nl = 0;
-  }
-
   // per level: planes that allow it run the register form (iiwt_reg.hip), the rest the
   // LDS tile kernel; SCHRO_HIP_IIWT_REG=0 keeps everything on the LDS kernel
   const bool use_reg = iiwt_reg_supported (filter, bpp)
@@ -457,8 +474,42 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   int ruc = 0, rur = 0, rmin = 0;
   if (use_reg)
     iiwt_reg_geometry (filter, &ruc, &rur, &rmin);
+
+  // Fused group (opt-in): SCHRO_HIP_IIWT_FUSE=n runs levels b .. b+n-1 as ONE launch of
+  // the fused LDS kernel, b = SCHRO_HIP_IIWT_FUSE_BASE (default 1 where level 0 has the
+  // register kernel, else 0).  It saves launches and the intermediate LL round trips, but
+  // measured on 8 x 2160p it loses to a launch per level both for the finest levels
+  // (0.181 vs 0.166 ms, LDS kernels) and for levels 2+1 (0.054 vs 0.042 ms against the
+  // register kernel), so nothing is fused by default.
+  int fb = 0, nl = 0;
+  {
+    const char *env = getenv ("SCHRO_HIP_IIWT_FUSE"), *envb = getenv ("SCHRO_HIP_IIWT_FUSE_BASE");
+    fb = envb ? atoi (envb) : (use_reg ? 1 : 0);
+    fb = std::max (0, std::min (fb, depth - 1));
+    int want = env ? atoi (env) : 0;
+    nl = std::min (std::min (want, depth - fb), iiwt_fused_max_levels (filter, bpp));
+    const int vl = 8 / bpp;
+    for (int p = 0; p < nplanes && nl >= 2; p++) {
+      const SchroHipIwtPlane & pl = planes[p];
+      if ((((uintptr_t) pl.src | (uintptr_t) pl.src_stride) & 7) != 0)
+        nl = 0;
+      while (nl >= 2 && (((pl.width >> (fb + nl)) % vl) != 0 || (pl.width >> (fb + nl)) < vl))
+        nl--;
+    }
+    if (nl < 2)
+      nl = 0;
+  }
+
   std::vector < IwtJob > jobs, rjobs;
-  for (int level = depth - 1; level >= nl; level--) {
+  for (int level = depth - 1; level >= 0; level--) {
+    if (nl && level >= fb && level < fb + nl) {
+      if (level == fb + nl - 1) {
+        int r = iiwt_fused_group (ctx, planes, nplanes, depth, filter, bpp, fb, nl, scratch_off, scratch_stride, uc, ur);
+        if (r)
+          return r;
+      }
+      continue;
+    }
     int tile_base = 0, rtile_base = 0;
     jobs.clear ();
     rjobs.clear ();
@@ -530,34 +581,6 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       return r;
   }
 
-  if (nl) {
-    const size_t jsz = iiwt_fused_job_size ();
-    std::vector < char >fj (jsz * nplanes);
-    int tile_base = 0;
-    for (int p = 0; p < nplanes; p++) {
-      const SchroHipIwtPlane & pl = planes[p];
-      const void *ll = pl.src;
-      int ll_stride = (pl.src_stride << (nl - 1)) * 2;
-      if (nl < depth) {
-        ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + nl];
-        ll_stride = scratch_stride[(size_t) p * depth + nl];
-      }
-      int tiles_x = div_up (pl.width / 2, uc);
-      iiwt_fused_job_fill (fj.data () + jsz * p, pl.src, pl.src_stride, bpp, nl, ll, ll_stride,
-          pl.dst, pl.dst_stride, pl.width, pl.height, tiles_x, tile_base);
-      tile_base += tiles_x * div_up (pl.height / 2, ur);
-    }
-    void *d_jobs;
-    int r = push_args (ctx, fj.data (), fj.size (), &d_jobs);
-    if (r)
-      return r;
-    {
-      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
-      r = launch_iiwt_fused (ctx->stream, d_jobs, nplanes, tile_base, filter, bpp, nl);
-    }
-    if (r)
-      return r;
-  }
   return 0;
 }
 

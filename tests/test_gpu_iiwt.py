@@ -70,12 +70,15 @@ def test_baseline_sizes_s16(ctx, filt, depth, h, w):
     assert np.array_equal(got, img)
 
 
-@pytest.mark.parametrize("fuse", ["2", "3"])
+@pytest.mark.parametrize("base", ["0", "1"])
+@pytest.mark.parametrize("fuse", ["0", "2", "3"])
 @pytest.mark.parametrize("dtype", [np.int16, np.int32])
 @pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 6])
-def test_fused_levels(ctx, filt, dtype, fuse, monkeypatch):
-    # SCHRO_HIP_IIWT_FUSE: the finest 2 / 3 levels in one launch; same answer
+def test_fused_levels(ctx, filt, dtype, fuse, base, monkeypatch):
+    # SCHRO_HIP_IIWT_FUSE / _FUSE_BASE: levels base .. base+n-1 in one launch (the default
+    # fuses the levels above level 0 for s16); same answer whatever the grouping
     monkeypatch.setenv("SCHRO_HIP_IIWT_FUSE", fuse)
+    monkeypatch.setenv("SCHRO_HIP_IIWT_FUSE_BASE", base)
     for (h, w, depth) in [(48, 64, 3), (240, 320, 4), (136, 248, 3), (272, 480, 2), (544, 960, 3)]:
         img = synth.image_s(h, w, dtype, seed=17)
         co = O.forward_iwt(img, depth, filt)
