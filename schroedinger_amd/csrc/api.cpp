@@ -660,7 +660,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       "obmc_batch: bad arguments");
   (void) hipSetDevice (ctx->device);
   // kernel variant per plane: default weights (1,1,bits 1) run the LDS-accumulate
-  // tile kernel, everything else the exact per-pixel kernel
+  // item kernel, everything else the exact per-pixel kernel
   auto variant_of = [](const SchroHipObmcPlane & pl) {
     return (pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1 && pl.picture_weight_bits == 1) ? 1 : 0;
   };

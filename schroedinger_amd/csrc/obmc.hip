@@ -252,20 +252,20 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 }
 
 // ---------------------------------------------------------------------------
-// Tile kernel for the default picture weights (1,1,bits 1 -- "simple_weight",
+// Item kernel for the default picture weights (1,1,bits 1 -- "simple_weight",
 // schromotion8.c:773-776), the case every stream in the reference's test
 // suite uses.  With those weights edge and interior blocks predict the same
 // value, so the only edge special-case left is the weight folding.
 //
-// One 256-thread workgroup owns a 64x32 output tile and an int accumulator
-// tile in LDS.  Work items are (block, block row, 4-pixel segment): each lane
-// fetches its segment's reference samples with two unaligned 8-byte loads per
-// reference (quarter/eighth-pel: v_perm_b32 + v_dot4_u32_u8 per pixel), forms
-// the prediction once, and adds pred*wx*wy into the LDS tile (ds_add_u32; all
-// adds are modulo 2^16 in the reference, so order is irrelevant).  The MV
-// decode and clamp are amortised over 4 pixels and every block row is touched
-// once per tile instead of once per pixel.  The finish pass reads the residual
-// (8-byte loads), rounds, adds, clamps and stores 4 pixels per lane.
+// One 256-thread workgroup owns a 128x32 output tile and an int accumulator
+// tile in LDS.  Work items are (block, block row); a lane takes a 4-pixel
+// segment of one: it fetches the segment's reference samples with two unaligned
+// 8-byte loads per reference (quarter/eighth-pel: v_perm_b32 + v_dot4_u32_u8 per
+// pixel), forms the prediction once, and adds pred*wx*wy into the LDS tile
+// (ds_add_u32; all adds are modulo 2^16 in the reference, so order is
+// irrelevant).  The MV decode and clamp are done once per block and tile.  The
+// finish pass reads the residual (8-byte loads), rounds, adds, clamps and
+// stores 4 pixels per lane.  (How the work list is built: see obmc_item_kernel.)
 
 constexpr int kFTW = 128, kFTH = 32;
 
@@ -278,7 +278,6 @@ floor_div (int a, int b)
 }
 
 constexpr int kAccStride = 141; // odd: block rows land on different LDS banks
-constexpr int kBlkCap = 256;    // decoded blocks held in LDS per chunk
 
 // One decoded block.  Everything that is uniform over the block's pixels is
 // worked out once here: position, prediction mode, get_block's clamped fetch
@@ -385,65 +384,6 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
   }
 }
 
-// Hot item: both sample windows inside the image, no weight folding.
-// wx0[e] is 0 for padding pixels of a partial last segment.
-template < int PC >
-__device__ __forceinline__ void
-obmc_item_fast (const ObmcJob & job, const BlkInfo & bi, int md, int row, int seg, int y, int xs,
-    const TileCtx & tc, int wy0, const int *wx0, int *acc)
-{
-  constexpr int kStep = PC == 0 ? 1 : 2;
-  const int mode = md & 3;
-  int v0[4], v1[4];
-  const int dcv = md >> 8;
-  v0[0] = v0[1] = v0[2] = v0[3] = dcv;
-  if (mode & 1)
-    fetch4_inside < PC > (job.ref[0] + bi.off[0] + (row * kStep) * job.ref_stride[0]
-        + seg * (4 * kStep), job.ref_stride[0], bi.wpk[0], v0);
-#pragma unroll
-  for (int e = 0; e < 4; e++)
-    v1[e] = v0[e];              // one reference (or DC): avg (a, a) == a
-  if (mode & 2) {
-    fetch4_inside < PC > (job.ref[1] + bi.off[1] + (row * kStep) * job.ref_stride[1]
-        + seg * (4 * kStep), job.ref_stride[1], bi.wpk[1], v1);
-    if (!(mode & 1)) {
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        v0[e] = v1[e];
-    }
-  }
-  int *ap = acc + (y - tc.y_lo) * kAccStride + kAccMargin + (xs - tc.x_lo);
-#pragma unroll
-  for (int e = 0; e < 4; e++)
-    atomicAdd (ap + e, ((v0[e] + v1[e] + 1) >> 1) * (wx0[e] * wy0));
-}
-
-// SLOW == false: the hot pass, handles the items that need neither clamping
-// nor folding and returns true if this item was left for the slow pass.
-// SLOW == true: the (rare) second pass over exactly those items.
-template < int PC, bool SLOW >
-__device__ __forceinline__ bool
-obmc_item (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const TileCtx & tc,
-    int wy0, const int *wx0, const int *s_wx, const int *s_wy, int *acc)
-{
-  const int y = bi.by + row, xs = bi.bx + 4 * seg;
-  if (y < tc.y_lo || y >= tc.y_hi || xs + 3 < tc.x_lo || xs >= tc.x_hi)
-    return false;
-  const int md = bi.mode_dc;
-  const bool clamped = ((md >> 2) & md & 3) != 0;       // a reference in use needs clamping
-  const bool fold = y < job.yoff || y >= tc.yfold_hi || xs < job.xoff || xs + 3 >= tc.xfold_hi;
-  if constexpr (SLOW) {
-    if (clamped || fold)
-      obmc_item_slow < PC > (job, bi, row, seg, tc, s_wx, s_wy, acc);
-    return false;
-  } else {
-    if (clamped || fold)
-      return true;
-    obmc_item_fast < PC > (job, bi, md, row, seg, y, xs, tc, wy0, wx0, acc);
-    return false;
-  }
-}
-
 // out = sat_u8 (residual + ((acc + 32) >> 6)) for one tile, 4 pixels per lane
 __device__ __forceinline__ void
 obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, int x_hi, int y_hi)
@@ -490,20 +430,124 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// The work list.  Blocks are decoded once per tile (one per thread), sorted by class
+// (two references / first / second / DC / needs the exact rim path), and a prefix sum over
+// "rows of the block inside the tile" turns them into a dense list of ITEMS = (block, row).
+// nseg = ceil (xblen / 4) adjacent lanes take one item, 4 pixels each, so every lane of a
+// pass has work and all lanes of a pass belong to one class: the pass body is straight
+// line (loads of both references issued together, one wait, v_perm/v_dot4 bilinear,
+// v_mul_u32_u24 with the 4 packed weights of the (row, segment), 4 ds_add_u32).
+// Everything that does not depend on the pixel is precomputed per block (tile-relative
+// origin, sample-window offsets, packed bilinear weights) or per (row, segment) (weights).
+//
+// This form replaced a kernel whose lanes were fixed (block slot, row, segment) triples:
+// 44 % of its lanes were rows outside the tile and every item walked a chain of divergent
+// range / mode / clamp tests (3050 wave instructions per wave, a third of them scalar
+// exec-mask bookkeeping; this one 2000).  Both run 8 x 2160p in 0.55 ms: the launch is
+// bound by the cache-line gather itself -- 47 M 128-byte lines per launch from L2 /
+// Infinity Cache for 24 useful bytes each, 11 TB/s of line traffic (rocprofv3
+// TCP_TCC_READ_REQ; MI355X_MICROARCH.md gives 8.6 - 18 TB/s for gathers) -- not by
+// instruction issue, occupancy (3, 4 or 5 workgroups per CU: same time) or LDS atomics.
+
+constexpr int kItemBlkCap = 128;        // decoded blocks per chunk
+constexpr int kItemCap = 1536;          // (block, row) items per chunk
+constexpr int kItemWCap = 1024;         // (row, segment) weight words
+
+struct __attribute__ ((aligned (16))) HotBlk {
+  int y, x;                     // block origin relative to the tile
+  int mode_dc;                  // as BlkInfo
+  int rows;                     // first block row inside the tile | rows inside << 8
+  int off[2];                   // byte offset of the first sample of the window
+  uint32_t wpk[2];              // packed bilinear weights
+};
+
+// get_block's clamped fetch origin of reference r, in 1/2^prec pel (schromotion8.c:303-335)
+__device__ __forceinline__ void
+mv_origin (const ObmcJob & job, int bx, int by, uint32_t v01, uint32_t v23, int r, int *fx, int *fy)
+{
+  const int prec = job.prec, expx = 32 << prec;
+  const int max_fast_x = (job.w - job.xblen) * (1 << prec), max_fast_y = (job.h - job.yblen) * (1 << prec);
+  int dx = r == 0 ? (int16_t) (v01 & 0xffff) : (int16_t) (v01 >> 16);
+  int dy = r == 0 ? (int16_t) (v23 & 0xffff) : (int16_t) (v23 >> 16);
+  dx >>= job.mv_shift_x;
+  dy >>= job.mv_shift_y;
+  *fx = clampi (bx * (1 << prec) + dx, -expx, max_fast_x + expx - 1);
+  *fy = clampi (by * (1 << prec) + dy, -expx, max_fast_y + expx - 1);
+}
+
+struct ItemLane {
+  int slot, seg;                // item slot within the pass, 4-pixel segment within the row
+  int seg_bytes;                // byte offset of the segment inside the sample window
+  int tw3;                      // tile width + 3 (range test of a segment)
+  bool active;                  // lanes beyond the last whole item of a pass idle
+};
+
+// one pass of one class: CLS 0 both references, 1 / 2 one reference, 3 DC
+template < int PC, int CLS >
+__device__ __forceinline__ void
+item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
+    const uint32_t * s_w4, int nseg, int *acc, int i0, int hi)
+{
+  constexpr int kStep = PC == 0 ? 1 : 2;
+  const int it = i0 + il.slot;
+  const int e = s_item[min (it, hi - 1)];
+  const HotBlk & hb = s_hot[e & 0xff];
+  const int row = e >> 8;
+  const int yrel = hb.y + row, xrel = hb.x + 4 * il.seg;
+  const uint32_t w4 = s_w4[row * nseg + il.seg];
+  int v0[4], v1[4];
+  if constexpr (CLS == 3) {
+    v0[0] = v0[1] = v0[2] = v0[3] = v1[0] = v1[1] = v1[2] = v1[3] = hb.mode_dc >> 8;
+  } else {
+    constexpr int r0 = CLS == 2 ? 1 : 0;
+    fetch4_inside < PC > (job.ref[r0] + (hb.off[r0] + (row * kStep) * job.ref_stride[r0] + il.seg_bytes),
+        job.ref_stride[r0], hb.wpk[r0], v0);
+    if constexpr (CLS == 0) {
+      fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
+          job.ref_stride[1], hb.wpk[1], v1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v1[k] = v0[k];
+    }
+  }
+  if (il.active && it < hi && (unsigned) (xrel + 3) < (unsigned) il.tw3) {
+    int *ap = acc + yrel * kAccStride + kAccMargin + xrel;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int pred = CLS == 0 ? (v0[k] + v1[k] + 1) >> 1 : v0[k];
+      atomicAdd (ap + k, pred * (int) ((w4 >> (8 * k)) & 0xff));
+    }
+  }
+}
+
+template < int PC, int CLS >
+__device__ __forceinline__ void
+item_class (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
+    const uint32_t * s_w4, int nseg, int *acc, int first, int hi, int stride)
+{
+  for (int i0 = first; i0 < hi; i0 += stride)
+    item_pass < PC, CLS > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi);
+}
+
 template < int PC >
 __global__ __launch_bounds__ (kThreads)
-void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
+void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 {
   __shared__ int acc[kFTH * kAccStride];
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
-  __shared__ BlkInfo s_blk[kBlkCap];
-  __shared__ int s_cnt[4];
+  __shared__ HotBlk s_hot[kItemBlkCap];
+  __shared__ uint16_t s_item[kItemCap];
+  __shared__ uint32_t s_w4[kItemWCap];
+  __shared__ int s_start[kItemBlkCap + 1];      // first item of each sorted block
+  __shared__ int s_cnt[8];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x_lo = tx * kFTW, y_lo = ty * kFTH;
   const int x_hi = min (x_lo + kFTW, job.w), y_hi = min (y_lo + kFTH, job.h);
 
@@ -516,34 +560,25 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 
   const int xblen = job.xblen, yblen = job.yblen, xbsep = job.xbsep, ybsep = job.ybsep;
   const int xoff = job.xoff, yoff = job.yoff, prec = job.prec;
-  // blocks whose footprint meets the tile
   const int i_lo = max (0, floor_div (x_lo + xoff - xblen, xbsep) + 1);
   const int i_hi = min (job.nbx - 1, (x_hi - 1 + xoff) / xbsep);
   const int j_lo = max (0, floor_div (y_lo + yoff - yblen, ybsep) + 1);
   const int j_hi = min (job.nby - 1, (y_hi - 1 + yoff) / ybsep);
   const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
   const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
-  const int nseg = (xblen + 3) >> 2;
-  const int per_block = yblen * nseg;
-  const int expx = 32 << prec;
-  const int max_fast_x = (job.w - xblen) * (1 << prec), max_fast_y = (job.h - yblen) * (1 << prec);
   const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
-  // sample-grid geometry of one reference image
   const int gw = PC == 0 ? job.w - 1 : 2 * job.w - 2;   // last valid sample column
   const int gh = PC == 0 ? job.h - 1 : 2 * job.h - 2;
   constexpr int kStep = PC == 0 ? 1 : 2;        // samples per pixel step
-
-  // lane -> (block slot, row, segment), fixed for the whole tile when a block
-  // fits in the workgroup; C blocks are processed per pass
-  const int C = per_block <= kThreads ? kThreads / per_block : 0;
-  const int total_per_pass = C ? C * per_block : kThreads;
-  int b_local = 0, row = 0, seg = 0;
-  if (C) {
-    b_local = tid / per_block;
-    const int rem = tid - b_local * per_block;
-    row = rem / nseg;
-    seg = rem - row * nseg;
-  }
+  const int nseg = (xblen + 3) >> 2;
+  const int chunk_cap = min (kItemBlkCap, kItemCap / min (yblen, kFTH));
+  ItemLane il;
+  il.slot = lane / nseg;
+  il.seg = lane - il.slot * nseg;
+  il.seg_bytes = il.seg * (4 * kStep);
+  il.tw3 = x_hi - x_lo + 3;
+  const int IPW = 64 / nseg;                    // items per wave pass
+  il.active = il.slot < IPW;
   TileCtx tc;
   tc.x_lo = x_lo;
   tc.x_hi = x_hi;
@@ -552,37 +587,38 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   tc.xfold_hi = xfold_hi;
   tc.yfold_hi = yfold_hi;
   __syncthreads ();             // weights visible
-  int wy0 = 0, wx0[4] = { 0, 0, 0, 0 };
-  if (C && tid < total_per_pass) {
-    wy0 = s_wy[row];
+  // the 4 weights wx * wy of every (block row, segment), one byte each (<= 64)
+  for (int i = tid; i < yblen * nseg && i < kItemWCap; i += kThreads) {
+    const int r = i / nseg, sg = i - r * nseg;
+    uint32_t w = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++)
-      wx0[e] = 4 * seg + e < xblen ? s_wx[4 * seg + e] : 0;
+    for (int k = 0; k < 4; k++)
+      if (4 * sg + k < xblen)
+        w |= (uint32_t) (s_wx[4 * sg + k] * s_wy[r]) << (8 * k);
+    s_w4[i] = w;
   }
 
-  for (int chunk0 = 0; chunk0 < nblk; chunk0 += kBlkCap) {
-    const int nb = min (kBlkCap, nblk - chunk0);
-    if (tid < 4)
+  for (int chunk0 = 0; chunk0 < nblk; chunk0 += chunk_cap) {
+    const int nb = min (chunk_cap, nblk - chunk0);
+    if (tid < 8)
       s_cnt[tid] = 0;
-    __syncthreads ();           // acc/weights ready; previous chunk's table consumed
-    // ---- decode this chunk's motion vectors once per block (kBlkCap == kThreads:
-    // one block per thread) and place them in the table sorted by prediction
-    // mode, so that the lanes of a pass mostly take the same fetch branches ------
-    static_assert (kBlkCap == kThreads, "one block per thread per chunk");
-    BlkInfo info;
+    __syncthreads ();           // acc / weights ready; previous chunk's tables consumed
+    // ---- decode one block per thread; class 0 two references, 1 / 2 one reference,
+    // 3 DC, 4 picture rim (exact clamp / fold path) -------------------------------
+    HotBlk info;
     int key = 0, rank = 0;
     const bool have = tid < nb;
     if (have) {
-      const int b = tid;
-      const int blk = chunk0 + b;
+      const int blk = chunk0 + tid;
       const int bj = blk / nbi;
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
       const uint32_t flags = gload < uint32_t > (mvp);
       const uint32_t v01 = gload < uint32_t > (mvp + 12);
       const uint32_t v23 = gload < uint32_t > (mvp + 16);
-      info.bx = xbsep * i - xoff;
-      info.by = ybsep * jj - yoff;
+      const int bx = xbsep * i - xoff, by = ybsep * jj - yoff;
+      info.x = bx - x_lo;
+      info.y = by - y_lo;
       const int mode = flags & 3;
       const bool interior = i >= 1 && i < job.max_x_blocks && jj >= 1 && jj < job.max_y_blocks;
       int dc = job.comp == 0 ? (int16_t) (v01 & 0xffff)
@@ -592,16 +628,8 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       int md = mode | (p << 8);
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        int dx = r == 0 ? (int16_t) (v01 & 0xffff) : (int16_t) (v01 >> 16);
-        int dy = r == 0 ? (int16_t) (v23 & 0xffff) : (int16_t) (v23 >> 16);
-        dx >>= job.mv_shift_x;
-        dy >>= job.mv_shift_y;
-        const int fx = clampi (info.bx * (1 << prec) + dx, -expx, max_fast_x + expx - 1);
-        const int fy = clampi (info.by * (1 << prec) + dy, -expx, max_fast_y + expx - 1);
-        info.fx[r] = fx;
-        info.fy[r] = fy;
-        // first sample of the block on the reference's sample grid, and the
-        // last one any of its pixels touches
+        int fx, fy;
+        mv_origin (job, bx, by, v01, v23, r, &fx, &fy);
         int gx0, gy0, gx1, gy1;
         uint32_t wpk = 0;
         if constexpr (PC == 2) {
@@ -626,44 +654,93 @@ void obmc_tile_kernel (const ObmcJob * __restrict__ jobs, int njobs)
         info.wpk[r] = wpk;
       }
       info.mode_dc = md;
-      info.pad = 0;
-      key = mode == 3 ? 0 : (mode == 1 ? 1 : (mode == 2 ? 2 : 3));
+      const int ra = max (0, -info.y), rb = min (yblen, y_hi - by);
+      info.rows = ra | ((rb - ra) << 8);
+      const bool clamped = ((md >> 2) & md & 3) != 0;
+      const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + nseg * 4 > xfold_hi;
+      key = (clamped || fold) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
       rank = atomicAdd (&s_cnt[key], 1);
     }
     __syncthreads ();
+    int cbase[6];               // first sorted position of each class
+    cbase[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+      cbase[k + 1] = cbase[k] + s_cnt[k];
     if (have) {
       int base = 0;
-      for (int k = 0; k < key; k++)
-        base += s_cnt[k];
-      s_blk[base + rank] = info;
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+        base = key == k ? cbase[k] : base;
+      s_hot[base + rank] = info;
     }
     __syncthreads ();
-    // ---- accumulate: one (block, row, 4-pixel segment) per lane per pass ------
-    if (C) {
-      if (tid < total_per_pass) {
-        bool leftover = false;
-        for (int b = b_local; b < nb; b += C)
-          leftover |= obmc_item < PC, false > (job, s_blk[b], row, seg, tc, wy0, wx0, s_wx, s_wy, acc);
-        if (leftover)
-          for (int b = b_local; b < nb; b += C)
-            obmc_item < PC, true > (job, s_blk[b], row, seg, tc, wy0, wx0, s_wx, s_wy, acc);
+    // ---- items: exclusive prefix sum of rows-in-tile over the sorted fast blocks
+    // (waves 0 and 1 hold the <= 128 entries) --------------------------------------
+    int nrows = 0, incl = 0;
+    if (tid < kItemBlkCap) {
+      nrows = tid < cbase[4] ? (s_hot[tid].rows >> 8) : 0;
+      incl = nrows;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up (incl, d);
+        if (lane >= d)
+          incl += up;
       }
-    } else {
-      // blocks larger than the workgroup: generic item decode, everything on the slow path
-      for (int item = tid; item < nb * per_block; item += kThreads) {
+      if (tid == 63)
+        s_cnt[5] = incl;
+    }
+    __syncthreads ();
+    if (tid < kItemBlkCap) {
+      if (tid >= 64)
+        incl += s_cnt[5];
+      const int start = incl - nrows;
+      s_start[tid] = start;
+      if (tid == kItemBlkCap - 1)
+        s_start[kItemBlkCap] = incl;
+      if (tid < cbase[4]) {
+        const int ra = s_hot[tid].rows & 0xff;
+        for (int r = 0; r < nrows; r++)
+          s_item[start + r] = (uint16_t) (tid | ((ra + r) << 8));
+      }
+    }
+    __syncthreads ();
+
+    // ---- accumulate: every pass of a wave is IPW whole items of one class ---------
+    const int first = wave * IPW, stride = (kThreads / 64) * IPW;
+    item_class < PC, 0 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[0]] + first, s_start[cbase[1]], stride);
+    item_class < PC, 1 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[1]] + first, s_start[cbase[2]], stride);
+    item_class < PC, 2 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[2]] + first, s_start[cbase[3]], stride);
+    item_class < PC, 3 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[3]] + first, s_start[cbase[4]], stride);
+
+    // ---- picture-rim blocks: exact clamp / fold path -----------------------------
+    {
+      const int per_block = yblen * nseg;
+      const int nslow = cbase[5] - cbase[4];
+      for (int item = tid; item < nslow * per_block; item += kThreads) {
         const int b = item / per_block;
         const int rem = item - b * per_block;
         const int r2 = rem / nseg, s2 = rem - r2 * nseg;
-        const BlkInfo & bi = s_blk[b];
+        const HotBlk & hb = s_hot[cbase[4] + b];
+        BlkInfo bi;
+        bi.bx = hb.x + x_lo;
+        bi.by = hb.y + y_lo;
         const int y = bi.by + r2, xs = bi.bx + 4 * s2;
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
+        bi.mode_dc = hb.mode_dc;
+        {
+          const int i = (bi.bx + xoff) / xbsep, jj = (bi.by + yoff) / ybsep;
+          const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
+          const uint32_t v01 = gload < uint32_t > (mvp + 12), v23 = gload < uint32_t > (mvp + 16);
+          mv_origin (job, bi.bx, bi.by, v01, v23, 0, &bi.fx[0], &bi.fy[0]);
+          mv_origin (job, bi.bx, bi.by, v01, v23, 1, &bi.fx[1], &bi.fy[1]);
+        }
         obmc_item_slow < PC > (job, bi, r2, s2, tc, s_wx, s_wy, acc);
       }
     }
   }
   __syncthreads ();
-
   obmc_finish (job, acc, tid, x_lo, y_lo, x_hi, y_hi);
 }
 
@@ -672,7 +749,7 @@ int
 launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant)
 {
   if (variant == 1)
-    hipLaunchKernelGGL ((obmc_tile_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), 0, stream,
+    hipLaunchKernelGGL ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), 0, stream,
         d_jobs, njobs);
   else
     hipLaunchKernelGGL ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,
@@ -686,12 +763,12 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 }                               // namespace
 
 // variant 0: per-pixel kernel (any weights), 64x4 tiles
-// variant 1: LDS-accumulate tile kernel (default weights), 128x32 tiles
+// variant 1: LDS-accumulate item kernel (default weights), 128x32 tiles
 void
 obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 {
   (void) xoff;
-  if (variant == 1) {
+  if (variant >= 1) {
     *tiles_x = (w + kFTW - 1) / kFTW;
     *tiles_y = (h + kFTH - 1) / kFTH;
   } else {

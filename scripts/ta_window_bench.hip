@@ -42,8 +42,9 @@ __global__ __launch_bounds__ (256) void k (const uint8_t * img, const int2 * win
   out[tid] = acc;
 }
 
-int main ()
+int main (int argc, char **argv)
 {
+  const bool shuffle = argc > 1;
   const int W = 7680, H = 4320;         // one 2160p half-pel luma image (33 MB)
   uint8_t *img; (void) hipMalloc (&img, (size_t) W * H + 65536);
   (void) hipMemset (img, 1, (size_t) W * H + 65536);
@@ -62,11 +63,19 @@ int main ()
           int x = 64 + tx * 256 + bx * 16 + dx, y = 64 + ty * 64 + by * 16 + dy;
           win[n++] = make_int2 (x, y);
         }
+  if (shuffle) {                // emulate the mode-sorted block order: random within each 64-window tile
+    for (int t0 = 0; t0 + 64 <= n; t0 += 64)
+      for (int i = 63; i > 0; i--) {
+        s = s * 1664525u + 1013904223u;
+        int j = (s >> 8) % (i + 1);
+        int2 tmp = win[t0 + i]; win[t0 + i] = win[t0 + j]; win[t0 + j] = tmp;
+      }
+  }
   int2 *d_win; (void) hipMalloc (&d_win, n * 8); (void) hipMemcpy (d_win, win.data (), n * 8, hipMemcpyHostToDevice);
   uint32_t *out; (void) hipMalloc (&out, 4 * 256 * 16384);
   hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
   const char *names[] = { "linear, x3 2 lanes/row", "tiled 16x8, 3 chunks/row", "tiled 16x8, 2 chunks/row", "tiled 32x4, 3 chunks/row" };
-  printf ("%d windows\n", n);
+  printf ("%d windows%s\n", n, shuffle ? " (shuffled within tiles)" : "");
   for (int mode = 0; mode < 4; mode++) {
     const int grid = 9 * 1024, iters = 8;
     float ms = 0;
