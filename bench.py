@@ -57,7 +57,7 @@ class Workload:
         self.ref_np = [[synth.picture_u8(h, w, seed=seed + 100 + 10 * r + k) for k, (h, w) in
                         enumerate(dims)] for r in range(2)]
         self.ref = [[ctx.upload(p) for p in comps] for comps in self.ref_np]
-        self.hp = [[ctx.plane(2 * h, 2 * w, np.uint8) for (h, w) in dims] for _ in range(2)]
+        self.hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
         self.up_pairs = [(self.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
         self.iwt_pairs, self.obmc_jobs = [], []
         self.coeff_np, self.mv_np, self.out = [], [], []

@@ -162,15 +162,33 @@ int schro_hip_convert_u8_batch (SchroHipContext * ctx,
  *   HP[2y+1][2x+1] = hv-half  (the reference's planes 0,1,2,3).
  * No aprons are stored: the OBMC kernel clamps the half-pel coordinate to
  * [0, 2w-2] x [0, 2h-2], which is what the reference's 32-pixel aprons
- * materialise. */
+ * materialise.
+ *
+ * Memory layout of HP ("tiled 16x8"): OBMC gathers a 24-byte x 24-row window of
+ * HP per 12x12 block and reference, and on MI355X the cost of that gather is
+ * the number of 128-byte cache lines it touches.  HP is therefore stored so
+ * that one line holds 16 bytes x 8 rows instead of 128 bytes of one row:
+ *   offset (x, y) = (y >> 3) * 8 * stride + (x >> 4) * 128 + (y & 7) * 16 + (x & 15)
+ * with stride % 16 == 0 and the buffer holding round_up (2*height, 8) rows of
+ * `stride` bytes (the same size as a linear image of that many rows).
+ * schro_hip_upsampled_bytes () gives stride and size,
+ * schro_hip_upsampled_download () copies an HP image to the host in linear
+ * order.  Plain (not upsampled) frames are linear. */
 typedef struct {
   const uint8_t *src;
   int src_stride;
-  uint8_t *dst;
-  int dst_stride;               /* bytes, >= 2*width */
+  uint8_t *dst;                 /* tiled 16x8, see above */
+  int dst_stride;               /* bytes, >= 2*width, multiple of 16 */
   int width;
   int height;
 } SchroHipUpsamplePlane;
+
+/* bytes to allocate for the HP image of a width x height component; *stride
+ * receives its row pitch */
+size_t schro_hip_upsampled_bytes (int width, int height, int *stride);
+/* HP image (2*width x 2*height bytes, tiled, on the device) -> linear host rows */
+int schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride,
+    const void *dev, int dev_stride, int width, int height);
 
 int schro_hip_upsample_batch (SchroHipContext * ctx,
     const SchroHipUpsamplePlane * planes, int nplanes);

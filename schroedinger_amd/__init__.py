@@ -65,6 +65,32 @@ class DevicePlane:
             self.ptr = None
 
 
+class HpPlane(DevicePlane):
+    """The half-pel (2x upsampled) image of a width x height u8 component: 2*height x
+    2*width samples in the tiled 16x8 layout of include/schro_hip.h."""
+
+    def __init__(self, ctx, height, width):
+        self.ctx = ctx
+        self.dtype = np.dtype(np.uint8)
+        self.comp_height, self.comp_width = int(height), int(width)
+        self.height, self.width = 2 * self.comp_height, 2 * self.comp_width
+        st = C.c_int(0)
+        self.nbytes = ctx.lib.schro_hip_upsampled_bytes(self.comp_width, self.comp_height, C.byref(st))
+        self.stride = st.value
+        self.ptr = ctx.alloc(self.nbytes)
+
+    def upload(self, a):
+        raise SchroHipError("half-pel images are produced by upsample_batch")
+
+    def download(self):
+        """Linear (2*height, 2*width) array."""
+        out = np.empty((self.height, self.width), np.uint8)
+        check(self.ctx.lib.schro_hip_upsampled_download(
+            self.ctx.h, out.ctypes.data_as(C.c_void_p), out.strides[0], self.ptr, self.stride,
+            self.comp_width, self.comp_height))
+        return out
+
+
 class Context:
     """One exec-domain context: device, stream, memory domain."""
 
@@ -124,6 +150,10 @@ class Context:
 
     def plane(self, height, width, dtype, stride=None):
         return DevicePlane(self, height, width, dtype, stride)
+
+    def hp_plane(self, height, width):
+        """Half-pel image buffer for a height x width u8 component (upsample_batch's dst)."""
+        return HpPlane(self, height, width)
 
     def upload(self, a, stride=None):
         a = np.ascontiguousarray(a)

@@ -619,6 +619,38 @@ schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * 
   return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
 }
 
+size_t
+schro_hip_upsampled_bytes (int width, int height, int *stride)
+{
+  if (width <= 0 || height <= 0)
+    return 0;
+  const size_t st = round_up ((size_t) width * 2, 64);
+  if (stride)
+    *stride = (int) st;
+  return st * round_up ((size_t) height * 2, 8);
+}
+
+int
+schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride, const void *dev,
+    int dev_stride, int width, int height)
+{
+  SCHRO_HIP_REQUIRE (ctx && host && dev && width > 0 && height > 0 && dev_stride >= 2 * width
+      && dev_stride % 16 == 0 && host_stride >= 2 * width, "upsampled_download: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  const size_t rows = round_up ((size_t) height * 2, 8);
+  std::vector < uint8_t > raw ((size_t) dev_stride * rows);
+  SCHRO_HIP_CHECK (hipMemcpyAsync (raw.data (), dev, raw.size (), hipMemcpyDeviceToHost, ctx->stream));
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (int y = 0; y < 2 * height; y++) {
+    uint8_t *d = (uint8_t *) host + (size_t) y * host_stride;
+    for (int x = 0; x < 2 * width; x += 16) {
+      const int n = std::min (16, 2 * width - x);
+      memcpy (d + x, raw.data () + hp_offset (x, y, dev_stride), (size_t) n);
+    }
+  }
+  return 0;
+}
+
 int
 schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * planes, int nplanes)
 {
@@ -632,8 +664,8 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
   for (int p = 0; p < nplanes; p++) {
     const SchroHipUpsamplePlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0
-        && pl.dst_stride >= 2 * pl.width && pl.src_stride >= pl.width,
-        "upsample_batch: plane %d invalid", p);
+        && pl.dst_stride >= 2 * pl.width && pl.dst_stride % 16 == 0 && pl.src_stride >= pl.width,
+        "upsample_batch: plane %d invalid (the half-pel image needs a stride that is a multiple of 16)", p);
     UpsampleJob & j = jobs[p];
     j.src = pl.src;
     j.dst = pl.dst;
@@ -792,7 +824,8 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     c->v_shift = k ? v_shift : 0;
     int mul = upsampled ? 2 : 1;
     c->stride = (int) round_up ((size_t) c->width * mul * bpp, 64);
-    c->length = c->stride * c->height * mul;
+    // half-pel images are tiled 16x8: whole tile rows
+    c->length = c->stride * (upsampled ? (int) round_up ((size_t) c->height * 2, 8) : c->height);
     total += round_up ((size_t) c->length, 256);
   }
   void *base = schro_hip_domain_alloc (ctx, total);

@@ -229,8 +229,10 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
         __builtin_amdgcn_perm (d1, c0, 0x07030602u));
     const uint2 odd = make_uint2 (__builtin_amdgcn_perm (d3, c2, 0x05010400u),
         __builtin_amdgcn_perm (d3, c2, 0x07030602u));
-    uint8_t *de = job.dst + (size_t) (2 * gy) * job.dst_stride + 2 * gx;
-    uint8_t *dod = de + job.dst_stride;
+    // tiled 16x8 (include/schro_hip.h): rows 2gy and 2gy+1 are in the same tile, 2gx is a
+    // multiple of 8, so each 8-byte piece stays inside one 16-byte tile row
+    uint8_t *de = job.dst + hp_offset (2 * gx, 2 * gy, job.dst_stride);
+    uint8_t *dod = de + 16;
     if (gx + 4 <= w && (((uintptr_t) de | (uintptr_t) dod) & 7) == 0) {
       gstore < u32x2 > (de, (u32x2) { even.x, even.y });
       gstore < u32x2 > (dod, (u32x2) { odd.x, odd.y });

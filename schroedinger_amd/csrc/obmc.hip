@@ -50,7 +50,7 @@ get_ramp (int x, int offset)
 {
   if (offset == 1)
     return x == 0 ? 3 : 5;
-  return 1 + (6 * x + offset - 1) / (2 * offset - 1);
+  return 1 + fdiv (6 * x + offset - 1, 2 * offset - 1);
 }
 
 // schromotion.c:57-69
@@ -67,7 +67,7 @@ obmc_weight_1d (int i, int blen, int offset)
 }
 
 // One reference sample at (sx, sy) in 1/2^prec pel units.
-// PC 0: plain plane.  PC 1: half-pel image.  PC 2: 1/4- or 1/8-pel bilinear
+// PC 0: plain plane.  PC 1: half-pel image (tiled 16x8).  PC 2: 1/4- or 1/8-pel bilinear
 // of four half-pel samples (orc_combine4_nxm_u8, schroorc.orc:1635-1662; the
 // avg2 / copy special cases of schroframe.c:2306-2350 are the same formula).
 template < int PC >
@@ -79,15 +79,14 @@ fetch_ref (const uint8_t * __restrict__ ref, int stride, int w, int h, int sx, i
     return gload < uint8_t > (ref + (size_t) Y * stride + X);
   } else if constexpr (PC == 1) {
     int X = clampi (sx, 0, 2 * w - 2), Y = clampi (sy, 0, 2 * h - 2);
-    return gload < uint8_t > (ref + (size_t) Y * stride + X);
+    return gload < uint8_t > (ref + hp_offset (X, Y, stride));
   } else {
     int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
     int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
     int X0 = clampi (hx, 0, 2 * w - 2), X1 = clampi (hx + 1, 0, 2 * w - 2);
     int Y0 = clampi (hy, 0, 2 * h - 2), Y1 = clampi (hy + 1, 0, 2 * h - 2);
-    const uint8_t *r0 = ref + (size_t) Y0 * stride, *r1 = ref + (size_t) Y1 * stride;
-    int p00 = gload < uint8_t > (r0 + X0), p01 = gload < uint8_t > (r0 + X1);
-    int p10 = gload < uint8_t > (r1 + X0), p11 = gload < uint8_t > (r1 + X1);
+    int p00 = gload < uint8_t > (ref + hp_offset (X0, Y0, stride)), p01 = gload < uint8_t > (ref + hp_offset (X1, Y0, stride));
+    int p10 = gload < uint8_t > (ref + hp_offset (X0, Y1, stride)), p11 = gload < uint8_t > (ref + hp_offset (X1, Y1, stride));
     int v = (4 - ry) * ((4 - rx) * p00 + rx * p01) + ry * ((4 - rx) * p10 + rx * p11);
     return (v + 8) >> 4;
   }
@@ -277,7 +276,7 @@ floor_div (int a, int b)
   return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-constexpr int kAccStride = 141; // odd: block rows land on different LDS banks
+constexpr int kAccStride = 148; // 20 mod 64: block rows spread over the LDS banks; rows stay 16-byte aligned
 
 // One decoded block.  Everything that is uniform over the block's pixels is
 // worked out once here: position, prediction mode, get_block's clamped fetch
@@ -333,7 +332,7 @@ fetch4_clamped (const uint8_t * __restrict__ ref, int stride, int w, int h, int 
   return pk;
 }
 
-constexpr int kAccMargin = 3;   // a 4-pixel segment may stick out of the tile by 3 pixels
+constexpr int kAccMargin = 4;   // a 4-pixel segment may stick out of the tile by 3 pixels; 4 keeps rows aligned
 
 struct TileCtx {
   int x_lo, x_hi, y_lo, y_hi;
@@ -388,6 +387,43 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
 __device__ __forceinline__ void
 obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, int x_hi, int y_hi)
 {
+  typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+  // whole-width tile, s16 residual, aligned rows: 8 pixels per lane with packed 16-bit
+  // arithmetic (the reference's adds wrap at 16 bits: v_pk_add_u16 does exactly that)
+  const bool fast = job.res_bpp == 2 && x_hi - x_lo == kFTW
+      && ((((uintptr_t) job.residual) | (uintptr_t) job.residual_stride) & 15) == 0
+      && ((((uintptr_t) job.out) | (uintptr_t) job.out_stride) & 7) == 0;
+  if (fast) {
+    const int n = (y_hi - y_lo) * (kFTW / 8);
+    for (int it = tid; it < n; it += kThreads) {
+      const int g = it & (kFTW / 8 - 1), yy = it >> 4;
+      static_assert (kFTW / 8 == 16, "8-pixel groups per tile row");
+      const int x = x_lo + 8 * g, y = y_lo + yy;
+      const int4 *ap = reinterpret_cast < const int4 * >(acc + yy * kAccStride + kAccMargin + 8 * g);
+      const int4 a0 = ap[0], a1 = ap[1];
+      const u32x4 r = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * x);
+      const uint32_t av[4] = {
+        __builtin_amdgcn_perm ((uint32_t) a0.y, (uint32_t) a0.x, 0x05040100u),
+        __builtin_amdgcn_perm ((uint32_t) a0.w, (uint32_t) a0.z, 0x05040100u),
+        __builtin_amdgcn_perm ((uint32_t) a1.y, (uint32_t) a1.x, 0x05040100u),
+        __builtin_amdgcn_perm ((uint32_t) a1.w, (uint32_t) a1.z, 0x05040100u)
+      };
+      const uint32_t rv[4] = { r.x, r.y, r.z, r.w };
+      uint32_t t[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s16x2 v = (__builtin_bit_cast (s16x2, av[k]) + (short) 32) >> 6;
+        v = v + __builtin_bit_cast (s16x2, rv[k]);
+        v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+        t[k] = __builtin_bit_cast (uint32_t, v);
+      }
+      u32x2 o;
+      o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
+      o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
+      gstore < u32x2 > (job.out + (size_t) y * job.out_stride + x, o);
+    }
+    return;
+  }
   // orc_rrshift6_add_s16_2d / _s32_2d on 4 pixels per lane
   for (int it = tid; it < kFTH * kFTW / 4; it += kThreads) {
     const int g = it % (kFTW / 4), yy = it / (kFTW / 4);
@@ -450,15 +486,16 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
 // TCP_TCC_READ_REQ; MI355X_MICROARCH.md gives 8.6 - 18 TB/s for gathers) -- not by
 // instruction issue, occupancy (3, 4 or 5 workgroups per CU: same time) or LDS atomics.
 
-constexpr int kItemBlkCap = 128;        // decoded blocks per chunk
+constexpr int kItemBlkCap = 192;        // decoded blocks per chunk (<= kThreads: one per thread)
 constexpr int kItemCap = 1536;          // (block, row) items per chunk
-constexpr int kItemWCap = 1024;         // (row, segment) weight words
+constexpr int kItemWCap = 256;          // (row, segment) weight words; larger blocks take the rim path
+constexpr int kItemStage = 2576;        // staging bytes per wave (half-pel references), 16 spare
 
 struct __attribute__ ((aligned (16))) HotBlk {
   int y, x;                     // block origin relative to the tile
   int mode_dc;                  // as BlkInfo
-  int rows;                     // first block row inside the tile | rows inside << 8
-  int off[2];                   // byte offset of the first sample of the window
+  int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
+  int off[2];                   // first sample of the window: byte offset (plain plane) / of its chunk's tile row (half-pel image)
   uint32_t wpk[2];              // packed bilinear weights
 };
 
@@ -481,7 +518,67 @@ struct ItemLane {
   int seg_bytes;                // byte offset of the segment inside the sample window
   int tw3;                      // tile width + 3 (range test of a segment)
   bool active;                  // lanes beyond the last whole item of a pass idle
+  int ipw;                      // items per wave pass
+  // half-pel references (tiled 16x8): the load role of this lane, two slots per pass
+  uint8_t *stage;               // this wave's staging buffer
+  int ld_item[2], ld_row[2], ld_x8[2];  // item within the pass, half-pel row 0 / 1, chunk * 128
+  int ld_wr[2];                 // where the chunk is staged (lanes without a slot: a spare chunk)
+  int rd_base, rd_row1;         // compute role: staged bytes of this segment, second row
 };
+
+// Four predicted pixels of one reference from a tiled half-pel image.  The wave first
+// stages, for each of its items, the aligned 16-byte chunks that cover the item's
+// 8 * nseg sample bytes of row(s) 2 row (+ 1) -- every lane loads two chunks, whatever
+// item they belong to -- then each lane reads its own 8 (+ 8) bytes back at the window's
+// byte phase.  16-byte chunk = one row of a 16x8 tile: the chunks of one item's two rows
+// mostly share a cache line, and so do those of the rows above and below.
+template < int PC >
+__device__ __forceinline__ void
+fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, const HotBlk * s_hot,
+    const int *ld_blk, const int *ld_y, uint32_t own_phase, uint32_t wpk, int *val)
+{
+  static_assert (PC >= 1, "plain references are linear");
+  const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
+  u32x4 v[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    // hp_offset of chunk (ld_x / 16, ld_y) of the block's window: off[r] is the offset of
+    // the window's first chunk in the tile row of its first sample row, the phase (y & 7)
+    // of that row comes with it
+    const HotBlk & lb = s_hot[ld_blk[j]];
+    const uint32_t yy = ((uint32_t) lb.rows >> (16 + 8 * r) & 7u) + (uint32_t) ld_y[j];
+    const uint32_t o = (uint32_t) lb.off[r] + __umul24 (yy >> 3, tile_row_bytes) + ((yy & 7u) << 4) + (uint32_t) il.ld_x8[j];
+    v[j] = gload < u32x4 > (job.ref[r] + o);
+  }
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+    *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr[j]) = v[j];       // unused slots land in a spare chunk
+  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier ();
+  const int off = il.rd_base + (int) (own_phase >> 4);          // + (x of the first sample & 15)
+  const uint32_t *p = reinterpret_cast < const uint32_t * >(il.stage + (off & ~3));
+  const uint32_t sh = off & 3;
+  const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
+  const uint32_t alo = __builtin_amdgcn_alignbyte (a1, a0, sh), ahi = __builtin_amdgcn_alignbyte (a2, a1, sh);
+  if constexpr (PC == 1) {
+    val[0] = alo & 0xff;
+    val[1] = (alo >> 16) & 0xff;
+    val[2] = ahi & 0xff;
+    val[3] = (ahi >> 16) & 0xff;
+    (void) wpk;
+  } else {
+    const uint32_t *q = reinterpret_cast < const uint32_t * >(il.stage + (off & ~3) + il.rd_row1);
+    const uint32_t b0 = q[0], b1 = q[1], b2 = q[2];
+    const uint32_t blo = __builtin_amdgcn_alignbyte (b1, b0, sh), bhi = __builtin_amdgcn_alignbyte (b2, b1, sh);
+    val[0] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x05040100u), wpk, 8u, false) >> 4);
+    val[1] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x07060302u), wpk, 8u, false) >> 4);
+    val[2] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x05040100u), wpk, 8u, false) >> 4);
+    val[3] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x07060302u), wpk, 8u, false) >> 4);
+  }
+  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier ();     // the next staging pass may overwrite
+}
 
 // one pass of one class: CLS 0 both references, 1 / 2 one reference, 3 DC
 template < int PC, int CLS >
@@ -495,29 +592,43 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
   const HotBlk & hb = s_hot[e & 0xff];
   const int row = e >> 8;
   const int yrel = hb.y + row, xrel = hb.x + 4 * il.seg;
-  const uint32_t w4 = s_w4[row * nseg + il.seg];
+  const uint32_t w4 = s_w4[__umul24 (row, nseg) + il.seg];
   int v0[4], v1[4];
   if constexpr (CLS == 3) {
     v0[0] = v0[1] = v0[2] = v0[3] = v1[0] = v1[1] = v1[2] = v1[3] = hb.mode_dc >> 8;
   } else {
     constexpr int r0 = CLS == 2 ? 1 : 0;
-    fetch4_inside < PC > (job.ref[r0] + (hb.off[r0] + (row * kStep) * job.ref_stride[r0] + il.seg_bytes),
-        job.ref_stride[r0], hb.wpk[r0], v0);
-    if constexpr (CLS == 0) {
-      fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
-          job.ref_stride[1], hb.wpk[1], v1);
+    if constexpr (PC == 0) {
+      fetch4_inside < PC > (job.ref[r0] + (hb.off[r0] + (row * kStep) * job.ref_stride[r0] + il.seg_bytes),
+          job.ref_stride[r0], hb.wpk[r0], v0);
+      if constexpr (CLS == 0)
+        fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
+            job.ref_stride[1], hb.wpk[1], v1);
     } else {
+      // load role: the two (item, row, chunk) slots of this lane, shared by both references
+      int ld_blk[2], ld_y[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int el = s_item[min (i0 + il.ld_item[j], hi - 1)];
+        ld_blk[j] = el & 0xff;
+        ld_y[j] = 2 * (el >> 8) + il.ld_row[j];
+      }
+      fetch4_tiled < PC > (job, r0, il, s_hot, ld_blk, ld_y, ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, hb.wpk[r0], v0);
+      if constexpr (CLS == 0)
+        fetch4_tiled < PC > (job, 1, il, s_hot, ld_blk, ld_y, ((uint32_t) hb.rows >> 24) & 0xffu, hb.wpk[1], v1);
+    }
+    if constexpr (CLS != 0) {
 #pragma unroll
       for (int k = 0; k < 4; k++)
         v1[k] = v0[k];
     }
   }
   if (il.active && it < hi && (unsigned) (xrel + 3) < (unsigned) il.tw3) {
-    int *ap = acc + yrel * kAccStride + kAccMargin + xrel;
+    int *ap = acc + (__umul24 (yrel, kAccStride) + kAccMargin + xrel);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int pred = CLS == 0 ? (v0[k] + v1[k] + 1) >> 1 : v0[k];
-      atomicAdd (ap + k, pred * (int) ((w4 >> (8 * k)) & 0xff));
+      atomicAdd (ap + k, __mul24 (pred, (int) ((w4 >> (8 * k)) & 0xff)));       // only the low 16 bits matter
     }
   }
 }
@@ -535,24 +646,26 @@ template < int PC >
 __global__ __launch_bounds__ (kThreads)
 void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 {
-  __shared__ int acc[kFTH * kAccStride];
+  __shared__ __attribute__ ((aligned (16))) int acc[kFTH * kAccStride];
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
   __shared__ HotBlk s_hot[kItemBlkCap];
   __shared__ uint16_t s_item[kItemCap];
   __shared__ uint32_t s_w4[kItemWCap];
-  __shared__ int s_start[kItemBlkCap + 1];      // first item of each sorted block
+  __shared__ uint16_t s_start[kThreads + 2];    // first item of each sorted block
   __shared__ int s_cnt[8];
+  __shared__ __attribute__ ((aligned (16))) uint8_t s_stage[PC == 0 ? 1 : kThreads / 64][PC == 0 ? 16 : kItemStage];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
-  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  const int ty = fdiv (t, job.tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x_lo = tx * kFTW, y_lo = ty * kFTH;
   const int x_hi = min (x_lo + kFTW, job.w), y_hi = min (y_lo + kFTH, job.h);
 
-  for (int it = tid; it < kFTH * kAccStride; it += kThreads)
-    acc[it] = 0;
+  static_assert ((kFTH * kAccStride) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
+  for (int it = tid; it < kFTH * kAccStride / 4; it += kThreads)
+    reinterpret_cast < int4 * >(acc)[it] = make_int4 (0, 0, 0, 0);
   if (tid < job.xblen)
     s_wx[tid] = obmc_weight_1d (tid, job.xblen, job.xoff);
   if (tid >= 64 && tid - 64 < job.yblen)
@@ -560,10 +673,11 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 
   const int xblen = job.xblen, yblen = job.yblen, xbsep = job.xbsep, ybsep = job.ybsep;
   const int xoff = job.xoff, yoff = job.yoff, prec = job.prec;
-  const int i_lo = max (0, floor_div (x_lo + xoff - xblen, xbsep) + 1);
-  const int i_hi = min (job.nbx - 1, (x_hi - 1 + xoff) / xbsep);
-  const int j_lo = max (0, floor_div (y_lo + yoff - yblen, ybsep) + 1);
-  const int j_hi = min (job.nby - 1, (y_hi - 1 + yoff) / ybsep);
+  // first / last block whose footprint meets the tile (numerators kept non-negative)
+  const int i_lo = max (0, fdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep) - 1);
+  const int i_hi = min (job.nbx - 1, fdiv (x_hi - 1 + xoff, xbsep));
+  const int j_lo = max (0, fdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep) - 1);
+  const int j_hi = min (job.nby - 1, fdiv (y_hi - 1 + yoff, ybsep));
   const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
   const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
   const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
@@ -571,14 +685,33 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   const int gh = PC == 0 ? job.h - 1 : 2 * job.h - 2;
   constexpr int kStep = PC == 0 ? 1 : 2;        // samples per pixel step
   const int nseg = (xblen + 3) >> 2;
-  const int chunk_cap = min (kItemBlkCap, kItemCap / min (yblen, kFTH));
+  const int chunk_cap = min (kItemBlkCap, fdiv (kItemCap, min (yblen, kFTH)));
+  // half-pel references: 16-byte chunks per sample row of an item, rows per item, load
+  // slots per item; a pass is as many items as 128 load slots and 64 compute lanes allow
+  const int nch = ((nseg + 1) >> 1) + 1, nrow = PC == 2 ? 2 : 1, slots = nch * nrow;
+  const int item_bytes = slots * 16 + 16;       // + 16: items start on different LDS banks
+  const int IPW = PC == 0 ? fdiv (64, nseg)     // items per wave pass
+      : min (min (fdiv (64, nseg), fdiv (128, slots)), fdiv (kItemStage - 16, item_bytes));
   ItemLane il;
-  il.slot = lane / nseg;
+  il.slot = fdiv (lane, nseg);
   il.seg = lane - il.slot * nseg;
   il.seg_bytes = il.seg * (4 * kStep);
   il.tw3 = x_hi - x_lo + 3;
-  const int IPW = 64 / nseg;                    // items per wave pass
+  il.ipw = IPW;
   il.active = il.slot < IPW;
+  il.stage = s_stage[PC == 0 ? 0 : wave];
+  il.rd_base = il.slot * item_bytes + 8 * il.seg;
+  il.rd_row1 = 16 * nch;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int sl = lane + 64 * j;
+    const int li = fdiv (sl, slots), rem = sl - li * slots;
+    const int h = fdiv (rem, nch), ch = rem - h * nch;
+    il.ld_item[j] = min (li, IPW - 1);
+    il.ld_row[j] = h;
+    il.ld_x8[j] = 128 * ch;
+    il.ld_wr[j] = li < IPW ? li * item_bytes + h * (16 * nch) + 16 * ch : kItemStage - 16;
+  }
   TileCtx tc;
   tc.x_lo = x_lo;
   tc.x_hi = x_hi;
@@ -589,7 +722,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   __syncthreads ();             // weights visible
   // the 4 weights wx * wy of every (block row, segment), one byte each (<= 64)
   for (int i = tid; i < yblen * nseg && i < kItemWCap; i += kThreads) {
-    const int r = i / nseg, sg = i - r * nseg;
+    const int r = fdiv (i, nseg), sg = i - r * nseg;
     uint32_t w = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -610,7 +743,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
     const bool have = tid < nb;
     if (have) {
       const int blk = chunk0 + tid;
-      const int bj = blk / nbi;
+      const int bj = fdiv (blk, nbi);
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
       const uint32_t flags = gload < uint32_t > (mvp);
@@ -626,6 +759,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
       int p = interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
       int md = mode | (p << 8);
+      int phases = 0;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         int fx, fy;
@@ -647,18 +781,31 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
           gx1 = gx0 + kStep * (nseg * 4 - 1);
           gy1 = gy0 + kStep * (yblen - 1);
         }
-        const bool inside = gx0 >= 0 && gy0 >= 0 && gx1 <= gw && gy1 <= gh;
+        bool inside = gx0 >= 0 && gy0 >= 0 && gx1 <= gw && gy1 <= gh;
         if (!inside)
           md |= 4 << r;
-        info.off[r] = inside ? gy0 * job.ref_stride[r] + gx0 : 0;
+        // plain planes are linear.  Half-pel images are tiled: keep the offset of the window's
+        // first 16-byte chunk in the tile row of its first sample row, and the phases
+        // (y & 7) | (x & 15) << 4 of the first sample
+        if constexpr (PC == 0) {
+          info.off[r] = inside ? gy0 * job.ref_stride[r] + gx0 : 0;
+        } else {
+          // every chunk a lane may fetch lies inside the row pitch
+          if (inside && (gx0 & ~15) + 16 * nch > job.ref_stride[r]) {
+            inside = false;
+            md |= 4 << r;
+          }
+          info.off[r] = inside ? (gy0 >> 3) * (8 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
+          phases |= inside ? ((gy0 & 7) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+        }
         info.wpk[r] = wpk;
       }
       info.mode_dc = md;
       const int ra = max (0, -info.y), rb = min (yblen, y_hi - by);
-      info.rows = ra | ((rb - ra) << 8);
+      info.rows = ra | ((rb - ra) << 8) | (phases << 16);
       const bool clamped = ((md >> 2) & md & 3) != 0;
       const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + nseg * 4 > xfold_hi;
-      key = (clamped || fold) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
+      key = (clamped || fold || yblen * nseg > kItemWCap) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
       rank = atomicAdd (&s_cnt[key], 1);
     }
     __syncthreads ();
@@ -675,29 +822,25 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       s_hot[base + rank] = info;
     }
     __syncthreads ();
-    // ---- items: exclusive prefix sum of rows-in-tile over the sorted fast blocks
-    // (waves 0 and 1 hold the <= 128 entries) --------------------------------------
-    int nrows = 0, incl = 0;
-    if (tid < kItemBlkCap) {
-      nrows = tid < cbase[4] ? (s_hot[tid].rows >> 8) : 0;
-      incl = nrows;
+    // ---- items: exclusive prefix sum of rows-in-tile over the sorted fast blocks --------
+    int nrows = tid < cbase[4] ? ((s_hot[tid].rows >> 8) & 0xff) : 0, incl = nrows;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up (incl, d);
-        if (lane >= d)
-          incl += up;
-      }
-      if (tid == 63)
-        s_cnt[5] = incl;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up (incl, d);
+      if (lane >= d)
+        incl += up;
     }
+    if (lane == 63)
+      s_cnt[4 + wave] = incl;   // s_cnt[4] (the rim class count) is already in cbase
     __syncthreads ();
-    if (tid < kItemBlkCap) {
-      if (tid >= 64)
-        incl += s_cnt[5];
+    {
+#pragma unroll
+      for (int w = 0; w < kThreads / 64 - 1; w++)
+        incl += wave > w ? s_cnt[4 + w] : 0;
       const int start = incl - nrows;
-      s_start[tid] = start;
-      if (tid == kItemBlkCap - 1)
-        s_start[kItemBlkCap] = incl;
+      s_start[tid] = (uint16_t) start;
+      if (tid == kThreads - 1)
+        s_start[kThreads] = (uint16_t) incl;
       if (tid < cbase[4]) {
         const int ra = s_hot[tid].rows & 0xff;
         for (int r = 0; r < nrows; r++)
@@ -718,9 +861,9 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       const int per_block = yblen * nseg;
       const int nslow = cbase[5] - cbase[4];
       for (int item = tid; item < nslow * per_block; item += kThreads) {
-        const int b = item / per_block;
+        const int b = fdiv (item, per_block);
         const int rem = item - b * per_block;
-        const int r2 = rem / nseg, s2 = rem - r2 * nseg;
+        const int r2 = fdiv (rem, nseg), s2 = rem - r2 * nseg;
         const HotBlk & hb = s_hot[cbase[4] + b];
         BlkInfo bi;
         bi.bx = hb.x + x_lo;
@@ -730,7 +873,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
           continue;
         bi.mode_dc = hb.mode_dc;
         {
-          const int i = (bi.bx + xoff) / xbsep, jj = (bi.by + yoff) / ybsep;
+          const int i = fdiv (bi.bx + xoff, xbsep), jj = fdiv (bi.by + yoff, ybsep);
           const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
           const uint32_t v01 = gload < uint32_t > (mvp + 12), v23 = gload < uint32_t > (mvp + 16);
           mv_origin (job, bi.bx, bi.by, v01, v23, 0, &bi.fx[0], &bi.fy[0]);

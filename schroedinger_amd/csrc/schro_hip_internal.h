@@ -113,6 +113,36 @@ gstore (P * p, V v)
   *(SCHRO_GLOBAL V *) p = v;
 }
 
+// n / d for 1 <= d <= 1024 and 0 <= n < 2^22 without the ~35-instruction integer division
+// sequence (there is no hardware divide): one v_mul_hi_u32 by ceil (2^32 / d).  Tile and
+// block geometry (tiles per row, block separation, lanes per item ...) is divided by in
+// every workgroup's prologue; the item kernel spent ~500 instructions per wave there.
+struct DivMagic {
+  uint32_t m[1025];
+};
+constexpr DivMagic
+make_div_magic ()
+{
+  DivMagic t = { };
+  for (uint32_t d = 2; d <= 1024; d++)
+    t.m[d] = (uint32_t) ((0x100000000ull + d - 1) / d);
+  return t;
+}
+static __device__ __constant__ DivMagic kDivMagic = make_div_magic ();
+
+__device__ __forceinline__ int
+fdiv (int n, int d)
+{
+  return d == 1 ? n : (int) __umulhi ((uint32_t) n, kDivMagic.m[d]);
+}
+
+// byte offset of half-pel sample (x, y) in the tiled 16x8 layout (include/schro_hip.h)
+__host__ __device__ __forceinline__ size_t
+hp_offset (int x, int y, int stride)
+{
+  return (size_t) (y >> 3) * 8 * (size_t) stride + (size_t) (x >> 4) * 128 + (size_t) ((y & 7) * 16 + (x & 15));
+}
+
 __device__ __forceinline__ int
 xcd_tile_id (int bid, int nblocks)
 {

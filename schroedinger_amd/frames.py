@@ -66,9 +66,9 @@ class DeviceFrame:
         if f.is_upsampled:      # copy the full half-pel images
             for k in range(3):
                 comp = f.components[k]
-                check(self.ctx.lib.schro_hip_download_2d(
+                check(self.ctx.lib.schro_hip_upsampled_download(
                     self.ctx.h, planes[k].ctypes.data_as(C.c_void_p), planes[k].strides[0],
-                    comp.data, comp.stride, comp.width * 2, comp.height * 2))
+                    comp.data, comp.stride, comp.width, comp.height))
             return planes
         check(self.ctx.lib.schro_hipframe_to_cpu(host.ptr(), self.p))
         return host.planes

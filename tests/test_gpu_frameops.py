@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def gpu_upsample(ctx, pic):
     h, w = pic.shape
     src = ctx.upload(pic)
-    dst = ctx.plane(2 * h, 2 * w, np.uint8).fill(0xa5)
+    dst = ctx.hp_plane(h, w).fill(0xa5)
     ctx.upsample_batch([(src, dst)])
     hp = dst.download()
     src.free()

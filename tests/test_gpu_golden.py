@@ -54,7 +54,7 @@ def test_obmc_golden(ctx):
             tmp = []
         else:
             p1, p2 = ctx.upload(r1), ctx.upload(r2)
-            g1, g2 = ctx.plane(2 * ch, 2 * cw, np.uint8), ctx.plane(2 * ch, 2 * cw, np.uint8)
+            g1, g2 = ctx.hp_plane(ch, cw), ctx.hp_plane(ch, cw)
             ctx.upsample_batch([(p1, g1), (p2, g2)])
             tmp = [p1, p2]
         d_res, out = ctx.upload(res), ctx.plane(ch, cw, np.uint8)

@@ -41,7 +41,7 @@ def run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, mv_range, seed, res
             g1, g2 = ctx.upload(r1), ctx.upload(r2)
         else:
             p1, p2 = ctx.upload(r1), ctx.upload(r2)
-            g1, g2 = ctx.plane(2 * ch, 2 * cw, np.uint8), ctx.plane(2 * ch, 2 * cw, np.uint8)
+            g1, g2 = ctx.hp_plane(ch, cw), ctx.hp_plane(ch, cw)
             ctx.upsample_batch([(p1, g1), (p2, g2)])
             keep += [p1, p2]
         d_res = ctx.upload(res)
