@@ -276,7 +276,7 @@ floor_div (int a, int b)
   return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-constexpr int kAccStride = 148; // 20 mod 64: block rows spread over the LDS banks; rows stay 16-byte aligned
+constexpr int kAccStride = 136; // 4 + 128 + 4; 8 mod 64: block rows spread over the LDS banks, rows 16-byte aligned
 
 // One decoded block.  Everything that is uniform over the block's pixels is
 // worked out once here: position, prediction mode, get_block's clamped fetch
@@ -339,6 +339,24 @@ struct TileCtx {
   int xfold_hi, yfold_hi;
 };
 
+// The accumulator tile folds rows y and y + kFTH/2 into one LDS word (low / high half):
+// the sums are 16-bit quantities (the reference accumulates in s16) and a sum of
+// pred * weight with pred <= 255 and weights adding up to 64 never carries out of its
+// half, so the hot path adds with one ds_add_u32.  This form is exact for ANY operand
+// (a DC value outside 0..255 makes the reference's s16 sum wrap): it adds inside the
+// chosen half only.
+__device__ __forceinline__ void
+acc_add_wrap (int *word, int high, int value)
+{
+  unsigned int old = *(volatile unsigned int *) word, assumed;
+  do {
+    assumed = old;
+    const unsigned int upd = high ? (assumed & 0xffffu) | ((assumed + ((unsigned int) value << 16)) & 0xffff0000u)
+        : (assumed & 0xffff0000u) | ((assumed + (unsigned int) value) & 0xffffu);
+    old = atomicCAS ((unsigned int *) word, assumed, upd);
+  } while (old != assumed);
+}
+
 // Generic item: border blocks (per-sample clamp) and picture-edge weight
 // folding (accumulate_slow, schromotion8.c:673-693).  Rare, not tuned.
 template < int PC >
@@ -369,7 +387,8 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
     wy += s_wy[2 * job.yoff - row - 1];
   if (y >= tc.yfold_hi)
     wy += s_wy[2 * (job.yblen - job.yoff) - row - 1];
-  int *arow = acc + (y - tc.y_lo) * kAccStride + kAccMargin - tc.x_lo;
+  const int yrel = y - tc.y_lo;
+  int *arow = acc + (yrel & (kFTH / 2 - 1)) * kAccStride + kAccMargin - tc.x_lo;
   for (int e = 0; e < 4; e++) {
     const int x = xs + e, idx = 4 * seg + e;
     if (idx >= job.xblen)
@@ -379,7 +398,7 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
       wx += s_wx[2 * job.xoff - idx - 1];
     if (x >= tc.xfold_hi)
       wx += s_wx[2 * (job.xblen - job.xoff) - idx - 1];
-    atomicAdd (arow + x, pred[e] * wx * wy);
+    acc_add_wrap (arow + x, yrel & (kFTH / 2), pred[e] * wx * wy);
   }
 }
 
@@ -394,33 +413,40 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
       && ((((uintptr_t) job.residual) | (uintptr_t) job.residual_stride) & 15) == 0
       && ((((uintptr_t) job.out) | (uintptr_t) job.out_stride) & 7) == 0;
   if (fast) {
-    const int n = (y_hi - y_lo) * (kFTW / 8);
-    for (int it = tid; it < n; it += kThreads) {
+    // one lane: 8 pixels of row yy (low halves) and of row yy + kFTH/2 (high halves)
+    for (int it = tid; it < (kFTH / 2) * (kFTW / 8); it += kThreads) {
       const int g = it & (kFTW / 8 - 1), yy = it >> 4;
       static_assert (kFTW / 8 == 16, "8-pixel groups per tile row");
-      const int x = x_lo + 8 * g, y = y_lo + yy;
+      const int x = x_lo + 8 * g;
       const int4 *ap = reinterpret_cast < const int4 * >(acc + yy * kAccStride + kAccMargin + 8 * g);
       const int4 a0 = ap[0], a1 = ap[1];
-      const u32x4 r = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * x);
-      const uint32_t av[4] = {
-        __builtin_amdgcn_perm ((uint32_t) a0.y, (uint32_t) a0.x, 0x05040100u),
-        __builtin_amdgcn_perm ((uint32_t) a0.w, (uint32_t) a0.z, 0x05040100u),
-        __builtin_amdgcn_perm ((uint32_t) a1.y, (uint32_t) a1.x, 0x05040100u),
-        __builtin_amdgcn_perm ((uint32_t) a1.w, (uint32_t) a1.z, 0x05040100u)
-      };
-      const uint32_t rv[4] = { r.x, r.y, r.z, r.w };
-      uint32_t t[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        s16x2 v = (__builtin_bit_cast (s16x2, av[k]) + (short) 32) >> 6;
-        v = v + __builtin_bit_cast (s16x2, rv[k]);
-        v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
-        t[k] = __builtin_bit_cast (uint32_t, v);
+      for (int half = 0; half < 2; half++) {
+        const int y = y_lo + yy + half * (kFTH / 2);
+        if (y >= y_hi)
+          continue;
+        const uint32_t sel = half ? 0x07060302u : 0x05040100u;
+        const u32x4 r = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * x);
+        const uint32_t av[4] = {
+          __builtin_amdgcn_perm ((uint32_t) a0.y, (uint32_t) a0.x, sel),
+          __builtin_amdgcn_perm ((uint32_t) a0.w, (uint32_t) a0.z, sel),
+          __builtin_amdgcn_perm ((uint32_t) a1.y, (uint32_t) a1.x, sel),
+          __builtin_amdgcn_perm ((uint32_t) a1.w, (uint32_t) a1.z, sel)
+        };
+        const uint32_t rv[4] = { r.x, r.y, r.z, r.w };
+        uint32_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          s16x2 v = (__builtin_bit_cast (s16x2, av[k]) + (short) 32) >> 6;
+          v = v + __builtin_bit_cast (s16x2, rv[k]);
+          v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+          t[k] = __builtin_bit_cast (uint32_t, v);
+        }
+        u32x2 o;
+        o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
+        o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
+        gstore < u32x2 > (job.out + (size_t) y * job.out_stride + x, o);
       }
-      u32x2 o;
-      o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
-      o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
-      gstore < u32x2 > (job.out + (size_t) y * job.out_stride + x, o);
     }
     return;
   }
@@ -430,8 +456,9 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
     const int x = x_lo + 4 * g, y = y_lo + yy;
     if (y >= y_hi || x >= x_hi)
       continue;
-    const int *ap = acc + yy * kAccStride + kAccMargin + 4 * g;
-    const int av[4] = { ap[0], ap[1], ap[2], ap[3] };
+    const int *ap = acc + (yy & (kFTH / 2 - 1)) * kAccStride + kAccMargin + 4 * g;
+    const int hs = yy & (kFTH / 2);     // 0 or 16: which half of the word
+    const int av[4] = { ap[0] >> hs, ap[1] >> hs, ap[2] >> hs, ap[3] >> hs };
     const char *rrow = (const char *) job.residual + (size_t) y * job.residual_stride;
     uint8_t *orow = job.out + (size_t) y * job.out_stride + x;
     __attribute__ ((aligned (8))) int16_t res[4];
@@ -584,7 +611,7 @@ fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, const HotBlk * s_
 template < int PC, int CLS >
 __device__ __forceinline__ void
 item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
-    const uint32_t * s_w4, int nseg, int *acc, int i0, int hi)
+    const uint32_t * s_w4, int nseg, int *acc, int i0, int hi, bool exact)
 {
   constexpr int kStep = PC == 0 ? 1 : 2;
   const int it = i0 + il.slot;
@@ -624,11 +651,18 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
     }
   }
   if (il.active && it < hi && (unsigned) (xrel + 3) < (unsigned) il.tw3) {
-    int *ap = acc + (__umul24 (yrel, kAccStride) + kAccMargin + xrel);
+    // rows yrel and yrel + 16 share a word (low / high half); pred <= 255 here
+    int *ap = acc + (__umul24 (yrel & (kFTH / 2 - 1), kAccStride) + kAccMargin + xrel);
+    const int hs = yrel & (kFTH / 2);
+    static_assert (kFTH / 2 == 16, "the high half of an accumulator word is bit 16 up");
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int pred = CLS == 0 ? (v0[k] + v1[k] + 1) >> 1 : v0[k];
-      atomicAdd (ap + k, __mul24 (pred, (int) ((w4 >> (8 * k)) & 0xff)));       // only the low 16 bits matter
+      const int v = __mul24 (pred, (int) ((w4 >> (8 * k)) & 0xff));
+      if (exact)                // some sum of this tile may wrap: no plain adds (see the kernel)
+        acc_add_wrap (ap + k, hs, v);
+      else
+        atomicAdd (ap + k, v << hs);
     }
   }
 }
@@ -636,23 +670,24 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
 template < int PC, int CLS >
 __device__ __forceinline__ void
 item_class (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
-    const uint32_t * s_w4, int nseg, int *acc, int first, int hi, int stride)
+    const uint32_t * s_w4, int nseg, int *acc, int first, int hi, int stride, bool exact)
 {
   for (int i0 = first; i0 < hi; i0 += stride)
-    item_pass < PC, CLS > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi);
+    item_pass < PC, CLS > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi, exact);
 }
 
 template < int PC >
-__global__ __launch_bounds__ (kThreads)
+__global__ __launch_bounds__ (kThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
 void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 {
-  __shared__ __attribute__ ((aligned (16))) int acc[kFTH * kAccStride];
+  __shared__ __attribute__ ((aligned (16))) int acc[(kFTH / 2) * kAccStride];   // rows y and y + 16 per word
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
   __shared__ HotBlk s_hot[kItemBlkCap];
   __shared__ uint16_t s_item[kItemCap];
   __shared__ uint32_t s_w4[kItemWCap];
   __shared__ uint16_t s_start[kThreads + 2];    // first item of each sorted block
   __shared__ int s_cnt[8];
+  __shared__ int s_wide;
   __shared__ __attribute__ ((aligned (16))) uint8_t s_stage[PC == 0 ? 1 : kThreads / 64][PC == 0 ? 16 : kItemStage];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
@@ -663,8 +698,8 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   const int x_lo = tx * kFTW, y_lo = ty * kFTH;
   const int x_hi = min (x_lo + kFTW, job.w), y_hi = min (y_lo + kFTH, job.h);
 
-  static_assert ((kFTH * kAccStride) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
-  for (int it = tid; it < kFTH * kAccStride / 4; it += kThreads)
+  static_assert (((kFTH / 2) * kAccStride) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
+  for (int it = tid; it < (kFTH / 2) * kAccStride / 4; it += kThreads)
     reinterpret_cast < int4 * >(acc)[it] = make_int4 (0, 0, 0, 0);
   if (tid < job.xblen)
     s_wx[tid] = obmc_weight_1d (tid, job.xblen, job.xoff);
@@ -731,10 +766,17 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
     s_w4[i] = w;
   }
 
+  // The hot path adds into one half of an accumulator word with a plain ds_add_u32.  That is
+  // exact as long as no 16-bit sum of the tile wraps, which only a DC value outside 0..255
+  // can cause (never in a legal stream).  If a block has one, every add of the tile goes
+  // through acc_add_wrap instead; found in a later chunk, the tile starts over that way.
+  bool exact = false;
   for (int chunk0 = 0; chunk0 < nblk; chunk0 += chunk_cap) {
     const int nb = min (chunk_cap, nblk - chunk0);
     if (tid < 8)
       s_cnt[tid] = 0;
+    if (tid == 8)
+      s_wide = 0;
     __syncthreads ();           // acc / weights ready; previous chunk's tables consumed
     // ---- decode one block per thread; class 0 two references, 1 / 2 one reference,
     // 3 DC, 4 picture rim (exact clamp / fold path) -------------------------------
@@ -805,10 +847,24 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
       info.rows = ra | ((rb - ra) << 8) | (phases << 16);
       const bool clamped = ((md >> 2) & md & 3) != 0;
       const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + nseg * 4 > xfold_hi;
-      key = (clamped || fold || yblen * nseg > kItemWCap) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
+      // (a DC value outside 0..255 would carry between the halves of an accumulator word)
+      const bool wide_dc = mode == 0 && (unsigned) p > 255u;
+      if (wide_dc)
+        s_wide = 1;
+      key = (clamped || fold || wide_dc || yblen * nseg > kItemWCap) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
       rank = atomicAdd (&s_cnt[key], 1);
     }
     __syncthreads ();
+    if (s_wide && !exact) {
+      exact = true;
+      if (chunk0 > 0) {         // adds already made may have carried: start the tile over
+        __syncthreads ();
+        for (int it = tid; it < (kFTH / 2) * kAccStride / 4; it += kThreads)
+          reinterpret_cast < int4 * >(acc)[it] = make_int4 (0, 0, 0, 0);
+        chunk0 = -chunk_cap;
+        continue;
+      }
+    }
     int cbase[6];               // first sorted position of each class
     cbase[0] = 0;
 #pragma unroll
@@ -851,10 +907,10 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 
     // ---- accumulate: every pass of a wave is IPW whole items of one class ---------
     const int first = wave * IPW, stride = (kThreads / 64) * IPW;
-    item_class < PC, 0 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[0]] + first, s_start[cbase[1]], stride);
-    item_class < PC, 1 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[1]] + first, s_start[cbase[2]], stride);
-    item_class < PC, 2 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[2]] + first, s_start[cbase[3]], stride);
-    item_class < PC, 3 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[3]] + first, s_start[cbase[4]], stride);
+    item_class < PC, 0 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[0]] + first, s_start[cbase[1]], stride, exact);
+    item_class < PC, 1 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[1]] + first, s_start[cbase[2]], stride, exact);
+    item_class < PC, 2 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[2]] + first, s_start[cbase[3]], stride, exact);
+    item_class < PC, 3 > (job, il, s_item, s_hot, s_w4, nseg, acc, s_start[cbase[3]] + first, s_start[cbase[4]], stride, exact);
 
     // ---- picture-rim blocks: exact clamp / fold path -----------------------------
     {

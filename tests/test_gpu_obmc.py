@@ -23,9 +23,11 @@ def comp_size(w, h, k, chroma):
 
 
 def run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, mv_range, seed, res_dtype=np.int16,
-             modes=(0.05, 0.45, 0.15, 0.35)):
+             modes=(0.05, 0.45, 0.15, 0.35), edit_mv=None):
     P = synth.motion_params(w, h, xblen, xbsep, prec, weights, chroma)
     mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], mv_range, seed, modes)
+    if edit_mv is not None:
+        edit_mv(mv, P)
     op = O.MotionParams(**P)
     d_mv = ctx.upload_bytes(mv)
     jobs, keep, want = [], [], []
@@ -75,6 +77,28 @@ def test_weighted_prediction(ctx, weights, prec):
     # arithmetic of the reference differ there and both must be reproduced
     for blk in ((12, 8), (16, 12)):
         run_case(ctx, 96, 64, blk[0], blk[1], prec, weights, (1, 1), 24 << prec, 5)
+
+
+def test_dc_values_outside_8_bits(ctx):
+    # A DC value outside [-128, 127] makes the reference's s16 accumulator wrap (interior
+    # blocks multiply the 16-bit dc + 128; edge blocks store it into a uint8_t).  No legal
+    # stream has one, the arithmetic is still the reference's.  The kernel packs two rows
+    # per accumulator word and must not let such a sum carry into the neighbour row: wide
+    # blocks early (first chunk of a tile) and late (chroma tiles span several chunks).
+    def widen(where):
+        def edit(mv, P):
+            nbx, nby = P["x_num_blocks"], P["y_num_blocks"]
+            dc_blocks = np.flatnonzero((mv["flags"] & 3) == 0)
+            pick = dc_blocks[::5] if where == "all" else dc_blocks[dc_blocks >= (nby - 3) * nbx][::2]
+            vals = np.array([300, -400, 1000, -3000, 32767, -32768, 127 + 129, -129], np.int16)
+            for n, b in enumerate(pick):
+                mv["v"][b, :3] = vals[(n + np.arange(3)) % len(vals)]
+        return edit
+    for where in ("all", "last-rows"):
+        for prec in (0, 2):
+            run_case(ctx, 320, 128, 12, 8, prec, (1, 1, 1), (1, 1), 8 << prec, 7,
+                     modes=(0.3, 0.3, 0.1, 0.3), edit_mv=widen(where))
+    run_case(ctx, 96, 64, 8, 4, 1, (1, 1, 1), (0, 0), 6, 9, modes=(0.5, 0.2, 0.1, 0.2), edit_mv=widen("all"))
 
 
 def test_ragged_sizes(ctx):
