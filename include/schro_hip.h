@@ -154,6 +154,35 @@ typedef struct {
 int schro_hip_convert_u8_batch (SchroHipContext * ctx,
     const SchroHipConvertPlane * planes, int nplanes, int bpp);
 
+/* Copy-out of a decoded u8 picture into a packed output frame; replaces the
+ * packed-destination case of schro_frame_convert (&output_picture, ref_output_frame)
+ * in x_combine (schrodecoder.c:2011, 2052 -> schroframe.c:869-979): chroma
+ * resampled by sample repetition / decimation to the packed format's chroma
+ * (convert_4xx_4yy, schrovirtframe.c:1438-1537), cropped or edge-extended to
+ * width x height (:1823-1895), packed (pack_yuyv / _uyvy / _ayuv :943-991,
+ * 1230-1247).  On the device this halves the bytes of the device-to-host copy
+ * of an 8-bit picture for a host that asked for a packed format.
+ * YUYV / UYVY write width / 2 four-byte groups per row, AYUV width. */
+#define SCHRO_HIP_FORMAT_YUYV 0x100     /* SCHRO_FRAME_FORMAT_YUYV, schroframe.h:36-38 */
+#define SCHRO_HIP_FORMAT_UYVY 0x101
+#define SCHRO_HIP_FORMAT_AYUV 0x102
+
+typedef struct {
+  const uint8_t *src[3];        /* Y, U, V planes (device) */
+  int src_stride[3];
+  int src_width, src_height;    /* luma size of the source picture */
+  int src_h_shift, src_v_shift; /* its chroma subsampling (0/1) */
+  uint8_t *dst;                 /* packed rows (device) */
+  int dst_stride;
+  int width, height;            /* size of the packed picture; not wider AND shorter (or
+                                 * narrower and taller) than the source: the reference
+                                 * crops both dimensions or extends both */
+  int format;                   /* SCHRO_HIP_FORMAT_YUYV / _UYVY / _AYUV */
+} SchroHipPackPlane;
+
+int schro_hip_pack_u8_batch (SchroHipContext * ctx,
+    const SchroHipPackPlane * planes, int nplanes);
+
 /* Half-pel upsampling of one u8 component; replaces
  * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /
  * schro_upsampled_gpuframe_upsample.  Device layout of an upsampled

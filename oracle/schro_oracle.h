@@ -143,6 +143,25 @@ int oracle_motion_render_u8 (const OracleMotionVector * mvs,
     int16_t * acc, int acc_stride,
     uint8_t * out, int out_stride, int width, int height);
 
+/* ---- packed output (oracle_pack.c) -------------------------------------- */
+
+/* SCHRO_FRAME_FORMAT_YUYV / _UYVY / _AYUV, schroframe.h:36-38 */
+enum { ORACLE_FORMAT_YUYV = 0x100, ORACLE_FORMAT_UYVY = 0x101, ORACLE_FORMAT_AYUV = 0x102 };
+
+/* a planar u8 picture: luma width x height, chroma subsampled by h_shift / v_shift */
+typedef struct {
+  const uint8_t *data[3];
+  int stride[3];
+  int width, height;
+  int h_shift, v_shift;
+} OraclePackSrc;
+
+/* schro_frame_convert (packed dest, planar u8 src), schroframe.c:869-979: nearest-neighbour
+ * chroma resampling to the packed format's chroma, crop or edge-extend to width x height,
+ * pack.  Rows are dst_stride bytes; YUYV / UYVY write width / 2 four-byte groups per row. */
+int oracle_pack_u8 (uint8_t * dst, int dst_stride, int format, int width, int height,
+    const OraclePackSrc * src);
+
 #ifdef __cplusplus
 }
 #endif

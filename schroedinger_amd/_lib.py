@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_timer_begin", "schro_hip_timer_end",
     "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
-    "schro_hip_upsampled_bytes", "schro_hip_upsampled_download",
+    "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
@@ -38,6 +38,14 @@ class ConvertPlane(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
                 ("width", C.c_int), ("height", C.c_int)]
+
+
+class PackPlane(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("src_stride", C.c_int * 3),
+                ("src_width", C.c_int), ("src_height", C.c_int),
+                ("src_h_shift", C.c_int), ("src_v_shift", C.c_int),
+                ("dst", C.c_void_p), ("dst_stride", C.c_int),
+                ("width", C.c_int), ("height", C.c_int), ("format", C.c_int)]
 
 
 class UpsamplePlane(C.Structure):
@@ -147,6 +155,8 @@ def load():
     L.schro_hip_convert_u8_batch.restype = i
     L.schro_hip_upsample_batch.argtypes = [vp, C.POINTER(UpsamplePlane), i]
     L.schro_hip_upsample_batch.restype = i
+    L.schro_hip_pack_u8_batch.argtypes = [vp, C.POINTER(PackPlane), i]
+    L.schro_hip_pack_u8_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]
     L.schro_hip_upsampled_bytes.restype = C.c_size_t
     L.schro_hip_upsampled_download.argtypes = [vp, vp, i, vp, i, i, i]

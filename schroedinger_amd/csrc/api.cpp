@@ -619,6 +619,59 @@ schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * 
   return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
 }
 
+int
+schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs, "pack_batch: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  int gx, rows;
+  pack_tile_geometry (&gx, &rows);
+  std::vector < PackJob > jobs (nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipPackPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.src[0] && pl.src[1] && pl.src[2] && pl.dst && pl.width > 0 && pl.height > 0
+        && pl.src_width > 0 && pl.src_height > 0, "pack_batch: plane %d invalid", p);
+    SCHRO_HIP_REQUIRE (pl.format == SCHRO_HIP_FORMAT_YUYV || pl.format == SCHRO_HIP_FORMAT_UYVY
+        || pl.format == SCHRO_HIP_FORMAT_AYUV, "pack_batch: plane %d: format 0x%x is not YUYV / UYVY / AYUV",
+        p, pl.format);
+    SCHRO_HIP_REQUIRE ((pl.src_h_shift | pl.src_v_shift) >= 0 && pl.src_h_shift <= 1 && pl.src_v_shift <= 1
+        && !(pl.src_v_shift && !pl.src_h_shift), "pack_batch: plane %d: chroma format not 4:4:4 / 4:2:2 / 4:2:0", p);
+    // schroframe.c:931-941 crops both dimensions or extends both
+    SCHRO_HIP_REQUIRE (!((pl.width < pl.src_width || pl.height < pl.src_height)
+            && (pl.width > pl.src_width || pl.height > pl.src_height)),
+        "pack_batch: plane %d: %dx%d from %dx%d mixes crop and extension", p, pl.width, pl.height,
+        pl.src_width, pl.src_height);
+    const int row_bytes = pl.format == SCHRO_HIP_FORMAT_AYUV ? 4 * pl.width : 4 * (pl.width / 2);
+    SCHRO_HIP_REQUIRE (pl.dst_stride >= row_bytes, "pack_batch: plane %d stride too small", p);
+    PackJob & j = jobs[p];
+    for (int k = 0; k < 3; k++) {
+      j.src[k] = pl.src[k];
+      j.src_stride[k] = pl.src_stride[k];
+    }
+    j.dst = pl.dst;
+    j.dst_stride = pl.dst_stride;
+    j.sw = pl.src_width;
+    j.sh = pl.src_height;
+    j.hs = pl.src_h_shift;
+    j.vs = pl.src_v_shift;
+    j.w = pl.width;
+    j.h = pl.height;
+    j.format = pl.format;
+    j.tiles_x = div_up (div_up (row_bytes, 16), gx);
+    if (j.tiles_x == 0)
+      j.tiles_x = 1;
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (pl.height, rows);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (PackJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
+  return launch_pack (ctx->stream, (const PackJob *) d_jobs, nplanes, tile_base);
+}
+
 size_t
 schro_hip_upsampled_bytes (int width, int height, int *stride)
 {
@@ -799,6 +852,29 @@ SchroHipFrame *
 schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int height,
     int upsampled)
 {
+  if (ctx && width > 0 && height > 0 && !upsampled && (format == SCHRO_HIP_FORMAT_YUYV
+          || format == SCHRO_HIP_FORMAT_UYVY || format == SCHRO_HIP_FORMAT_AYUV)) {
+    // packed output frame: one component (schroframe.c:81-99)
+    SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+    f->refcount = 1;
+    f->domain = ctx;
+    f->format = format;
+    f->width = width;
+    f->height = height;
+    SchroHipFrameData *c = &f->components[0];
+    c->format = format;
+    c->width = width;
+    c->height = height;
+    c->stride = (int) round_up ((size_t) (format == SCHRO_HIP_FORMAT_AYUV ? width * 4 : ((width + 1) & ~1) * 2), 64);
+    c->length = c->stride * height;
+    c->data = schro_hip_domain_alloc (ctx, round_up ((size_t) c->length, 256));
+    if (!c->data) {
+      free (f);
+      return nullptr;
+    }
+    f->regions[0] = c->data;
+    return f;
+  }
   int bpp = format_bpp (format);
   if (!ctx || !bpp || width <= 0 || height <= 0 || (format & 0x100) || (upsampled && bpp != 1)) {
     set_error (SCHRO_HIP_EINVAL, "frame_new_and_alloc: bad arguments");
@@ -866,6 +942,18 @@ static int
 copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src,
     hipMemcpyKind kind)
 {
+  if ((src->format & 0x100) || (dest->format & 0x100)) {
+    SCHRO_HIP_REQUIRE (src->format == dest->format, "frame copy: packed format mismatch");
+    (void) hipSetDevice (ctx->device);
+    const SchroHipFrameData *s = &src->components[0];
+    SchroHipFrameData *d = &dest->components[0];
+    int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
+    size_t row = src->format == SCHRO_HIP_FORMAT_AYUV ? (size_t) w * 4 : (size_t) (w / 2) * 4;
+    if (row && h > 0)
+      SCHRO_HIP_CHECK (hipMemcpy2DAsync (d->data, d->stride, s->data, s->stride, row, h, kind, ctx->stream));
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+    return 0;
+  }
   int bpp = format_bpp (src->format);
   SCHRO_HIP_REQUIRE (bpp && format_bpp (dest->format) == bpp, "frame copy: depth mismatch");
   (void) hipSetDevice (ctx->device);
@@ -1054,6 +1142,27 @@ schro_hipframe_convert (SchroHipFrame * dest, const SchroHipFrame * src)
   SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain,
       "hipframe_convert: both frames must live in the same device domain");
   SchroHipContext *ctx = dest->domain;
+  if (dest->format & 0x100) {
+    // copy-out into a packed frame (schroframe.c:878-899, 943-955): u8 planar sources only
+    SCHRO_HIP_REQUIRE (!(src->format & 0x100) && format_bpp (src->format) == 1,
+        "hipframe_convert: packed destinations take a planar u8 source (convert to u8 first)");
+    SchroHipPackPlane pl;
+    for (int k = 0; k < 3; k++) {
+      pl.src[k] = (const uint8_t *) src->components[k].data;
+      pl.src_stride[k] = src->components[k].stride;
+    }
+    pl.src_width = src->width;
+    pl.src_height = src->height;
+    pl.src_h_shift = SCHRO_HIP_FORMAT_H_SHIFT (src->format);
+    pl.src_v_shift = SCHRO_HIP_FORMAT_V_SHIFT (src->format);
+    pl.dst = (uint8_t *) dest->components[0].data;
+    pl.dst_stride = dest->components[0].stride;
+    pl.width = dest->width;
+    pl.height = dest->height;
+    pl.format = dest->format;
+    int r = schro_hip_pack_u8_batch (ctx, &pl, 1);
+    return r ? r : schro_hip_synchronize (ctx);
+  }
   int sb = format_bpp (src->format), db = format_bpp (dest->format);
   if (db == 1 && (sb == 2 || sb == 4)) {
     SchroHipConvertPlane planes[3];

@@ -246,7 +246,129 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   }
 }
 
+// ---- packed copy-out -----------------------------------------------------------
+// schro_frame_convert (packed dest, planar u8 src), schroframe.c:869-979, as one pass:
+// one lane writes one 16-byte group of a packed row (8 pixels of YUYV / UYVY, 4 of AYUV).
+
+constexpr int kPackGX = 64, kPackRows = 4;      // 64 groups x 4 rows per workgroup
+
+// component sample (X, Y) of the frame just before packing: nearest-neighbour chroma
+// resampling (convert_4xx_4yy, schrovirtframe.c:1438-1537) after the crop / edge-extend
+// clamp (crop_u8, edge_extend_u8 :1823-1895)
+__device__ __forceinline__ uint32_t
+pack_sample (const PackJob & job, int comp, int t_hs, int X, int Y)
+{
+  int x, y;
+  if (comp == 0) {
+    x = min (X, job.sw - 1);
+    y = min (Y, job.sh - 1);
+  } else {
+    const int sw = (job.sw + (1 << t_hs) - 1) >> t_hs;
+    const int Xc = min (X, sw - 1), Yc = min (Y, job.sh - 1);
+    x = t_hs == job.hs ? Xc : (t_hs > job.hs ? 2 * Xc : Xc >> 1);
+    y = job.vs ? Yc >> 1 : Yc;
+  }
+  return gload < uint8_t > (job.src[comp] + (size_t) y * job.src_stride[comp] + x);
+}
+
+__global__ __launch_bounds__ (kThreads)
+void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
+{
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const PackJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int ty = fdiv (t, job.tiles_x), tx = t - ty * job.tiles_x;
+  const int g = tx * kPackGX + (threadIdx.x & (kPackGX - 1));   // 16-byte group in the row
+  const int y = ty * kPackRows + (threadIdx.x >> 6);
+  static_assert (kPackGX == 64 && kThreads == kPackGX * kPackRows, "one wave per packed row");
+  if (y >= job.h)
+    return;
+  uint8_t *d = job.dst + (size_t) y * job.dst_stride + 16 * (size_t) g;
+  uint32_t o[4];
+  if (job.format == SCHRO_HIP_FORMAT_AYUV) {
+    const int x0 = 4 * g;
+    if (x0 >= job.w)
+      return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int x = x0 + k;
+      o[k] = 0xffu | (pack_sample (job, 0, 0, x, y) << 8) | (pack_sample (job, 1, 0, x, y) << 16)
+          | (pack_sample (job, 2, 0, x, y) << 24);
+    }
+    const int n = min (4, job.w - x0);
+    if (n == 4 && (((uintptr_t) d) & 15) == 0) {
+      gstore < u32x4 > (d, (u32x4) { o[0], o[1], o[2], o[3] });
+    } else {
+      for (int k = 0; k < n; k++)
+        for (int b = 0; b < 4; b++)
+          gstore < uint8_t > (d + 4 * k + b, (uint8_t) (o[k] >> (8 * b)));
+    }
+  } else {
+    const int p0 = 4 * g, pairs = job.w >> 1;   // pixel pairs: width / 2 groups of 4 bytes
+    if (p0 >= pairs)
+      return;
+    const bool yuyv = job.format == SCHRO_HIP_FORMAT_YUYV;
+    // common case: 4:2:0 or 4:2:2 source, the 8 pixels inside it and aligned: 8 + 4 + 4 bytes
+    const int cy = job.vs ? min (y, job.sh - 1) >> 1 : min (y, job.sh - 1);
+    const uint8_t *py = job.src[0] + (size_t) min (y, job.sh - 1) * job.src_stride[0] + 2 * p0;
+    const uint8_t *pu = job.src[1] + (size_t) cy * job.src_stride[1] + p0;
+    const uint8_t *pv = job.src[2] + (size_t) cy * job.src_stride[2] + p0;
+    if (job.hs == 1 && 2 * p0 + 8 <= job.sw && p0 + 4 <= pairs
+        && ((((uintptr_t) py) & 7) | (((uintptr_t) pu) & 3) | (((uintptr_t) pv) & 3)) == 0) {
+      const u32x2 yy = gload < u32x2 > (py);
+      const uint32_t uu = gload < uint32_t > (pu), vv = gload < uint32_t > (pv);
+      // (Y0 U Y1 V) or (U Y0 V Y1) per pair: bytes of yy.x / yy.y with bytes of uu and vv
+      const uint32_t uv01 = __builtin_amdgcn_perm (vv, uu, 0x05010400u);        // u0 v0 u1 v1
+      const uint32_t uv23 = __builtin_amdgcn_perm (vv, uu, 0x07030602u);        // u2 v2 u3 v3
+      if (yuyv) {
+        o[0] = __builtin_amdgcn_perm (uv01, yy.x, 0x05010400u);   // y0 u0 y1 v0
+        o[1] = __builtin_amdgcn_perm (uv01, yy.x, 0x07030602u);   // y2 u1 y3 v1
+        o[2] = __builtin_amdgcn_perm (uv23, yy.y, 0x05010400u);
+        o[3] = __builtin_amdgcn_perm (uv23, yy.y, 0x07030602u);
+      } else {
+        o[0] = __builtin_amdgcn_perm (yy.x, uv01, 0x05010400u);   // u0 y0 v0 y1
+        o[1] = __builtin_amdgcn_perm (yy.x, uv01, 0x07030602u);
+        o[2] = __builtin_amdgcn_perm (yy.y, uv23, 0x05010400u);
+        o[3] = __builtin_amdgcn_perm (yy.y, uv23, 0x07030602u);
+      }
+      if ((((uintptr_t) d) & 15) == 0) {
+        gstore < u32x4 > (d, (u32x4) { o[0], o[1], o[2], o[3] });
+        return;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = p0 + k;
+        const uint32_t y0 = pack_sample (job, 0, 1, 2 * j, y), y1 = pack_sample (job, 0, 1, 2 * j + 1, y);
+        const uint32_t u = pack_sample (job, 1, 1, j, y), v = pack_sample (job, 2, 1, j, y);
+        o[k] = yuyv ? (y0 | (u << 8) | (y1 << 16) | (v << 24)) : (u | (y0 << 8) | (v << 16) | (y1 << 24));
+      }
+    }
+    const int n = min (4, pairs - p0);
+    for (int k = 0; k < n; k++)
+      for (int b = 0; b < 4; b++)
+        gstore < uint8_t > (d + 4 * k + b, (uint8_t) (o[k] >> (8 * b)));
+  }
+}
+
 }                               // namespace
+
+void
+pack_tile_geometry (int *groups_x, int *rows)
+{
+  *groups_x = kPackGX;
+  *rows = kPackRows;
+}
+
+int
+launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int total_tiles)
+{
+  hipLaunchKernelGGL (pack_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs, njobs);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "pack launch: %s", hipGetErrorString (e));
+  return 0;
+}
 
 void
 convert_tile_geometry (int *tw, int *th)

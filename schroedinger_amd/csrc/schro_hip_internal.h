@@ -50,6 +50,19 @@ struct ConvertJob {
   int tile_base;
 };
 
+struct PackJob {
+  const uint8_t *src[3];
+  uint8_t *dst;
+  int src_stride[3];
+  int dst_stride;
+  int sw, sh;                   // source luma size
+  int hs, vs;                   // source chroma shifts
+  int w, h;                     // packed picture size
+  int format;
+  int tiles_x;
+  int tile_base;
+};
+
 struct UpsampleJob {
   const uint8_t *src;
   uint8_t *dst;
@@ -193,6 +206,8 @@ void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
 int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,
     int total_tiles, int bpp);
 void convert_tile_geometry (int *tw, int *th);
+int launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int total_tiles);
+void pack_tile_geometry (int *groups_x, int *rows);
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);
 void upsample_tile_geometry (int *tw, int *th);

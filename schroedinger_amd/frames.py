@@ -38,6 +38,23 @@ class HostFrame:
         return C.byref(self.c)
 
 
+class PackedHostFrame:
+    """A packed (YUYV / UYVY / AYUV) host frame: one component of 4-byte groups."""
+
+    def __init__(self, fmt, width, height):
+        groups = width if fmt == 0x102 else (width + 1) // 2
+        self.rows = np.zeros((height, 4 * groups), np.uint8)
+        self.c = _lib.Frame()
+        f = self.c
+        f.refcount, f.domain, f.format, f.width, f.height = 1, None, fmt, width, height
+        d = f.components[0]
+        d.format, d.data, d.stride = fmt, self.rows.ctypes.data, self.rows.strides[0]
+        d.width, d.height, d.length = width, height, self.rows.nbytes
+
+    def ptr(self):
+        return C.byref(self.c)
+
+
 class DeviceFrame:
     def __init__(self, ctx, fmt, width, height, upsampled=False):
         self.ctx = ctx
@@ -58,6 +75,11 @@ class DeviceFrame:
 
     def download(self):
         f = self.c
+        if f.format & 0x100:            # packed: rows of 4-byte groups
+            host = PackedHostFrame(f.format, f.width, f.height)
+            check(self.ctx.lib.schro_hipframe_to_cpu(host.ptr(), self.p))
+            groups = f.width if f.format == 0x102 else f.width // 2
+            return host.rows[:, :4 * groups]
         dt = _DTYPE[f.format & 0xc]
         mul = 2 if f.is_upsampled else 1
         planes = [np.zeros((f.components[k].height * mul, f.components[k].width * mul), dt)

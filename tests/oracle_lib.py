@@ -47,6 +47,8 @@ def lib():
         L.oracle_convert_u8_from_signed.argtypes = [vp, i, vp, i, i, i, i]
         L.oracle_motion_render_u8.argtypes = [vp, vp, i, vp, vp, vp, i, i, vp, i, vp, i, i, i]
         L.oracle_motion_render_u8.restype = i
+        L.oracle_pack_u8.argtypes = [vp, i, i, i, i, vp]
+        L.oracle_pack_u8.restype = i
         _LIB = L
     return _LIB
 
@@ -160,6 +162,31 @@ def convert_u8(src, width, height):
     out = np.empty((height, width), np.uint8)
     lib().oracle_convert_u8_from_signed(_ptr(out), out.strides[0], _ptr(src), src.strides[0],
                                         _bpp(src), width, height)
+    return out
+
+
+FORMAT_YUYV, FORMAT_UYVY, FORMAT_AYUV = 0x100, 0x101, 0x102
+
+
+class PackSrc(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_int * 3), ("width", C.c_int),
+                ("height", C.c_int), ("h_shift", C.c_int), ("v_shift", C.c_int)]
+
+
+def pack_u8(planes, h_shift, v_shift, fmt, width, height):
+    """schro_frame_convert (packed dest, planar u8 src): rows of 4-byte groups."""
+    planes = [np.ascontiguousarray(p, np.uint8) for p in planes]
+    src = PackSrc()
+    for k in range(3):
+        src.data[k] = planes[k].ctypes.data
+        src.stride[k] = planes[k].strides[0]
+    src.height, src.width = planes[0].shape
+    src.h_shift, src.v_shift = h_shift, v_shift
+    groups = width if fmt == FORMAT_AYUV else width // 2
+    out = np.zeros((height, 4 * groups), np.uint8)
+    if groups:
+        r = lib().oracle_pack_u8(_ptr(out), out.strides[0], fmt, width, height, C.byref(src))
+        assert r == 0, "oracle_pack_u8 refused the arguments"
     return out
 
 

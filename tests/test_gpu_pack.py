@@ -1,0 +1,79 @@
+"""GPU parity: packed copy-out (schro_hip_pack_u8_batch) vs the CPU oracle
+(schro_frame_convert with a YUYV / UYVY / AYUV destination, schroframe.c:869-979)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def planes(w, h, hs, vs, seed):
+    cw, ch = -(-w // (1 << hs)), -(-h // (1 << vs))
+    return [synth.picture_u8(h, w, seed=seed), synth.picture_u8(ch, cw, seed=seed + 1),
+            synth.picture_u8(ch, cw, seed=seed + 2)]
+
+
+def gpu_pack(ctx, cases):
+    jobs, outs = [], []
+    for (pl, hs, vs, fmt, W, H) in cases:
+        dev = [ctx.upload(p) for p in pl]
+        groups = W if fmt == sa.FORMAT_AYUV else W // 2
+        dst = ctx.plane(H, max(4 * groups, 4), np.uint8).fill(0x5a)
+        jobs.append((dev, hs, vs, dst, W, H, fmt))
+        outs.append((dst, groups, dev))
+    ctx.pack_u8_batch(jobs)
+    res = []
+    for dst, groups, dev in outs:
+        res.append(dst.download()[:, :4 * groups])
+        dst.free()
+        for d in dev:
+            d.free()
+    return res
+
+
+@pytest.mark.parametrize("fmt", [sa.FORMAT_YUYV, sa.FORMAT_UYVY, sa.FORMAT_AYUV])
+@pytest.mark.parametrize("chroma", [(0, 0), (1, 0), (1, 1)])
+def test_pack_sizes_crop_and_extend(ctx, fmt, chroma):
+    hs, vs = chroma
+    cases = []
+    for (w, h) in [(16, 8), (17, 9), (34, 20), (2, 2), (1, 1), (64, 48), (200, 37), (1030, 5)]:
+        pl = planes(w, h, hs, vs, seed=w * 7 + h)
+        for (W, H) in [(w, h), (w + 5, h + 3), (w + 1, h), (max(w - 3, 1), max(h - 2, 1)), (max(w - 1, 1), h)]:
+            cases.append((pl, hs, vs, fmt, W, H))
+    got = gpu_pack(ctx, cases)              # one launch for all of them
+    for (pl, hs, vs, f, W, H), g in zip(cases, got):
+        assert np.array_equal(g, O.pack_u8(pl, hs, vs, f, W, H)), (f, chroma, pl[0].shape, W, H)
+
+
+def test_pack_picture_sizes(ctx):
+    # decoded 1080p / 2160p 4:2:0 pictures to the packed formats an application asks for
+    for (w, h) in [(1920, 1080), (3840, 2160)]:
+        pl = planes(w, h, 1, 1, seed=11)
+        cases = [(pl, 1, 1, fmt, w, h) for fmt in (sa.FORMAT_YUYV, sa.FORMAT_UYVY, sa.FORMAT_AYUV)]
+        for (c, g) in zip(cases, gpu_pack(ctx, cases)):
+            assert np.array_equal(g, O.pack_u8(pl, 1, 1, c[3], w, h)), (c[3], w, h)
+
+
+def test_pack_rows_outside_the_picture_are_untouched(ctx):
+    pl = planes(40, 12, 1, 1, seed=5)
+    dev = [ctx.upload(p) for p in pl]
+    dst = ctx.plane(16, 96, np.uint8).fill(0x5a)        # 4 rows and 16 bytes per row to spare
+    ctx.pack_u8_batch([(dev, 1, 1, dst, 40, 12, sa.FORMAT_UYVY)])
+    out = dst.download()
+    assert np.array_equal(out[:12, :80], O.pack_u8(pl, 1, 1, O.FORMAT_UYVY, 40, 12))
+    assert (out[12:] == 0x5a).all() and (out[:, 80:] == 0x5a).all()
+
+
+def test_pack_argument_errors(ctx):
+    pl = planes(16, 8, 1, 1, seed=1)
+    dev = [ctx.upload(p) for p in pl]
+    dst = ctx.plane(16, 128, np.uint8)
+    with pytest.raises(sa.SchroHipError):
+        ctx.pack_u8_batch([(dev, 1, 1, dst, 20, 4, sa.FORMAT_YUYV)])     # wider and shorter
+    with pytest.raises(sa.SchroHipError):
+        ctx.pack_u8_batch([(dev, 1, 1, dst, 16, 8, 0x103)])              # not a format of this call
+    with pytest.raises(sa.SchroHipError):
+        ctx.pack_u8_batch([(dev, 0, 1, dst, 16, 8, sa.FORMAT_YUYV)])     # 4:4:0 does not exist

@@ -133,3 +133,22 @@ def test_error_behaviour(ctx):
     assert ctx.domain_bytes() == before
     for f in (ref, res, out):
         f.unref()
+
+
+def test_copy_out_to_packed_frames(ctx):
+    # x_combine's schro_frame_convert (&output_picture, ref_output_frame) when the application
+    # supplied a packed frame (schrodecoder.c:2011, 2052): device u8 picture -> device packed
+    # frame -> host, half the bytes of the planar download for YUYV / UYVY
+    lib = ctx.lib
+    for (w, h, fmt8, hs, vs) in [(176, 144, sa.FORMAT_U8_420, 1, 1), (97, 35, sa.FORMAT_U8_422, 1, 0),
+                                 (64, 48, sa.FORMAT_U8_444, 0, 0)]:
+        cw, ch = -(-w // (1 << hs)), -(-h // (1 << vs))
+        pl = [synth.picture_u8(h, w, seed=2), synth.picture_u8(ch, cw, seed=3), synth.picture_u8(ch, cw, seed=4)]
+        dev = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(pl, hs, vs))
+        for fmt in (sa.FORMAT_YUYV, sa.FORMAT_UYVY, sa.FORMAT_AYUV):
+            for (W, H) in [(w, h), (w + 6, h + 2), (w - 8, h - 4)]:
+                out = frames.DeviceFrame(ctx, fmt, W, H)
+                sa.check(lib.schro_hipframe_convert(out.ptr(), dev.ptr()))
+                assert np.array_equal(out.download(), O.pack_u8(pl, hs, vs, fmt, W, H)), (fmt8, fmt, W, H)
+                out.unref()
+        dev.unref()

@@ -1,0 +1,91 @@
+"""The packed copy-out oracle (oracle/oracle_pack.c) against the reference's own packer
+kernel and against the reference's line-rendering chain restated in numpy
+(schroframe.c:869-979, schrovirtframe.c:943-991, 1230-1247, 1438-1537, 1823-1895)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+
+def planes(w, h, hs, vs, seed):
+    cw, ch = -(-w // (1 << hs)), -(-h // (1 << vs))
+    return [synth.picture_u8(h, w, seed=seed), synth.picture_u8(ch, cw, seed=seed + 1),
+            synth.picture_u8(ch, cw, seed=seed + 2)]
+
+
+def chain_numpy(pl, hs, vs, fmt, W, H):
+    """The reference's virtual-frame chain, stage by stage on whole arrays."""
+    y, u, v = [p.astype(np.uint8) for p in pl]
+    h, w = y.shape
+    t_hs = 0 if fmt == O.FORMAT_AYUV else 1
+
+    def subsample(c):                   # convert_4xx_4yy: to (t_hs, v_shift 0)
+        tw = -(-w // (1 << t_hs))
+        rows = np.arange(h) >> 1 if vs else np.arange(h)
+        if t_hs == hs:
+            cols = np.arange(tw)
+        elif t_hs > hs:
+            cols = 2 * np.arange(tw)
+        else:
+            cols = np.arange(tw) >> 1
+        return c[rows][:, cols]
+
+    def fit(c, cw, ch):                 # crop_u8 / edge_extend_u8
+        rows = np.minimum(np.arange(ch), c.shape[0] - 1)
+        cols = np.minimum(np.arange(cw), c.shape[1] - 1)
+        return c[rows][:, cols]
+
+    cw = -(-W // (1 << t_hs))
+    Y, U, V = fit(y, W, H), fit(subsample(u), cw, H), fit(subsample(v), cw, H)
+    if fmt == O.FORMAT_AYUV:
+        out = np.empty((H, W, 4), np.uint8)
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = 0xff, Y, U, V
+        return out.reshape(H, 4 * W)
+    n = W // 2
+    out = np.empty((H, n, 4), np.uint8)
+    y0, y1 = Y[:, 0:2 * n:2], Y[:, 1:2 * n:2]
+    if fmt == O.FORMAT_YUYV:
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = y0, U[:, :n], y1, V[:, :n]
+    else:
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = U[:, :n], y0, V[:, :n], y1
+    return out.reshape(H, 4 * n)
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_YUYV, O.FORMAT_UYVY, O.FORMAT_AYUV])
+@pytest.mark.parametrize("chroma", [(0, 0), (1, 0), (1, 1)])
+def test_pack_matches_the_chain(fmt, chroma):
+    hs, vs = chroma
+    for (w, h) in [(16, 8), (17, 9), (34, 20), (2, 2), (1, 1), (64, 48)]:
+        pl = planes(w, h, hs, vs, seed=w * 7 + h)
+        for (W, H) in [(w, h), (w + 5, h + 3), (w + 1, h), (max(w - 3, 1), max(h - 2, 1)), (max(w - 1, 1), h)]:
+            got = O.pack_u8(pl, hs, vs, fmt, W, H)
+            assert np.array_equal(got, chain_numpy(pl, hs, vs, fmt, W, H)), (fmt, chroma, w, h, W, H)
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="reference kernels not built (oracle/_ref)")
+def test_yuyv_byte_order_is_the_reference_kernels():
+    # orc_packyuyv (schroorc.orc:718-734) compiled from the reference's schroorc-dist.c
+    w, h = 64, 4
+    pl = planes(w, h, 1, 0, seed=3)
+    want = O.pack_u8(pl, 1, 0, O.FORMAT_YUYV, w, h)
+    R = O.reforc()
+    R.orc_packyuyv.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    for i in range(h):
+        row = np.zeros(2 * w, np.uint8)
+        y, u, v = [np.ascontiguousarray(p[i]) for p in pl]
+        R.orc_packyuyv(row.ctypes.data, y.ctypes.data, u.ctypes.data, v.ctypes.data, w // 2)
+        assert np.array_equal(row, want[i])
+
+
+def test_pack_refuses_mixed_crop_and_extension():
+    pl = planes(16, 8, 1, 1, seed=1)
+    src = O.PackSrc()
+    for k in range(3):
+        src.data[k] = pl[k].ctypes.data
+        src.stride[k] = pl[k].strides[0]
+    src.width, src.height, src.h_shift, src.v_shift = 16, 8, 1, 1
+    out = np.zeros((16, 64), np.uint8)
+    assert O.lib().oracle_pack_u8(out.ctypes.data, 64, O.FORMAT_YUYV, 20, 4, C.byref(src)) == -1
