@@ -341,7 +341,9 @@ void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_til
 {
   constexpr int RP = kRegRP, H = filter_halo (F), UR = RP - 2 * H;
   const int wg = xcd_tile_id (blockIdx.x, gridDim.x);
-  const int tile = wg * (kRegThreads / 64) + (threadIdx.x >> 6);
+  // the wave index is uniform, but only readfirstlane tells the compiler: with it the tile
+  // origin, row addresses and edge tests live in SGPRs and branch on SCC
+  const int tile = __builtin_amdgcn_readfirstlane (wg * (kRegThreads / 64) + (threadIdx.x >> 6));
   if (tile >= total_tiles)
     return;
   const int lane = threadIdx.x & 63;
