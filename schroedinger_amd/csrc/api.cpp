@@ -473,7 +473,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       && !(getenv ("SCHRO_HIP_IIWT_REG") && atoi (getenv ("SCHRO_HIP_IIWT_REG")) == 0);
   int ruc = 0, rur = 0, rmin = 0;
   if (use_reg)
-    iiwt_reg_geometry (filter, &ruc, &rur, &rmin);
+    iiwt_reg_geometry (filter, 0, &ruc, &rur, &rmin);
 
   // Fused group (opt-in): SCHRO_HIP_IIWT_FUSE=n runs levels b .. b+n-1 as ONE launch of
   // the fused LDS kernel, b = SCHRO_HIP_IIWT_FUSE_BASE (default 1 where level 0 has the
@@ -513,6 +513,18 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     int tile_base = 0, rtile_base = 0;
     jobs.clear ();
     rjobs.clear ();
+    // a level of fewer register tiles than the chip has SIMDs twice over is latency, not
+    // bandwidth: use the small form (4 useful row pairs per wave)
+    int lruc = ruc, lrur = rur, lrmin = rmin, small = 0;
+    if (use_reg) {
+      long tiles = 0;
+      for (int p = 0; p < nplanes; p++)
+        tiles += (long) div_up ((planes[p].width >> level) / 2, ruc) * div_up ((planes[p].height >> level) / 2, rur);
+      const char *env = getenv ("SCHRO_HIP_IIWT_SMALL");
+      small = env ? atoi (env) != 0 : tiles < 2048;
+      if (small)
+        iiwt_reg_geometry (filter, 1, &lruc, &lrur, &lrmin);
+    }
     for (int p = 0; p < nplanes; p++) {
       const SchroHipIwtPlane & pl = planes[p];
       IwtJob j;
@@ -552,10 +564,10 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
       j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
       j.pad = 0;
-      if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= rmin) {
-        j.tiles_x = div_up (nc, ruc);
+      if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= lrmin) {
+        j.tiles_x = div_up (nc, lruc);
         j.tile_base = rtile_base;
-        rtile_base += j.tiles_x * div_up (nr, rur);
+        rtile_base += j.tiles_x * div_up (nr, lrur);
         rjobs.push_back (j);
       } else {
         j.tiles_x = div_up (nc, uc);
@@ -574,7 +586,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       return r;
     ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
     if (d_rjobs)
-      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter);
+      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter, small);
     if (!r && d_jobs)
       r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, (int) jobs.size (), tile_base, filter, bpp);
     if (r)

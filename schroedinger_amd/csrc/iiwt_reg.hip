@@ -44,7 +44,7 @@ namespace {
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
 typedef uint32_t P;             // two packed s16 samples
 
-constexpr int kRegRP = 12;      // region row pairs held by a wave
+constexpr int kRegRP = 12;      // region row pairs held by a wave (bandwidth-bound levels)
 constexpr int kRegUC = 4 * 62;  // useful columns per half per wave (lanes 1 .. 62)
 constexpr int kRegThreads = 256;
 
@@ -271,11 +271,11 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
 }
 
 // LO..HI: region row pairs that exist in the picture (compile-time: see the header)
-template < int F, int LO, int HI, bool HEDGE >
+template < int F, int RP, int LO, int HI, bool HEDGE >
 __device__ __forceinline__ void
 reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
 {
-  constexpr int RP = kRegRP, H = filter_halo (F);
+  constexpr int H = filter_halo (F);
   P E[RP][4], O[RP][4];
 
   const int cl = c0 + 4 * lane;
@@ -323,23 +323,23 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
 }
 
 // tiles whose last N region row pairs lie below the picture
-template < int F, int N >
+template < int F, int RP, int N >
 __device__ __forceinline__ void
 reg_tile_bottom (int nout, const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
 {
   if constexpr (N >= 1) {
     if (nout == N)
-      reg_tile < F, 0, kRegRP - 1 - N, true > (job, r0, c0, nr, nc, lane);
+      reg_tile < F, RP, 0, RP - 1 - N, true > (job, r0, c0, nr, nc, lane);
     else
-      reg_tile_bottom < F, N - 1 > (nout, job, r0, c0, nr, nc, lane);
+      reg_tile_bottom < F, RP, N - 1 > (nout, job, r0, c0, nr, nc, lane);
   }
 }
 
-template < int F >
+template < int F, int RP >
 __global__ __launch_bounds__ (kRegThreads)
 void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)
 {
-  constexpr int RP = kRegRP, H = filter_halo (F), UR = RP - 2 * H;
+  constexpr int H = filter_halo (F), UR = RP - 2 * H;
   const int wg = xcd_tile_id (blockIdx.x, gridDim.x);
   // the wave index is uniform, but only readfirstlane tells the compiler: with it the tile
   // origin, row addresses and edge tests live in SGPRs and branch on SCC
@@ -362,24 +362,35 @@ void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_til
   const int c0 = tx * kRegUC - 4;
   const bool hedge = c0 < 0 || c0 + 256 > nc;
   if (r0 < 0) {
-    reg_tile < F, H, RP - 1, true > (job, r0, c0, nr, nc, lane);
+    reg_tile < F, RP, H, RP - 1, true > (job, r0, c0, nr, nc, lane);
   } else if (nout == 0) {
     if (!hedge)
-      reg_tile < F, 0, RP - 1, false > (job, r0, c0, nr, nc, lane);
+      reg_tile < F, RP, 0, RP - 1, false > (job, r0, c0, nr, nc, lane);
     else
-      reg_tile < F, 0, RP - 1, true > (job, r0, c0, nr, nc, lane);
+      reg_tile < F, RP, 0, RP - 1, true > (job, r0, c0, nr, nc, lane);
   } else {
-    reg_tile_bottom < F, H > (nout, job, r0, c0, nr, nc, lane);
+    reg_tile_bottom < F, RP, H > (nout, job, r0, c0, nr, nc, lane);
   }
+}
+
+// rows per wave of the small form: 4 useful row pairs whatever the halo
+constexpr int
+small_rp (int f)
+{
+  return 4 + 2 * filter_halo (f);
 }
 
 template < int F >
 int
-launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles)
+launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, bool small)
 {
   const int wgs = (total_tiles + kRegThreads / 64 - 1) / (kRegThreads / 64);
-  hipLaunchKernelGGL ((iiwt_reg_kernel < F >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
-      njobs, total_tiles);
+  if (small)
+    hipLaunchKernelGGL ((iiwt_reg_kernel < F, small_rp (F) >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
+        d_jobs, njobs, total_tiles);
+  else
+    hipLaunchKernelGGL ((iiwt_reg_kernel < F, kRegRP >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
+        njobs, total_tiles);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "iiwt (register form) launch: %s", hipGetErrorString (e));
@@ -395,25 +406,30 @@ iiwt_reg_supported (int filter, int bpp)
   return bpp == 2 && filter != 5 && filter >= 0 && filter <= 6;
 }
 
-// a plane needs at least min_row_pairs sub-band rows (top and bottom edge in different tiles)
+// Tile geometry of the large form (12 row pairs per wave: least halo re-reading, for levels
+// that are bandwidth) or the small one (4 useful row pairs per wave: levels of a few hundred
+// tiles are the latency of one wave's serial work, so halve it and double the waves).
+// A plane needs at least min_row_pairs sub-band rows (top and bottom edge in different tiles).
 void
-iiwt_reg_geometry (int filter, int *useful_cols, int *useful_row_pairs, int *min_row_pairs)
+iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pairs, int *min_row_pairs)
 {
+  const int rp = small ? small_rp (filter) : kRegRP;
   *useful_cols = kRegUC;
-  *useful_row_pairs = kRegRP - 2 * filter_halo (filter);
-  *min_row_pairs = kRegRP - filter_halo (filter);
+  *useful_row_pairs = rp - 2 * filter_halo (filter);
+  *min_row_pairs = rp - filter_halo (filter);
 }
 
 int
-launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter)
+launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter,
+    int small)
 {
   switch (filter) {
-    case 0: return launch_reg < 0 > (stream, d_jobs, njobs, total_tiles);
-    case 1: return launch_reg < 1 > (stream, d_jobs, njobs, total_tiles);
-    case 2: return launch_reg < 2 > (stream, d_jobs, njobs, total_tiles);
-    case 3: return launch_reg < 3 > (stream, d_jobs, njobs, total_tiles);
-    case 4: return launch_reg < 4 > (stream, d_jobs, njobs, total_tiles);
-    case 6: return launch_reg < 6 > (stream, d_jobs, njobs, total_tiles);
+    case 0: return launch_reg < 0 > (stream, d_jobs, njobs, total_tiles, small);
+    case 1: return launch_reg < 1 > (stream, d_jobs, njobs, total_tiles, small);
+    case 2: return launch_reg < 2 > (stream, d_jobs, njobs, total_tiles, small);
+    case 3: return launch_reg < 3 > (stream, d_jobs, njobs, total_tiles, small);
+    case 4: return launch_reg < 4 > (stream, d_jobs, njobs, total_tiles, small);
+    case 6: return launch_reg < 6 > (stream, d_jobs, njobs, total_tiles, small);
   }
   return set_error (SCHRO_HIP_EINVAL, "iiwt (register form): filter %d not built", filter);
 }

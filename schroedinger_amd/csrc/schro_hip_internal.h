@@ -198,9 +198,10 @@ int launch_iiwt_fused (hipStream_t stream, const void *d_jobs, int njobs, int to
     int filter, int bpp, int nl);
 // register form of one level (iiwt_reg.hip): s16, filters with a small lifting halo
 bool iiwt_reg_supported (int filter, int bpp);
-void iiwt_reg_geometry (int filter, int *useful_cols, int *useful_row_pairs, int *min_row_pairs);
+void iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pairs,
+    int *min_row_pairs);
 int launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles,
-    int filter);
+    int filter, int small);
 void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
     int *useful_row_pairs);
 int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,

@@ -88,12 +88,15 @@ def test_fused_levels(ctx, filt, dtype, fuse, base, monkeypatch):
 
 
 @pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 6])
-def test_register_form_tile_edges(ctx, filt, monkeypatch):
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_register_form_tile_edges(ctx, filt, small, monkeypatch):
     # s16 planes whose sub-band width is a multiple of 4 take the register kernel
     # (iiwt_reg.hip): one wave = 248 columns x (12 - 2H) row pairs.  Sizes around its tile
     # borders: single / several column tiles, last lane inside or outside the picture, the
     # bottom tile moved up (row pairs = k * UR + 1 ...), top and bottom in one tile.
-    for (nr, nc) in [(8, 4), (10, 8), (11, 12), (12, 8), (9, 248), (17, 252), (25, 256), (26, 260), (31, 500), (67, 996)]:
+    # SCHRO_HIP_IIWT_SMALL: 12 row pairs per wave (bandwidth-bound levels) or 4 + 2H
+    monkeypatch.setenv("SCHRO_HIP_IIWT_SMALL", small)
+    for (nr, nc) in [(4, 4), (5, 8), (6, 8), (7, 12), (8, 4), (10, 8), (11, 12), (12, 8), (9, 248), (17, 252), (25, 256), (26, 260), (31, 500), (67, 996)]:
         h, w = 2 * nr, 2 * nc
         fr = synth.full_range(h, w, np.int16, seed=nr * 131 + nc)
         want = O.iiwt_2d(fr, filt)
