@@ -348,7 +348,7 @@ struct TileCtx {
 __device__ __forceinline__ void
 acc_add_wrap (int *word, int high, int value)
 {
-  unsigned int old = *(volatile unsigned int *) word, assumed;
+  unsigned int old = __hip_atomic_load ((unsigned int *) word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), assumed;
   do {
     assumed = old;
     const unsigned int upd = high ? (assumed & 0xffffu) | ((assumed + ((unsigned int) value << 16)) & 0xffff0000u)
@@ -516,7 +516,7 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
 constexpr int kItemBlkCap = 192;        // decoded blocks per chunk (<= kThreads: one per thread)
 constexpr int kItemCap = 1536;          // (block, row) items per chunk
 constexpr int kItemWCap = 256;          // (row, segment) weight words; larger blocks take the rim path
-constexpr int kItemStage = 2576;        // staging bytes per wave (half-pel references), 16 spare
+constexpr int kItemStage = 2752;        // staging bytes per wave (half-pel references) incl. spare chunks
 
 struct __attribute__ ((aligned (16))) HotBlk {
   int y, x;                     // block origin relative to the tile
@@ -546,10 +546,11 @@ struct ItemLane {
   int tw3;                      // tile width + 3 (range test of a segment)
   bool active;                  // lanes beyond the last whole item of a pass idle
   int ipw;                      // items per wave pass
-  // half-pel references (tiled 16x8): the load role of this lane, two slots per pass
+  // half-pel references (tiled 16x8): the load role of this lane -- one 16-byte chunk of
+  // each sample row of its OWN item
   uint8_t *stage;               // this wave's staging buffer
-  int ld_item[2], ld_row[2], ld_x8[2];  // item within the pass, half-pel row 0 / 1, chunk * 128
-  int ld_wr[2];                 // where the chunk is staged (lanes without a slot: a spare chunk)
+  int ld_x8;                    // chunk * 128 (byte offset of the chunk's tile column)
+  int ld_wr;                    // where the row-0 chunk is staged (lanes without a chunk: a spare one)
   int rd_base, rd_row1;         // compute role: staged bytes of this segment, second row
 };
 
@@ -561,26 +562,27 @@ struct ItemLane {
 // mostly share a cache line, and so do those of the rows above and below.
 template < int PC >
 __device__ __forceinline__ void
-fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, const HotBlk * s_hot,
-    const int *ld_blk, const int *ld_y, uint32_t own_phase, uint32_t wpk, int *val)
+fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t own_phase, int row,
+    uint32_t wpk, int *val)
 {
   static_assert (PC >= 1, "plain references are linear");
   const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
-  u32x4 v[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    // hp_offset of chunk (ld_x / 16, ld_y) of the block's window: off[r] is the offset of
-    // the window's first chunk in the tile row of its first sample row, the phase (y & 7)
-    // of that row comes with it
-    const HotBlk & lb = s_hot[ld_blk[j]];
-    const uint32_t yy = ((uint32_t) lb.rows >> (16 + 8 * r) & 7u) + (uint32_t) ld_y[j];
-    const uint32_t o = (uint32_t) lb.off[r] + __umul24 (yy >> 3, tile_row_bytes) + ((yy & 7u) << 4) + (uint32_t) il.ld_x8[j];
-    v[j] = gload < u32x4 > (job.ref[r] + o);
+  // hp_offset of chunk (ld_x8 / 128) of sample rows 2 row (+ 1) of the block's window: off_r is
+  // the offset of the window's first chunk in the tile row of its first sample row, the
+  // phase (y & 7) of that row comes with it
+  const uint32_t y0 = (own_phase & 7u) + 2u * (uint32_t) row;
+  const uint32_t o0 = (uint32_t) off_r + __umul24 (y0 >> 3, tile_row_bytes) + ((y0 & 7u) << 4) + (uint32_t) il.ld_x8;
+  const u32x4 v0 = gload < u32x4 > (job.ref[r] + o0);
+  u32x4 v1 = v0;
+  if constexpr (PC == 2) {
+    const uint32_t y1 = y0 + 1u;
+    const uint32_t o1 = (uint32_t) off_r + __umul24 (y1 >> 3, tile_row_bytes) + ((y1 & 7u) << 4) + (uint32_t) il.ld_x8;
+    v1 = gload < u32x4 > (job.ref[r] + o1);
   }
   __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr[j]) = v[j];       // unused slots land in a spare chunk
+  *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr) = v0;
+  if constexpr (PC == 2)
+    *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr + il.rd_row1) = v1;
   __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier ();
   const int off = il.rd_base + (int) (own_phase >> 4);          // + (x of the first sample & 15)
@@ -608,10 +610,10 @@ fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, const HotBlk * s_
 }
 
 // one pass of one class: CLS 0 both references, 1 / 2 one reference, 3 DC
-template < int PC, int CLS >
+template < int PC, int CLS, bool EXACT >
 __device__ __forceinline__ void
 item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
-    const uint32_t * s_w4, int nseg, int *acc, int i0, int hi, bool exact)
+    const uint32_t * s_w4, int nseg, int *acc, int i0, int hi)
 {
   constexpr int kStep = PC == 0 ? 1 : 2;
   const int it = i0 + il.slot;
@@ -632,17 +634,9 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
         fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
             job.ref_stride[1], hb.wpk[1], v1);
     } else {
-      // load role: the two (item, row, chunk) slots of this lane, shared by both references
-      int ld_blk[2], ld_y[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int el = s_item[min (i0 + il.ld_item[j], hi - 1)];
-        ld_blk[j] = el & 0xff;
-        ld_y[j] = 2 * (el >> 8) + il.ld_row[j];
-      }
-      fetch4_tiled < PC > (job, r0, il, s_hot, ld_blk, ld_y, ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, hb.wpk[r0], v0);
+      fetch4_tiled < PC > (job, r0, il, hb.off[r0], ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, row, hb.wpk[r0], v0);
       if constexpr (CLS == 0)
-        fetch4_tiled < PC > (job, 1, il, s_hot, ld_blk, ld_y, ((uint32_t) hb.rows >> 24) & 0xffu, hb.wpk[1], v1);
+        fetch4_tiled < PC > (job, 1, il, hb.off[1], ((uint32_t) hb.rows >> 24) & 0xffu, row, hb.wpk[1], v1);
     }
     if constexpr (CLS != 0) {
 #pragma unroll
@@ -659,7 +653,7 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
     for (int k = 0; k < 4; k++) {
       const int pred = CLS == 0 ? (v0[k] + v1[k] + 1) >> 1 : v0[k];
       const int v = __mul24 (pred, (int) ((w4 >> (8 * k)) & 0xff));
-      if (exact)                // some sum of this tile may wrap: no plain adds (see the kernel)
+      if constexpr (EXACT)      // some sum of this tile may wrap: no plain adds (see the kernel)
         acc_add_wrap (ap + k, hs, v);
       else
         atomicAdd (ap + k, v << hs);
@@ -672,8 +666,13 @@ __device__ __forceinline__ void
 item_class (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, const HotBlk * s_hot,
     const uint32_t * s_w4, int nseg, int *acc, int first, int hi, int stride, bool exact)
 {
-  for (int i0 = first; i0 < hi; i0 += stride)
-    item_pass < PC, CLS > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi, exact);
+  if (exact) {                  // rare (see the kernel): keep it out of the hot loop
+    for (int i0 = first; i0 < hi; i0 += stride)
+      item_pass < PC, CLS, true > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi);
+  } else {
+    for (int i0 = first; i0 < hi; i0 += stride)
+      item_pass < PC, CLS, false > (job, il, s_item, s_hot, s_w4, nseg, acc, i0, hi);
+  }
 }
 
 template < int PC >
@@ -721,32 +720,27 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   constexpr int kStep = PC == 0 ? 1 : 2;        // samples per pixel step
   const int nseg = (xblen + 3) >> 2;
   const int chunk_cap = min (kItemBlkCap, fdiv (kItemCap, min (yblen, kFTH)));
-  // half-pel references: 16-byte chunks per sample row of an item, rows per item, load
-  // slots per item; a pass is as many items as 128 load slots and 64 compute lanes allow
-  const int nch = ((nseg + 1) >> 1) + 1, nrow = PC == 2 ? 2 : 1, slots = nch * nrow;
-  const int item_bytes = slots * 16 + 16;       // + 16: items start on different LDS banks
-  const int IPW = PC == 0 ? fdiv (64, nseg)     // items per wave pass
-      : min (min (fdiv (64, nseg), fdiv (128, slots)), fdiv (kItemStage - 16, item_bytes));
+  // half-pel references: 16-byte chunks per sample row of an item.  The lanes of an item
+  // are its load role too (lane k: chunk k of both sample rows), so an item takes
+  // max (segments, chunks) lanes
+  const int nch = ((nseg + 1) >> 1) + 1, nrow = PC == 2 ? 2 : 1;
+  const int lpi = PC == 0 ? nseg : max (nseg, nch);      // lanes per item
+  const int item_bytes = nrow * nch * 16 + 16;  // + 16: items start on different LDS banks
+  const int IPW = PC == 0 ? fdiv (64, lpi)      // items per wave pass
+      : min (fdiv (64, lpi), fdiv (kItemStage - 32 - 16 * nch, item_bytes));
   ItemLane il;
-  il.slot = fdiv (lane, nseg);
-  il.seg = lane - il.slot * nseg;
+  il.slot = fdiv (lane, lpi);
+  const int sub = lane - il.slot * lpi;
+  il.seg = min (sub, nseg - 1);
   il.seg_bytes = il.seg * (4 * kStep);
   il.tw3 = x_hi - x_lo + 3;
   il.ipw = IPW;
-  il.active = il.slot < IPW;
+  il.active = il.slot < IPW && sub < nseg;
   il.stage = s_stage[PC == 0 ? 0 : wave];
   il.rd_base = il.slot * item_bytes + 8 * il.seg;
   il.rd_row1 = 16 * nch;
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int sl = lane + 64 * j;
-    const int li = fdiv (sl, slots), rem = sl - li * slots;
-    const int h = fdiv (rem, nch), ch = rem - h * nch;
-    il.ld_item[j] = min (li, IPW - 1);
-    il.ld_row[j] = h;
-    il.ld_x8[j] = 128 * ch;
-    il.ld_wr[j] = li < IPW ? li * item_bytes + h * (16 * nch) + 16 * ch : kItemStage - 16;
-  }
+  il.ld_x8 = 128 * min (sub, nch - 1);
+  il.ld_wr = il.slot < IPW && sub < nch ? il.slot * item_bytes + 16 * sub : kItemStage - 16 - il.rd_row1;
   TileCtx tc;
   tc.x_lo = x_lo;
   tc.x_hi = x_hi;
