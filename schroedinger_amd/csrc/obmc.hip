@@ -560,25 +560,33 @@ struct ItemLane {
 // item they belong to -- then each lane reads its own 8 (+ 8) bytes back at the window's
 // byte phase.  16-byte chunk = one row of a 16x8 tile: the chunks of one item's two rows
 // mostly share a cache line, and so do those of the rows above and below.
+// load role: the 16-byte chunk (ld_x8 / 128) of sample rows 2 row (+ 1) of the block's window.
+// off_r is the offset of the window's first chunk in the tile row of its first sample row,
+// the phase (y & 7) of that row comes with it.
 template < int PC >
 __device__ __forceinline__ void
-fetch4_tiled (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t own_phase, int row,
-    uint32_t wpk, int *val)
+tiled_load (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t own_phase, int row,
+    u32x4 * v)
 {
   static_assert (PC >= 1, "plain references are linear");
   const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
-  // hp_offset of chunk (ld_x8 / 128) of sample rows 2 row (+ 1) of the block's window: off_r is
-  // the offset of the window's first chunk in the tile row of its first sample row, the
-  // phase (y & 7) of that row comes with it
   const uint32_t y0 = (own_phase & 7u) + 2u * (uint32_t) row;
   const uint32_t o0 = (uint32_t) off_r + __umul24 (y0 >> 3, tile_row_bytes) + ((y0 & 7u) << 4) + (uint32_t) il.ld_x8;
-  const u32x4 v0 = gload < u32x4 > (job.ref[r] + o0);
-  u32x4 v1 = v0;
+  v[0] = gload < u32x4 > (job.ref[r] + o0);
   if constexpr (PC == 2) {
     const uint32_t y1 = y0 + 1u;
     const uint32_t o1 = (uint32_t) off_r + __umul24 (y1 >> 3, tile_row_bytes) + ((y1 & 7u) << 4) + (uint32_t) il.ld_x8;
-    v1 = gload < u32x4 > (job.ref[r] + o1);
+    v[1] = gload < u32x4 > (job.ref[r] + o1);
   }
+}
+
+// compute role: stage the wave's chunks, read this lane's 8 (+ 8) bytes back at the window's
+// byte phase, four predicted pixels
+template < int PC >
+__device__ __forceinline__ void
+tiled_predict (const ItemLane & il, const u32x4 * v, uint32_t own_phase, uint32_t wpk, int *val)
+{
+  const u32x4 v0 = v[0], v1 = v[PC == 2 ? 1 : 0];
   __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
   *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr) = v0;
   if constexpr (PC == 2)
@@ -634,9 +642,16 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
         fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
             job.ref_stride[1], hb.wpk[1], v1);
     } else {
-      fetch4_tiled < PC > (job, r0, il, hb.off[r0], ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, row, hb.wpk[r0], v0);
+      // all loads of the pass go out before the first is waited for (a two-deep pipeline
+      // across passes was measured too: no gain, and it spills at 5 waves per SIMD)
+      const uint32_t ph0 = ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
+      u32x4 c0[2], c1[2];
+      tiled_load < PC > (job, r0, il, hb.off[r0], ph0, row, c0);
       if constexpr (CLS == 0)
-        fetch4_tiled < PC > (job, 1, il, hb.off[1], ((uint32_t) hb.rows >> 24) & 0xffu, row, hb.wpk[1], v1);
+        tiled_load < PC > (job, 1, il, hb.off[1], ph1, row, c1);
+      tiled_predict < PC > (il, c0, ph0, hb.wpk[r0], v0);
+      if constexpr (CLS == 0)
+        tiled_predict < PC > (il, c1, ph1, hb.wpk[1], v1);
     }
     if constexpr (CLS != 0) {
 #pragma unroll
