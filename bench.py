@@ -211,7 +211,11 @@ def main():
         kernels["iiwt_3_levels"] = {"avg_ms": round(iiwt_ms, 4), "launches": profiled_steps,
                                     "alg_GBs": round(4 * samples / (iiwt_ms * 1e-3) / 1e9, 1),
                                     "frac_of_8TBs": round(4 * samples / (iiwt_ms * 1e-3) / 1e9
-                                                          / HBM_PEAK_GBS, 4)}
+                                                          / HBM_PEAK_GBS, 4),
+                                    # the read side alone (2 B per sample), the
+                                    # quantity rocprof's FETCH_SIZE bounds
+                                    "read_frac_of_8TBs": round(2 * samples / (iiwt_ms * 1e-3) / 1e9
+                                                               / HBM_PEAK_GBS, 4)}
         # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/, collected offline)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -146,6 +146,8 @@ static __device__ __constant__ DivMagic kDivMagic = make_div_magic ();
 __device__ __forceinline__ int
 fdiv (int n, int d)
 {
+  if (d > 1024)                 // outside the table (no geometry of this path gets here)
+    return n / d;
   return d == 1 ? n : (int) __umulhi ((uint32_t) n, kDivMagic.m[d]);
 }
 
