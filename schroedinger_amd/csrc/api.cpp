@@ -827,6 +827,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       obmc_tiles (variant, pl.width, pl.height, j.xoff, &j.tiles_x, &tiles_y);
       j.tile_base = tile_base;
       tile_base += j.tiles_x * tiles_y;
+      obmc_item_geometry (&j);
       jobs.push_back (j);
     }
     void *d_jobs;

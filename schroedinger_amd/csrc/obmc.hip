@@ -30,6 +30,7 @@
 // + output 1 B + 1 B per reference used.
 
 #include "schro_hip_internal.h"
+#include <algorithm>
 
 namespace schro {
 namespace {
@@ -50,7 +51,7 @@ get_ramp (int x, int offset)
 {
   if (offset == 1)
     return x == 0 ? 3 : 5;
-  return 1 + fdiv (6 * x + offset - 1, 2 * offset - 1);
+  return 1 + (6 * x + offset - 1) / (2 * offset - 1);   // once per thread; no table round trip
 }
 
 // schromotion.c:57-69
@@ -707,7 +708,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
-  const int ty = fdiv (t, job.tiles_x), tx = t - ty * job.tiles_x;
+  const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x_lo = tx * kFTW, y_lo = ty * kFTH;
   const int x_hi = min (x_lo + kFTW, job.w), y_hi = min (y_lo + kFTH, job.h);
@@ -723,28 +724,23 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   const int xblen = job.xblen, yblen = job.yblen, xbsep = job.xbsep, ybsep = job.ybsep;
   const int xoff = job.xoff, yoff = job.yoff, prec = job.prec;
   // first / last block whose footprint meets the tile (numerators kept non-negative)
-  const int i_lo = max (0, fdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep) - 1);
-  const int i_hi = min (job.nbx - 1, fdiv (x_hi - 1 + xoff, xbsep));
-  const int j_lo = max (0, fdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep) - 1);
-  const int j_hi = min (job.nby - 1, fdiv (y_hi - 1 + yoff, ybsep));
+  const int i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
+  const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
+  const int j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
+  const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
   const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
   const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
+  // blk / nbi for blk < 2^10: one scalar division per workgroup instead of one per thread
+  const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
   const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
   const int gw = PC == 0 ? job.w - 1 : 2 * job.w - 2;   // last valid sample column
   const int gh = PC == 0 ? job.h - 1 : 2 * job.h - 2;
   constexpr int kStep = PC == 0 ? 1 : 2;        // samples per pixel step
-  const int nseg = (xblen + 3) >> 2;
-  const int chunk_cap = min (kItemBlkCap, fdiv (kItemCap, min (yblen, kFTH)));
-  // half-pel references: 16-byte chunks per sample row of an item.  The lanes of an item
-  // are its load role too (lane k: chunk k of both sample rows), so an item takes
-  // max (segments, chunks) lanes
-  const int nch = ((nseg + 1) >> 1) + 1, nrow = PC == 2 ? 2 : 1;
-  const int lpi = PC == 0 ? nseg : max (nseg, nch);      // lanes per item
-  const int item_bytes = nrow * nch * 16 + 16;  // + 16: items start on different LDS banks
-  const int IPW = PC == 0 ? fdiv (64, lpi)      // items per wave pass
-      : min (fdiv (64, lpi), fdiv (kItemStage - 32 - 16 * nch, item_bytes));
+  // block geometry of the plane: from the host (obmc_item_geometry)
+  const int nseg = job.nseg, nch = job.nch, lpi = job.lpi, item_bytes = job.item_bytes;
+  const int IPW = job.ipw, chunk_cap = job.chunk_cap;
   ItemLane il;
-  il.slot = fdiv (lane, lpi);
+  il.slot = mdiv (lane, lpi, job.m_lpi);
   const int sub = lane - il.slot * lpi;
   il.seg = min (sub, nseg - 1);
   il.seg_bytes = il.seg * (4 * kStep);
@@ -766,7 +762,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   __syncthreads ();             // weights visible
   // the 4 weights wx * wy of every (block row, segment), one byte each (<= 64)
   for (int i = tid; i < yblen * nseg && i < kItemWCap; i += kThreads) {
-    const int r = fdiv (i, nseg), sg = i - r * nseg;
+    const int r = mdiv (i, nseg, job.m_nseg), sg = i - r * nseg;
     uint32_t w = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -794,7 +790,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
     const bool have = tid < nb;
     if (have) {
       const int blk = chunk0 + tid;
-      const int bj = fdiv (blk, nbi);
+      const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
       const uint32_t flags = gload < uint32_t > (mvp);
@@ -969,6 +965,30 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 }
 
 }                               // namespace
+
+// geometry of the item kernel for one plane (the kernel reads it from the job)
+void
+obmc_item_geometry (ObmcJob * j)
+{
+  const int nseg = (j->xblen + 3) >> 2;
+  // half-pel references: 16-byte chunks per sample row of an item.  The lanes of an item are
+  // its load role too (lane k: chunk k of both sample rows), so an item takes
+  // max (segments, chunks) lanes
+  const int nch = ((nseg + 1) >> 1) + 1, nrow = j->prec >= 2 ? 2 : 1;
+  const int lpi = j->prec == 0 ? nseg : std::max (nseg, nch);
+  j->nseg = nseg;
+  j->nch = nch;
+  j->lpi = lpi;
+  j->item_bytes = nrow * nch * 16 + 16;         // + 16: items start on different LDS banks
+  j->ipw = j->prec == 0 ? 64 / lpi              // items per wave pass
+      : std::min (64 / lpi, (kItemStage - 32 - 16 * nch) / j->item_bytes);
+  j->chunk_cap = std::min (kItemBlkCap, kItemCap / std::min (j->yblen, kFTH));
+  j->m_tiles_x = div_magic (j->tiles_x);
+  j->m_xbsep = div_magic (j->xbsep);
+  j->m_ybsep = div_magic (j->ybsep);
+  j->m_nseg = div_magic (nseg);
+  j->m_lpi = div_magic (lpi);
+}
 
 // variant 0: per-pixel kernel (any weights), 64x4 tiles
 // variant 1: LDS-accumulate item kernel (default weights), 128x32 tiles

@@ -90,6 +90,11 @@ struct ObmcJob {
   int res_bpp;
   int tiles_x;
   int tile_base;
+  // item kernel: everything that depends only on the plane's block geometry, worked out
+  // on the host (obmc_item_geometry) instead of in every workgroup's prologue; m_* are
+  // ceil (2^32 / d) for mdiv ()
+  int nseg, nch, lpi, item_bytes, ipw, chunk_cap;
+  uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
 };
 
 constexpr int kMaxJobs = 256;
@@ -144,11 +149,24 @@ make_div_magic ()
 static __device__ __constant__ DivMagic kDivMagic = make_div_magic ();
 
 __device__ __forceinline__ int
+mdiv (int n, int d, uint32_t m)
+{
+  return d == 1 ? n : (int) __umulhi ((uint32_t) n, m);
+}
+
+__device__ __forceinline__ int
 fdiv (int n, int d)
 {
   if (d > 1024)                 // outside the table (no geometry of this path gets here)
     return n / d;
   return d == 1 ? n : (int) __umulhi ((uint32_t) n, kDivMagic.m[d]);
+}
+
+// n / d with the host-side magic m = div_magic (d): no table load in the kernel
+__host__ __device__ inline uint32_t
+div_magic (int d)
+{
+  return d <= 1 ? 0u : (uint32_t) ((0x100000000ull + (uint32_t) d - 1) / (uint32_t) d);
 }
 
 // byte offset of half-pel sample (x, y) in the tiled 16x8 layout (include/schro_hip.h)
@@ -216,6 +234,8 @@ int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
 void upsample_tile_geometry (int *tw, int *th);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant);
+// fills the item-kernel geometry fields of a job (obmc.hip)
+void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
 
 }                               // namespace schro
