@@ -26,7 +26,7 @@
 #include <stddef.h>
 #include <string.h>
 
-#define MAX_BLK 32              /* reads stay inside the 32-pixel apron */
+#define MAX_BLK 64              /* SCHRO_LIMIT_BLOCK_SIZE, schrolimits.h:67; get_block clamps the block origin so every read stays inside the 32-pixel apron */
 
 static inline int
 clampi (int x, int lo, int hi)

@@ -790,6 +790,9 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       j.ybsep = pl.ybsep_luma >> vs;
       j.xblen = pl.xblen_luma >> hs;
       j.yblen = pl.yblen_luma >> vs;
+      // schro_params_verify_block_params, schroparams.c:241-272
+      SCHRO_HIP_REQUIRE (((pl.xblen_luma | pl.yblen_luma | pl.xbsep_luma | pl.ybsep_luma) & 3) == 0,
+          "obmc_batch: plane %d: luma block sizes and separations must be multiples of 4", p);
       SCHRO_HIP_REQUIRE (j.xbsep > 0 && j.ybsep > 0 && j.xblen >= j.xbsep && j.yblen >= j.ybsep
           && j.xblen <= 2 * j.xbsep && j.yblen <= 2 * j.ybsep && j.xblen <= 64 && j.yblen <= 64,
           "obmc_batch: plane %d block geometry %dx%d sep %dx%d unsupported", p, j.xblen, j.yblen,

@@ -108,6 +108,16 @@ def test_ragged_sizes(ctx):
             run_case(ctx, w, h, 12, 8, prec, (1, 1, 1), (1, 1), 40, 7)
 
 
+def test_large_and_odd_block_geometries(ctx):
+    # legal block sizes (schro_params_verify_block_params: multiples of 4, sep <= len <=
+    # 2 sep) outside the four standard sets: up to SCHRO_LIMIT_BLOCK_SIZE (64), blocks whose
+    # (rows x segments) exceed the item kernel's weight table (exact rim path for all of
+    # them), chroma widths that are not a multiple of 4, len == sep (no overlap), len == 2 sep
+    for (blen, bsep) in [(32, 24), (48, 32), (64, 32), (20, 12), (8, 8), (16, 8), (24, 12), (4, 4)]:
+        for prec in (0, 1, 2):
+            run_case(ctx, 192, 128, blen, bsep, prec, (1, 1, 1), (1, 1), 20 << prec, 13)
+
+
 def test_all_modes_and_s32_residual(ctx):
     for modes in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)):
         run_case(ctx, 96, 64, 12, 8, 2, (1, 1, 1), (1, 1), 64, 11, modes=modes)
@@ -122,3 +132,11 @@ def test_test_stream_geometry(ctx):
 def test_2160p_config(ctx):
     # BASELINE config 3: 3840x2160 4:2:0, 12x12/8x8, quarter-pel, MVs +-64 quarter-pels
     run_case(ctx, 3840, 2160, 12, 8, 2, (1, 1, 1), (1, 1), 64, 2)
+
+
+def test_illegal_block_parameters_are_refused(ctx):
+    # schro_params_verify_block_params (schroparams.c:241-272): the reference never renders
+    # these; neither does the library (an error, not a silently different picture)
+    for (blen, bsep) in [(10, 8), (12, 6), (8, 12), (40, 16)]:
+        with pytest.raises(sa.SchroHipError):
+            run_case(ctx, 96, 64, blen, bsep, 0, (1, 1, 1), (1, 1), 4, 3)
