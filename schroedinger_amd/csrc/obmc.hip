@@ -270,13 +270,6 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 constexpr int kFTW = 128, kFTH = 32;
 
 
-__device__ __forceinline__ int
-floor_div (int a, int b)
-{
-  int q = a / b;
-  return (a % b != 0 && a < 0) ? q - 1 : q;
-}
-
 constexpr int kAccStride = 136; // 4 + 128 + 4; 8 mod 64: block rows spread over the LDS banks, rows 16-byte aligned
 
 // One decoded block.  Everything that is uniform over the block's pixels is
@@ -319,18 +312,6 @@ fetch4_inside (const uint8_t * __restrict__ p, int stride, uint32_t wpk, int *va
     val[2] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x05040100u), wpk, 8u, false) >> 4);
     val[3] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x07060302u), wpk, 8u, false) >> 4);
   }
-}
-
-// border blocks: per-sample coordinate clamp (kept out of line: rare)
-template < int PC >
-__device__ __noinline__ uint32_t
-fetch4_clamped (const uint8_t * __restrict__ ref, int stride, int w, int h, int sx, int sy,
-    int prec)
-{
-  uint32_t pk = 0;              // four u8 samples, returned in a register
-  for (int e = 0; e < 4; e++)
-    pk |= (uint32_t) fetch_ref < PC > (ref, stride, w, h, sx + e * (1 << prec), sy, prec) << (8 * e);
-  return pk;
 }
 
 constexpr int kAccMargin = 4;   // a 4-pixel segment may stick out of the tile by 3 pixels; 4 keeps rows aligned
@@ -546,7 +527,6 @@ struct ItemLane {
   int seg_bytes;                // byte offset of the segment inside the sample window
   int tw3;                      // tile width + 3 (range test of a segment)
   bool active;                  // lanes beyond the last whole item of a pass idle
-  int ipw;                      // items per wave pass
   // half-pel references (tiled 16x8): the load role of this lane -- one 16-byte chunk of
   // each sample row of its OWN item
   uint8_t *stage;               // this wave's staging buffer
@@ -745,7 +725,6 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   il.seg = min (sub, nseg - 1);
   il.seg_bytes = il.seg * (4 * kStep);
   il.tw3 = x_hi - x_lo + 3;
-  il.ipw = IPW;
   il.active = il.slot < IPW && sub < nseg;
   il.stage = s_stage[PC == 0 ? 0 : wave];
   il.rd_base = il.slot * item_bytes + 8 * il.seg;
