@@ -166,6 +166,7 @@ int schro_hip_convert_u8_batch (SchroHipContext * ctx,
 #define SCHRO_HIP_FORMAT_YUYV 0x100     /* SCHRO_FRAME_FORMAT_YUYV, schroframe.h:36-38 */
 #define SCHRO_HIP_FORMAT_UYVY 0x101
 #define SCHRO_HIP_FORMAT_AYUV 0x102
+#define SCHRO_HIP_FORMAT_v210 0x106     /* 10 bit 4:2:2, six pixels in four words */
 
 typedef struct {
   const uint8_t *src[3];        /* Y, U, V planes (device) */
@@ -182,6 +183,19 @@ typedef struct {
 
 int schro_hip_pack_u8_batch (SchroHipContext * ctx,
     const SchroHipPackPlane * planes, int nplanes);
+
+/* The same copy-out into v210 (schroframe.c:889-891, 960-962): rows of
+ * ceil (width / 6) 16-byte groups, samples beyond `width` in the last group 0.
+ * src_bpp 1: u8 planes of any chroma format, 10-bit value (x << 2) | (x >> 6)
+ * (pack_v210, schrovirtframe.c:1129-1210).  src_bpp 2 / 4: s16 / s32 planes --
+ * the frame of a > 8-bit stream (schrodecoder.c:350-352), e.g. the 10-bit 4:2:2
+ * 8K configuration -- which must be 4:2:2 as in the reference (its chroma
+ * resampler only knows u8, schrovirtframe.c:1545-1575); s32 is truncated to
+ * 16 bits (orc_convert_s16_s32), value clamp (x + 512, 0, 1023) (pack_v210_s16,
+ * :1044-1127).  `format` of the planes is ignored; `src` / `src_stride` are in
+ * bytes of the sample type. */
+int schro_hip_pack_v210_batch (SchroHipContext * ctx,
+    const SchroHipPackPlane * planes, int nplanes, int src_bpp);
 
 /* Half-pel upsampling of one u8 component; replaces
  * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /

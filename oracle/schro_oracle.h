@@ -162,6 +162,12 @@ typedef struct {
 int oracle_pack_u8 (uint8_t * dst, int dst_stride, int format, int width, int height,
     const OraclePackSrc * src);
 
+/* v210 destination (SCHRO_FRAME_FORMAT_v210 = 0x106): src_bpp 1 (u8, any chroma), 2 or 4
+ * (s16 / s32, 4:2:2 only, as the reference); data[] / stride[] of `src` are then in bytes
+ * of that sample type.  Rows of ceil (width / 6) 16-byte groups. */
+int oracle_pack_v210 (uint8_t * dst, int dst_stride, int width, int height,
+    const OraclePackSrc * src, int src_bpp);
+
 #ifdef __cplusplus
 }
 #endif

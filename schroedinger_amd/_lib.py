@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
+    "schro_hip_pack_v210_batch",
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
@@ -157,6 +158,8 @@ def load():
     L.schro_hip_upsample_batch.restype = i
     L.schro_hip_pack_u8_batch.argtypes = [vp, C.POINTER(PackPlane), i]
     L.schro_hip_pack_u8_batch.restype = i
+    L.schro_hip_pack_v210_batch.argtypes = [vp, C.POINTER(PackPlane), i, i]
+    L.schro_hip_pack_v210_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]
     L.schro_hip_upsampled_bytes.restype = C.c_size_t
     L.schro_hip_upsampled_download.argtypes = [vp, vp, i, vp, i, i, i]

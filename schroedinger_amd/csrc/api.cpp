@@ -631,8 +631,8 @@ schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * 
   return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
 }
 
-int
-schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes)
+static int
+pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes, int v210_bpp)
 {
   SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs, "pack_batch: bad arguments");
   (void) hipSetDevice (ctx->device);
@@ -644,9 +644,12 @@ schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes
     const SchroHipPackPlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.src[0] && pl.src[1] && pl.src[2] && pl.dst && pl.width > 0 && pl.height > 0
         && pl.src_width > 0 && pl.src_height > 0, "pack_batch: plane %d invalid", p);
-    SCHRO_HIP_REQUIRE (pl.format == SCHRO_HIP_FORMAT_YUYV || pl.format == SCHRO_HIP_FORMAT_UYVY
+    SCHRO_HIP_REQUIRE (v210_bpp || pl.format == SCHRO_HIP_FORMAT_YUYV || pl.format == SCHRO_HIP_FORMAT_UYVY
         || pl.format == SCHRO_HIP_FORMAT_AYUV, "pack_batch: plane %d: format 0x%x is not YUYV / UYVY / AYUV",
         p, pl.format);
+    // the reference resamples chroma of u8 frames only (schrovirtframe.c:1545-1575)
+    SCHRO_HIP_REQUIRE (v210_bpp <= 1 || (pl.src_h_shift == 1 && pl.src_v_shift == 0),
+        "pack_v210_batch: plane %d: s16 / s32 sources must be 4:2:2", p);
     SCHRO_HIP_REQUIRE ((pl.src_h_shift | pl.src_v_shift) >= 0 && pl.src_h_shift <= 1 && pl.src_v_shift <= 1
         && !(pl.src_v_shift && !pl.src_h_shift), "pack_batch: plane %d: chroma format not 4:4:4 / 4:2:2 / 4:2:0", p);
     // schroframe.c:931-941 crops both dimensions or extends both
@@ -654,7 +657,8 @@ schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes
             && (pl.width > pl.src_width || pl.height > pl.src_height)),
         "pack_batch: plane %d: %dx%d from %dx%d mixes crop and extension", p, pl.width, pl.height,
         pl.src_width, pl.src_height);
-    const int row_bytes = pl.format == SCHRO_HIP_FORMAT_AYUV ? 4 * pl.width : 4 * (pl.width / 2);
+    const int row_bytes = v210_bpp ? 16 * div_up (pl.width, 6)
+        : pl.format == SCHRO_HIP_FORMAT_AYUV ? 4 * pl.width : 4 * (pl.width / 2);
     SCHRO_HIP_REQUIRE (pl.dst_stride >= row_bytes, "pack_batch: plane %d stride too small", p);
     PackJob & j = jobs[p];
     for (int k = 0; k < 3; k++) {
@@ -669,7 +673,8 @@ schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes
     j.vs = pl.src_v_shift;
     j.w = pl.width;
     j.h = pl.height;
-    j.format = pl.format;
+    j.format = v210_bpp ? SCHRO_HIP_FORMAT_v210 : pl.format;
+    j.src_bpp = v210_bpp ? v210_bpp : 1;
     j.tiles_x = div_up (div_up (row_bytes, 16), gx);
     if (j.tiles_x == 0)
       j.tiles_x = 1;
@@ -682,6 +687,20 @@ schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes
     return r;
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
   return launch_pack (ctx->stream, (const PackJob *) d_jobs, nplanes, tile_base);
+}
+
+int
+schro_hip_pack_u8_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes)
+{
+  return pack_batch (ctx, planes, nplanes, 0);
+}
+
+int
+schro_hip_pack_v210_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes,
+    int src_bpp)
+{
+  SCHRO_HIP_REQUIRE (src_bpp == 1 || src_bpp == 2 || src_bpp == 4, "pack_v210_batch: src_bpp must be 1, 2 or 4");
+  return pack_batch (ctx, planes, nplanes, src_bpp);
 }
 
 size_t

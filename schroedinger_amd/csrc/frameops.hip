@@ -271,6 +271,23 @@ pack_sample (const PackJob & job, int comp, int t_hs, int X, int Y)
   return gload < uint8_t > (job.src[comp] + (size_t) y * job.src_stride[comp] + x);
 }
 
+// one 10-bit sample of the frame just before pack_v210 / pack_v210_s16
+__device__ __forceinline__ uint32_t
+v210_sample (const PackJob & job, int comp, int X, int Y)
+{
+  if (job.src_bpp == 1) {
+    const uint32_t v = pack_sample (job, comp, 1, X, Y);
+    return (v << 2) | (v >> 6);
+  }
+  const int cw = comp ? (job.sw + 1) >> 1 : job.sw;
+  const int x = min (X, cw - 1), y = min (Y, job.sh - 1);       // crop_s16 / edge_extend_s16
+  const uint8_t *row = job.src[comp] + (size_t) y * job.src_stride[comp];
+  // s32 frames are truncated to 16 bits first (convert_s16_s32: convlw)
+  const int v = job.src_bpp == 2 ? (int) gload < int16_t > ((const int16_t *) row + x)
+      : (int) (int16_t) gload < int32_t > ((const int32_t *) row + x);
+  return (uint32_t) clampi (v + 512, 0, 1023);
+}
+
 __global__ __launch_bounds__ (kThreads)
 void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
 {
@@ -285,6 +302,32 @@ void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
     return;
   uint8_t *d = job.dst + (size_t) y * job.dst_stride + 16 * (size_t) g;
   uint32_t o[4];
+  if (job.format == SCHRO_HIP_FORMAT_v210) {
+    const int x0 = 6 * g;       // six pixels, three chroma pairs
+    if (x0 >= job.w)
+      return;
+    uint32_t yv[6], cb[3], cr[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      yv[k] = x0 + k < job.w ? v210_sample (job, 0, x0 + k, y) : 0u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const bool in = x0 + 2 * k < job.w;
+      cb[k] = in ? v210_sample (job, 1, 3 * g + k, y) : 0u;
+      cr[k] = in ? v210_sample (job, 2, 3 * g + k, y) : 0u;
+    }
+    o[0] = (cr[0] << 20) | (yv[0] << 10) | cb[0];
+    o[1] = (yv[2] << 20) | (cb[1] << 10) | yv[1];
+    o[2] = (cb[2] << 20) | (yv[3] << 10) | cr[1];
+    o[3] = (yv[5] << 20) | (cr[2] << 10) | yv[4];
+    if ((((uintptr_t) d) & 15) == 0) {
+      gstore < u32x4 > (d, (u32x4) { o[0], o[1], o[2], o[3] });
+    } else {
+      for (int k = 0; k < 4; k++)
+        gstore < u32_u > (d + 4 * k, o[k]);
+    }
+    return;
+  }
   if (job.format == SCHRO_HIP_FORMAT_AYUV) {
     const int x0 = 4 * g;
     if (x0 >= job.w)

@@ -59,6 +59,7 @@ struct PackJob {
   int hs, vs;                   // source chroma shifts
   int w, h;                     // packed picture size
   int format;
+  int src_bpp;                  // v210 only: 1, 2 or 4
   int tiles_x;
   int tile_base;
 };

@@ -49,6 +49,8 @@ def lib():
         L.oracle_motion_render_u8.restype = i
         L.oracle_pack_u8.argtypes = [vp, i, i, i, i, vp]
         L.oracle_pack_u8.restype = i
+        L.oracle_pack_v210.argtypes = [vp, i, i, i, vp, i]
+        L.oracle_pack_v210.restype = i
         _LIB = L
     return _LIB
 
@@ -187,6 +189,25 @@ def pack_u8(planes, h_shift, v_shift, fmt, width, height):
     if groups:
         r = lib().oracle_pack_u8(_ptr(out), out.strides[0], fmt, width, height, C.byref(src))
         assert r == 0, "oracle_pack_u8 refused the arguments"
+    return out
+
+
+FORMAT_V210 = 0x106
+
+
+def pack_v210(planes, h_shift, v_shift, width, height):
+    """schro_frame_convert (v210 dest, planar u8 / s16 / s32 src): rows of 16-byte groups."""
+    dt = np.asarray(planes[0]).dtype
+    planes = [np.ascontiguousarray(p, dt) for p in planes]
+    src = PackSrc()
+    for k in range(3):
+        src.data[k] = planes[k].ctypes.data
+        src.stride[k] = planes[k].strides[0]
+    src.height, src.width = planes[0].shape
+    src.h_shift, src.v_shift = h_shift, v_shift
+    out = np.zeros((height, 16 * (-(-width // 6))), np.uint8)
+    r = lib().oracle_pack_v210(_ptr(out), out.strides[0], width, height, C.byref(src), dt.itemsize)
+    assert r == 0, "oracle_pack_v210 refused the arguments"
     return out
 
 

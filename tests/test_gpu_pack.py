@@ -77,3 +77,42 @@ def test_pack_argument_errors(ctx):
         ctx.pack_u8_batch([(dev, 1, 1, dst, 16, 8, 0x103)])              # not a format of this call
     with pytest.raises(sa.SchroHipError):
         ctx.pack_u8_batch([(dev, 0, 1, dst, 16, 8, sa.FORMAT_YUYV)])     # 4:4:0 does not exist
+
+
+def signed_planes(w, h, dtype, seed):
+    cw = -(-w // 2)
+    span = 1500 if dtype == np.int16 else 70000
+    mk = lambda hh, ww, sd: ((synth.lcg(hh * ww, sd).astype(np.int64) % (2 * span)) - span).reshape(hh, ww).astype(dtype)
+    return [mk(h, w, seed), mk(h, cw, seed + 1), mk(h, cw, seed + 2)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32])
+def test_pack_v210(ctx, dtype):
+    # the copy-out of > 8-bit streams (s16 / s32 4:2:2 frames, e.g. the 10-bit 8K 4:2:2
+    # configuration) and of 8-bit pictures into v210
+    cases = []
+    for (w, h) in [(12, 4), (13, 3), (6, 2), (1, 1), (50, 9), (96, 16), (1920, 8), (3842, 3)]:
+        for (hs, vs) in ([(0, 0), (1, 0), (1, 1)] if dtype == np.uint8 else [(1, 0)]):
+            pl = planes(w, h, hs, vs, seed=w + h) if dtype == np.uint8 else signed_planes(w, h, dtype, w + h)
+            for (W, H) in [(w, h), (w + 7, h + 2), (max(w - 5, 1), max(h - 1, 1))]:
+                cases.append((pl, hs, vs, W, H))
+    jobs, outs = [], []
+    for (pl, hs, vs, W, H) in cases:
+        dev = [ctx.upload(p) for p in pl]
+        dst = ctx.plane(H, 16 * (-(-W // 6)), np.uint8).fill(0x5a)
+        jobs.append((dev, hs, vs, dst, W, H))
+        outs.append((dst, dev))
+    ctx.pack_v210_batch(jobs)
+    for (pl, hs, vs, W, H), (dst, dev) in zip(cases, outs):
+        assert np.array_equal(dst.download(), O.pack_v210(pl, hs, vs, W, H)), (dtype, pl[0].shape, hs, vs, W, H)
+        dst.free()
+        for d in dev:
+            d.free()
+
+
+def test_pack_v210_refuses_non_422_signed_sources(ctx):
+    pl = signed_planes(16, 4, np.int16, 1)
+    dev = [ctx.upload(p) for p in pl]
+    dst = ctx.plane(4, 48, np.uint8)
+    with pytest.raises(sa.SchroHipError):
+        ctx.pack_v210_batch([(dev, 0, 0, dst, 16, 4)])

@@ -89,3 +89,57 @@ def test_pack_refuses_mixed_crop_and_extension():
     src.width, src.height, src.h_shift, src.v_shift = 16, 8, 1, 1
     out = np.zeros((16, 64), np.uint8)
     assert O.lib().oracle_pack_u8(out.ctypes.data, 64, O.FORMAT_YUYV, 20, 4, C.byref(src)) == -1
+
+
+def v210_numpy(pl, hs, vs, W, H):
+    """pack_v210 / pack_v210_s16 (schrovirtframe.c:1044-1210) on whole arrays."""
+    dt = pl[0].dtype
+    y, u, v = pl
+    h, w = y.shape
+    if dt == np.uint8:
+        rows = np.arange(h) >> 1 if vs else np.arange(h)
+        tw = -(-w // 2)
+        cols = np.arange(tw) if hs == 1 else 2 * np.arange(tw)
+        u, v = u[rows][:, cols], v[rows][:, cols]
+
+    def fit(c, cw, ch):
+        return c[np.minimum(np.arange(ch), c.shape[0] - 1)][:, np.minimum(np.arange(cw), c.shape[1] - 1)]
+
+    ng = -(-W // 6)
+    Y = fit(y, 6 * ng, H).astype(np.int64)
+    U, V = fit(u, 3 * ng, H).astype(np.int64), fit(v, 3 * ng, H).astype(np.int64)
+    if dt == np.uint8:
+        to10 = lambda a: (a << 2) | (a >> 6)
+    else:
+        to10 = lambda a: np.clip(a.astype(np.int16).astype(np.int64) + 512, 0, 1023)
+    Y, U, V = to10(Y), to10(U), to10(V)
+    Y[:, W:] = 0
+    cin = (2 * np.arange(3 * ng)) < W
+    U[:, ~cin] = 0
+    V[:, ~cin] = 0
+    Y, U, V = Y.reshape(H, ng, 6), U.reshape(H, ng, 3), V.reshape(H, ng, 3)
+    words = np.empty((H, ng, 4), np.uint32)
+    words[..., 0] = (V[..., 0] << 20) | (Y[..., 0] << 10) | U[..., 0]
+    words[..., 1] = (Y[..., 2] << 20) | (U[..., 1] << 10) | Y[..., 1]
+    words[..., 2] = (U[..., 2] << 20) | (Y[..., 3] << 10) | V[..., 1]
+    words[..., 3] = (Y[..., 5] << 20) | (V[..., 2] << 10) | Y[..., 4]
+    return words.astype("<u4").view(np.uint8).reshape(H, 16 * ng)
+
+
+def signed_planes(w, h, dtype, seed):
+    cw = -(-w // 2)
+    # mostly inside the 10-bit range, some samples beyond it (clamp) and, for s32, beyond 16
+    # bits (the truncation of convert_s16_s32)
+    span = 1500 if dtype == np.int16 else 70000
+    mk = lambda hh, ww, sd: ((synth.lcg(hh * ww, sd).astype(np.int64) % (2 * span)) - span).reshape(hh, ww).astype(dtype)
+    return [mk(h, w, seed), mk(h, cw, seed + 1), mk(h, cw, seed + 2)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32])
+def test_v210_matches_the_chain(dtype):
+    for (w, h) in [(12, 4), (13, 3), (6, 2), (1, 1), (50, 9), (96, 16)]:
+        for (hs, vs) in ([(0, 0), (1, 0), (1, 1)] if dtype == np.uint8 else [(1, 0)]):
+            pl = planes(w, h, hs, vs, seed=w + h) if dtype == np.uint8 else signed_planes(w, h, dtype, w + h)
+            for (W, H) in [(w, h), (w + 7, h + 2), (max(w - 5, 1), max(h - 1, 1))]:
+                got = O.pack_v210(pl, hs, vs, W, H)
+                assert np.array_equal(got, v210_numpy(pl, hs, vs, W, H)), (dtype, w, h, hs, vs, W, H)
