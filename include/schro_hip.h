@@ -107,7 +107,9 @@ float schro_hip_timer_end (SchroHipContext * ctx);
 #define SCHRO_HIP_KERNEL_UPSAMPLE 2
 #define SCHRO_HIP_KERNEL_OBMC 3
 #define SCHRO_HIP_KERNEL_CONVERT 4
-#define SCHRO_HIP_KERNEL_CLASSES 5
+#define SCHRO_HIP_KERNEL_SLICES 5
+#define SCHRO_HIP_KERNEL_DC_PREDICT 6
+#define SCHRO_HIP_KERNEL_CLASSES 7
 int schro_hip_profile_enable (SchroHipContext * ctx, int enable);
 int schro_hip_profile_reset (SchroHipContext * ctx);
 int schro_hip_profile_read (SchroHipContext * ctx, int kernel_class,
@@ -196,6 +198,65 @@ int schro_hip_pack_u8_batch (SchroHipContext * ctx,
  * bytes of the sample type. */
 int schro_hip_pack_v210_batch (SchroHipContext * ctx,
     const SchroHipPackPlane * planes, int nplanes, int src_bpp);
+
+/* ---- VC-2 low-delay transform data -----------------------------
+ * Replaces schro_decoder_decode_lowdelay_transform_data (schrolowdelay.c:746-762):
+ * the slices of a picture -- fixed-size and independent, offsets by the accumulator of
+ * :607-631 -- are unpacked (interleaved exp-Golomb, schrounpack.c:211-241) and
+ * dequantised (schro_dequantise, schroutils.c:180-189) one thread per slice straight
+ * into the interleaved coefficient frame (sub-bands by schro_subband_get_frame_data,
+ * schroparams.c:319-352; slice rectangles by schro_frame_data_get_codeblock,
+ * schroframe.c:1865-1884), then the three LL bands are DC-predicted
+ * (schro_decoder_subband_dc_predict (_s32), schrodecoder.c:3219-3277).  The host hands
+ * over the compressed slice bytes (picture->lowdelay_buffer) instead of 2 or 4 bytes
+ * per coefficient.
+ *
+ * Which arithmetic a picture gets follows the reference's own choice (:746-762):
+ * bytes_per_sample 4 -> the s32 decoder; 2 with the chroma LL band divisible by the
+ * slice counts -> the "fast" decoder, whose dequantisation is 16-bit throughout
+ * (orc_dequantise_var_s16_ip, factor and offset truncated to int16_t, :478-479) and
+ * whose slice_y_length field is sized from the short slice (:577); 2 otherwise -> the
+ * "slow" decoder (int arithmetic, field sized per slice).  Where the reference is
+ * undefined (a base index above 59 indexes past the fast decoder's tables; a corrupt
+ * slice_y_length at the end of the buffer reads out of bounds) this library clamps the
+ * quantiser index as the slow decoder does and reads guard bits. */
+#define SCHRO_HIP_LIMIT_SUBBANDS 19     /* schrolimits.h */
+typedef struct {
+  int transform_depth;
+  int iwt_luma_width, iwt_luma_height;
+  int iwt_chroma_width, iwt_chroma_height;
+  int n_horiz_slices, n_vert_slices;
+  int slice_bytes_num, slice_bytes_denom;
+  int quant_matrix[SCHRO_HIP_LIMIT_SUBBANDS];
+} SchroHipLowDelayParams;
+
+typedef struct {
+  const uint8_t *slices;        /* device: the picture's slices back to back */
+  size_t slices_bytes;          /* < 2^28 */
+  void *comp[3];                /* device: Y, U, V coefficient planes (transform_frame) */
+  int stride[3];                /* bytes */
+} SchroHipLowDelayPicture;
+
+/* the reference decoder a picture takes, from params and sample size (schrolowdelay.c:746-762) */
+#define SCHRO_HIP_LOWDELAY_FAST16 0
+#define SCHRO_HIP_LOWDELAY_SLOW16 1
+#define SCHRO_HIP_LOWDELAY_S32 2
+int schro_hip_lowdelay_arith (const SchroHipLowDelayParams * params, int bytes_per_sample);
+
+/* all pictures share `params`; bytes_per_sample 2 (s16) or 4 (s32) */
+int schro_hip_lowdelay_batch (SchroHipContext * ctx,
+    const SchroHipLowDelayPicture * pictures, int npictures,
+    const SchroHipLowDelayParams * params, int bytes_per_sample);
+
+/* the DC prediction alone, in place on an LL band (also the intra DC prediction of the
+ * core syntax, schrodecoder.c:3630-3636) */
+typedef struct {
+  void *data;
+  int stride;
+  int width, height;
+} SchroHipDcPlane;
+int schro_hip_dc_predict_batch (SchroHipContext * ctx,
+    const SchroHipDcPlane * planes, int nplanes, int bytes_per_sample);
 
 /* Half-pel upsampling of one u8 component; replaces
  * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /

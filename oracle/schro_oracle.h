@@ -168,6 +168,41 @@ int oracle_pack_u8 (uint8_t * dst, int dst_stride, int format, int width, int he
 int oracle_pack_v210 (uint8_t * dst, int dst_stride, int width, int height,
     const OraclePackSrc * src, int src_bpp);
 
+/* ---- VC-2 low-delay transform data (oracle_lowdelay.c) ------------------- */
+
+/* the SchroParams members the slice decode reads (schrolowdelay.c:559-762) */
+typedef struct {
+  int transform_depth;
+  int iwt_luma_width, iwt_luma_height, iwt_chroma_width, iwt_chroma_height;
+  int n_horiz_slices, n_vert_slices;
+  int slice_bytes_num, slice_bytes_denom;
+  int quant_matrix[19];         /* SCHRO_LIMIT_SUBBANDS */
+} OracleLowDelayParams;
+
+/* which of the reference's three slice decoders a picture takes (schrolowdelay.c:746-762) */
+enum { ORACLE_LOWDELAY_FAST16 = 0, ORACLE_LOWDELAY_SLOW16 = 1, ORACLE_LOWDELAY_S32 = 2 };
+int oracle_lowdelay_arith (const OracleLowDelayParams * p, int bpp);
+
+/* schro_decoder_decode_lowdelay_transform_data: all slices of one picture from `data`
+ * into the three coefficient planes (bpp 2: s16, 4: s32), then DC prediction of the three
+ * LL bands.  Returns 0, -1 on bad arguments, -2 if the slices do not fit n_data_bytes. */
+int oracle_lowdelay_decode (const uint8_t * data, int64_t n_data_bytes, void *const comp[3],
+    const int stride[3], const OracleLowDelayParams * p, int bpp);
+
+/* Test-vector generator (not a restatement): writes the slice syntax the decoder reads,
+ * from QUANTISED values held in the coefficient frame layout; base_index[] per slice. */
+int oracle_lowdelay_write (uint8_t * data, int64_t n_data_bytes, void *const comp[3], const int stride[3],
+    const OracleLowDelayParams * p, int bpp, const uint8_t * base_index, int pad_bit, int y_length_bias);
+
+/* schro_decoder_subband_dc_predict (_s32), schrodecoder.c:3219-3277, in place */
+void oracle_dc_predict (void *data, int stride, int width, int height, int bpp);
+
+/* schro_table_quant[q], schro_table_offset_1_2[q], 0 <= q <= 60 (schrotables.c) */
+uint32_t oracle_quant_factor (int q);
+uint32_t oracle_quant_offset_1_2 (int q);
+/* one element of orc_dequantise_var_s16_ip as the fast slice decoder calls it */
+int16_t oracle_dequantise_var_s16 (int16_t q, int quant_factor, int quant_offset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,7 +133,7 @@ class Context:
             raise SchroHipError(self.lib.schro_hip_last_error().decode())
         return ms
 
-    KERNEL_CLASSES = ("iiwt_finest", "iiwt_coarse", "upsample", "obmc", "convert")
+    KERNEL_CLASSES = ("iiwt_finest", "iiwt_coarse", "upsample", "obmc", "convert", "slices", "dc_predict")
 
     def profile_enable(self, on=True):
         check(self.lib.schro_hip_profile_enable(self.h, 1 if on else 0))
@@ -209,6 +209,45 @@ class Context:
             a.dst, a.dst_stride = dst.ptr, dst.stride
             a.width, a.height, a.format = w, h, FORMAT_V210
         check(self.lib.schro_hip_pack_v210_batch(self.h, arr, n, bpp))
+
+    @staticmethod
+    def lowdelay_params(P):
+        """dict with the SchroParams members of the slice decode -> the ABI struct."""
+        lp = _lib.LowDelayParams()
+        for name in ("transform_depth", "iwt_luma_width", "iwt_luma_height", "iwt_chroma_width",
+                     "iwt_chroma_height", "n_horiz_slices", "n_vert_slices", "slice_bytes_num",
+                     "slice_bytes_denom"):
+            setattr(lp, name, int(P[name]))
+        for k, q in enumerate(P["quant_matrix"]):
+            lp.quant_matrix[k] = int(q)
+        return lp
+
+    def lowdelay_arith(self, P, bpp):
+        r = self.lib.schro_hip_lowdelay_arith(C.byref(self.lowdelay_params(P)), bpp)
+        check(min(r, 0))
+        return r
+
+    def lowdelay_batch(self, pictures, P):
+        """pictures: (slice bytes on the device (upload_bytes), [Y, U, V] coefficient
+        DevicePlanes) per picture; P: the parameter dict.  Mirrors
+        schro_decoder_decode_lowdelay_transform_data."""
+        n = len(pictures)
+        arr = (_lib.LowDelayPicture * n)()
+        bpp = pictures[0][1][0].dtype.itemsize
+        for a, (sl, planes) in zip(arr, pictures):
+            a.slices, a.slices_bytes = sl.ptr, sl.width
+            for k in range(3):
+                assert planes[k].dtype.itemsize == bpp
+                a.comp[k], a.stride[k] = planes[k].ptr, planes[k].stride
+        check(self.lib.schro_hip_lowdelay_batch(self.h, arr, n, C.byref(self.lowdelay_params(P)), bpp))
+
+    def dc_predict_batch(self, planes):
+        """In-place DC prediction of LL bands given as DevicePlanes (s16 / s32)."""
+        n = len(planes)
+        arr = (_lib.DcPlane * n)()
+        for a, p in zip(arr, planes):
+            a.data, a.stride, a.width, a.height = p.ptr, p.stride, p.width, p.height
+        check(self.lib.schro_hip_dc_predict_batch(self.h, arr, n, planes[0].dtype.itemsize))
 
     def convert_u8_batch(self, pairs):
         n = len(pairs)

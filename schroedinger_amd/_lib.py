@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
     "schro_hip_pack_v210_batch",
+    "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
@@ -47,6 +48,24 @@ class PackPlane(C.Structure):
                 ("src_h_shift", C.c_int), ("src_v_shift", C.c_int),
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
                 ("width", C.c_int), ("height", C.c_int), ("format", C.c_int)]
+
+
+class LowDelayParams(C.Structure):
+    _fields_ = [("transform_depth", C.c_int),
+                ("iwt_luma_width", C.c_int), ("iwt_luma_height", C.c_int),
+                ("iwt_chroma_width", C.c_int), ("iwt_chroma_height", C.c_int),
+                ("n_horiz_slices", C.c_int), ("n_vert_slices", C.c_int),
+                ("slice_bytes_num", C.c_int), ("slice_bytes_denom", C.c_int),
+                ("quant_matrix", C.c_int * 19)]
+
+
+class LowDelayPicture(C.Structure):
+    _fields_ = [("slices", C.c_void_p), ("slices_bytes", C.c_size_t),
+                ("comp", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class DcPlane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_int), ("width", C.c_int), ("height", C.c_int)]
 
 
 class UpsamplePlane(C.Structure):
@@ -160,6 +179,12 @@ def load():
     L.schro_hip_pack_u8_batch.restype = i
     L.schro_hip_pack_v210_batch.argtypes = [vp, C.POINTER(PackPlane), i, i]
     L.schro_hip_pack_v210_batch.restype = i
+    L.schro_hip_lowdelay_arith.argtypes = [C.POINTER(LowDelayParams), i]
+    L.schro_hip_lowdelay_arith.restype = i
+    L.schro_hip_lowdelay_batch.argtypes = [vp, C.POINTER(LowDelayPicture), i, C.POINTER(LowDelayParams), i]
+    L.schro_hip_lowdelay_batch.restype = i
+    L.schro_hip_dc_predict_batch.argtypes = [vp, C.POINTER(DcPlane), i, i]
+    L.schro_hip_dc_predict_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]
     L.schro_hip_upsampled_bytes.restype = C.c_size_t
     L.schro_hip_upsampled_download.argtypes = [vp, vp, i, vp, i, i, i]

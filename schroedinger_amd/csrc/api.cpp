@@ -735,6 +735,136 @@ schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride
   return 0;
 }
 
+// ---- VC-2 low-delay transform data (lowdelay.hip) ---------------------------------
+
+int
+schro_hip_lowdelay_arith (const SchroHipLowDelayParams * p, int bytes_per_sample)
+{
+  SCHRO_HIP_REQUIRE (p && (bytes_per_sample == 2 || bytes_per_sample == 4) && p->n_horiz_slices > 0
+      && p->n_vert_slices > 0 && p->transform_depth >= 0 && p->transform_depth <= 6, "lowdelay_arith: bad arguments");
+  if (bytes_per_sample == 4)
+    return SCHRO_HIP_LOWDELAY_S32;
+  // schrolowdelay.c:751-760
+  if ((p->iwt_chroma_width >> p->transform_depth) % p->n_horiz_slices == 0
+      && (p->iwt_chroma_height >> p->transform_depth) % p->n_vert_slices == 0)
+    return SCHRO_HIP_LOWDELAY_FAST16;
+  return SCHRO_HIP_LOWDELAY_SLOW16;
+}
+
+int
+schro_hip_dc_predict_batch (SchroHipContext * ctx, const SchroHipDcPlane * planes, int nplanes,
+    int bytes_per_sample)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= 3 * kMaxJobs, "dc_predict_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (bytes_per_sample == 2 || bytes_per_sample == 4, "dc_predict_batch: bytes_per_sample must be 2 or 4");
+  (void) hipSetDevice (ctx->device);
+  std::vector < DcJob > jobs (nplanes);
+  int max_rows = 1;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipDcPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.data && pl.width > 0 && pl.height > 0 && pl.stride >= pl.width * bytes_per_sample
+        && pl.stride % bytes_per_sample == 0 && (uintptr_t) pl.data % bytes_per_sample == 0,
+        "dc_predict_batch: plane %d invalid", p);
+    jobs[p].data = pl.data;
+    jobs[p].stride = pl.stride;
+    jobs[p].w = pl.width;
+    jobs[p].h = pl.height;
+    jobs[p].pad = 0;
+    max_rows = std::max (max_rows, pl.height);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (DcJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
+  return launch_dc_predict (ctx->stream, (const DcJob *) d_jobs, nplanes, max_rows, bytes_per_sample);
+}
+
+int
+schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture * pictures, int npictures,
+    const SchroHipLowDelayParams * params, int bytes_per_sample)
+{
+  SCHRO_HIP_REQUIRE (ctx && pictures && params && npictures > 0 && npictures <= kMaxJobs,
+      "lowdelay_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (bytes_per_sample == 2 || bytes_per_sample == 4, "lowdelay_batch: bytes_per_sample must be 2 or 4");
+  const SchroHipLowDelayParams & lp = *params;
+  const int depth = lp.transform_depth;
+  SCHRO_HIP_REQUIRE (depth >= 0 && depth <= 6, "lowdelay_batch: transform_depth %d", depth);
+  SCHRO_HIP_REQUIRE (lp.iwt_luma_width > 0 && lp.iwt_luma_height > 0 && lp.iwt_chroma_width > 0
+      && lp.iwt_chroma_height > 0 && ((lp.iwt_luma_width | lp.iwt_luma_height | lp.iwt_chroma_width
+              | lp.iwt_chroma_height) & ((1 << depth) - 1)) == 0,
+      "lowdelay_batch: iwt sizes must be positive multiples of 2^depth");
+  SCHRO_HIP_REQUIRE (lp.n_horiz_slices > 0 && lp.n_vert_slices > 0
+      && (int64_t) lp.n_horiz_slices * lp.n_vert_slices < (1 << 24), "lowdelay_batch: bad slice counts");
+  SCHRO_HIP_REQUIRE (lp.slice_bytes_denom > 0 && lp.slice_bytes_num >= lp.slice_bytes_denom,
+      "lowdelay_batch: slice_bytes %d / %d", lp.slice_bytes_num, lp.slice_bytes_denom);
+  const int arith = schro_hip_lowdelay_arith (params, bytes_per_sample);
+  if (arith < 0)
+    return arith;
+  // schrodecoder.c:2931-2932: the slices of a picture take num * slices / denom bytes
+  const int64_t nslices = (int64_t) lp.n_horiz_slices * lp.n_vert_slices;
+  const int64_t need = ((int64_t) lp.slice_bytes_num * nslices) / lp.slice_bytes_denom;
+  SCHRO_HIP_REQUIRE (need < ((int64_t) 1 << 28), "lowdelay_batch: %lld bytes of slices per picture", (long long) need);
+  (void) hipSetDevice (ctx->device);
+
+  SliceParams P;
+  memset (&P, 0, sizeof (P));
+  P.depth = depth;
+  P.iwt_lw = lp.iwt_luma_width;
+  P.iwt_lh = lp.iwt_luma_height;
+  P.iwt_cw = lp.iwt_chroma_width;
+  P.iwt_ch = lp.iwt_chroma_height;
+  P.nh = lp.n_horiz_slices;
+  P.nv = lp.n_vert_slices;
+  P.n_bytes = lp.slice_bytes_num / lp.slice_bytes_denom;
+  P.remainder = lp.slice_bytes_num % lp.slice_bytes_denom;
+  P.denom = lp.slice_bytes_denom;
+  for (int i = 0; i < 1 + 3 * depth; i++)
+    P.quant_matrix[i] = lp.quant_matrix[i];
+
+  std::vector < SliceJob > jobs (npictures);
+  std::vector < DcJob > dc (3 * (size_t) npictures);
+  for (int p = 0; p < npictures; p++) {
+    const SchroHipLowDelayPicture & pic = pictures[p];
+    SCHRO_HIP_REQUIRE (pic.slices && (int64_t) pic.slices_bytes >= need && pic.slices_bytes < ((size_t) 1 << 28),
+        "lowdelay_batch: picture %d: %zu bytes of slices, %lld needed", p, pic.slices_bytes, (long long) need);
+    SliceJob & j = jobs[p];
+    memset (&j, 0, sizeof (j));
+    j.data = pic.slices;
+    j.data_bytes = (uint32_t) pic.slices_bytes;
+    for (int k = 0; k < 3; k++) {
+      const int w = k ? lp.iwt_chroma_width : lp.iwt_luma_width;
+      SCHRO_HIP_REQUIRE (pic.comp[k] && pic.stride[k] >= w * bytes_per_sample && pic.stride[k] % bytes_per_sample == 0
+          && (uintptr_t) pic.comp[k] % bytes_per_sample == 0, "lowdelay_batch: picture %d component %d invalid", p, k);
+      j.comp[k] = pic.comp[k];
+      j.stride[k] = pic.stride[k];
+      DcJob & d = dc[3 * (size_t) p + k];
+      d.data = pic.comp[k];             // the LL band: sub-band 0 of schro_subband_get_frame_data
+      d.stride = pic.stride[k] << depth;
+      d.w = w >> depth;
+      d.h = (k ? lp.iwt_chroma_height : lp.iwt_luma_height) >> depth;
+      d.pad = 0;
+    }
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (SliceJob) * npictures, &d_jobs);
+  if (r)
+    return r;
+  {
+    ProfileScope ps (ctx, SCHRO_HIP_KERNEL_SLICES);
+    r = launch_slices (ctx->stream, (const SliceJob *) d_jobs, npictures, P, bytes_per_sample, arith);
+    if (r)
+      return r;
+  }
+  void *d_dc;
+  r = push_args (ctx, dc.data (), sizeof (DcJob) * dc.size (), &d_dc);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
+  return launch_dc_predict (ctx->stream, (const DcJob *) d_dc, (int) dc.size (), lp.iwt_luma_height >> depth,
+      bytes_per_sample);
+}
+
 int
 schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * planes, int nplanes)
 {

@@ -1,0 +1,406 @@
+// lowdelay.hip -- VC-2 low-delay transform data on the device.
+//
+//   slice_kernel        one thread per slice: exp-Golomb unpack + dequantise into the
+//                       interleaved coefficient frame (schrolowdelay.c:109-310)
+//   dc_predict_kernel   DC prediction of an LL band (schrodecoder.c:3219-3277)
+//
+// Slices are fixed-size and independent (their offsets follow from the slice number,
+// schrolowdelay.c:607-631), the codes inside one are strictly serial: a lane walks its
+// own slice, a wave holds 64 neighbouring slices of one slice row.  Bit-exact with the
+// reference's three decoders (see include/schro_hip.h for which one a picture gets).
+
+#include "schro_hip_internal.h"
+
+#include <algorithm>
+
+namespace schro {
+
+// schro_table_quant / schro_table_offset_1_2 (schrotables.c), by the generating formula of
+// the Dirac specification (13.3.1); tests pin all 61 entries against the reference's
+struct QuantTables {
+  uint32_t factor[61], offset[61];
+};
+constexpr QuantTables
+make_quant_tables ()
+{
+  QuantTables t = { };
+  for (int q = 0; q <= 60; q++) {
+    const uint64_t base = (uint64_t) 1 << (q / 4);
+    const uint64_t f = (q & 3) == 0 ? 4 * base : (q & 3) == 1 ? (503829 * base + 52958) / 105917
+        : (q & 3) == 2 ? (665857 * base + 58854) / 117708 : (440253 * base + 32722) / 65444;
+    t.factor[q] = (uint32_t) f;
+    t.offset[q] = q == 0 ? 1u : q == 1 ? 2u : (uint32_t) ((f + 1) / 2);
+  }
+  return t;
+}
+static __device__ const QuantTables kQuant = make_quant_tables ();
+
+// MSB-first bit reader over global memory; bits at or beyond `end` read as 1 (the guard bit
+// of schro_unpack_init_with_data (..., 1), schrolowdelay.c:126).  Three big-endian dwords
+// are held: the third is fetched a whole dword (a dozen codes) before its first bit is
+// needed, so the fetch -- an L2 round trip, 64 lanes read 64 different slices -- overlaps
+// the decode instead of stalling it at every 32-bit boundary.
+struct BitReader {
+  const uint32_t *words;        // 4-byte aligned
+  uint32_t pos, end;            // bit positions from words[0]
+  uint32_t last;                // index of the last dword that holds a byte of the buffer
+  uint32_t w0, w1, w2, widx;
+
+  __device__ __forceinline__ uint32_t fetch (uint32_t i) const
+  {
+    return __builtin_bswap32 (gload < uint32_t > (words + min (i, last)));
+  }
+  __device__ __forceinline__ void start (uint32_t p)
+  {
+    pos = p;
+    widx = p >> 5;
+    w0 = fetch (widx);
+    w1 = fetch (widx + 1);
+    w2 = fetch (widx + 2);
+  }
+  __device__ __forceinline__ void skip (uint32_t n)
+  {
+    pos += n;
+    if ((pos >> 5) > widx + 1)
+      start (pos);
+  }
+  // the next 32 bits
+  __device__ __forceinline__ uint32_t peek ()
+  {
+    const uint32_t wi = pos >> 5;
+    if (wi != widx) {           // a code is at most 32 bits here: one dword further
+      w0 = w1;
+      w1 = w2;
+      w2 = fetch (wi + 2);
+      widx = wi;
+    }
+    uint32_t v = __funnelshift_l (w1, w0, pos & 31u);
+    const uint32_t left = pos < end ? end - pos : 0u;
+    if (left < 32u)
+      v |= left ? 0xffffffffu >> left : 0xffffffffu;
+    return v;
+  }
+  __device__ __forceinline__ uint32_t bit ()
+  {
+    const uint32_t v = peek () >> 31;
+    pos++;
+    return v;
+  }
+  __device__ __forceinline__ uint32_t bits (int n)      // 0 <= n <= 32
+  {
+    if (n == 0)
+      return 0;
+    const uint32_t v = peek () >> (32 - n);
+    pos += n;
+    return v;
+  }
+  // schro_unpack_decode_sint: interleaved exp-Golomb, "0 b" per data bit, "1", sign
+  __device__ __forceinline__ int32_t sint ()
+  {
+    const uint32_t v = peek ();
+    const uint32_t stop = v & 0xaaaaaaaau;      // first 1 at an even position ends the code
+    const int k = __clz ((int) stop);           // 2 * count (32 if none)
+    if (k <= 30) {
+      const int c = k >> 1;
+      if (c == 0) {
+        pos += 1;
+        return 0;
+      }
+      // the c data bits sit at the odd positions of the top 2c bits
+      uint32_t t = (v >> (32 - k)) & 0x55555555u;
+      t = (t | (t >> 1)) & 0x33333333u;
+      t = (t | (t >> 2)) & 0x0f0f0f0fu;
+      t = (t | (t >> 4)) & 0x00ff00ffu;
+      t = (t | (t >> 8)) & 0x0000ffffu;
+      const uint32_t mag = (1u << c) - 1u + t;  // never 0 here
+      const uint32_t neg = (v >> (30 - k)) & 1u;
+      pos += k + 2;
+      return neg ? -(int32_t) mag : (int32_t) mag;
+    }
+    // longer than the window (|value| >= 65535): bit by bit, modulo 2^32
+    uint32_t count = 0, value = 0;
+    while (!bit ()) {
+      count++;
+      value = (value << 1) | bit ();
+    }
+    value += (count < 32u ? 1u << count : 0u) - 1u;
+    if (value && bit ())
+      value = 0u - value;
+    return (int32_t) value;
+  }
+};
+
+// schro_dequantise (schroutils.c:180-189): int arithmetic
+__device__ __forceinline__ int32_t
+dequant_int (int32_t q, uint32_t factor, uint32_t offset)
+{
+  if (q == 0)
+    return 0;
+  const uint32_t mag = q < 0 ? 0u - (uint32_t) q : (uint32_t) q;
+  const int32_t r = (int32_t) (mag * factor + offset + 2u) >> 2;
+  return q < 0 ? -r : r;
+}
+
+// orc_dequantise_var_s16_ip (schroorc.orc:1204-1217): 16 bits at every step
+__device__ __forceinline__ int32_t
+dequant_s16 (int32_t value, uint32_t factor, uint32_t offset)
+{
+  const int16_t q = (int16_t) value;
+  const int16_t f = (int16_t) factor, o = (int16_t) (offset + 2u);
+  const int16_t sign = q > 0 ? 1 : (q < 0 ? -1 : 0);
+  const int16_t mag = (int16_t) (q < 0 ? -q : q);
+  int16_t t = (int16_t) (mag * f);
+  t = (int16_t) (t + o);
+  t = (int16_t) (t >> 2);
+  return (int16_t) (t * sign);
+}
+
+__device__ __forceinline__ int
+subband_position (int index)
+{                               // schroparams.c:355-368
+  return index == 0 ? 0 : ((index - 1) / 3 + 1) * 4 - 3 + (index - 1) % 3;
+}
+
+// Staging of one sub-band row of a wave's 64 slices: lane L puts its bw values at
+// L * (bw + 1) (odd pitch: no bank conflicts), then the wave copies the 64 * bw values out
+// 16 bytes per lane -- neighbouring slices are neighbours in the row, so the copy is one
+// contiguous run per slice row instead of 64 scattered 2- or 4-byte stores per code.
+constexpr int kStageWords = 64 * 34;    // luma: bw <= 33; chroma (U and V): bw <= 16
+
+template < typename T, int ARITH >
+__global__ __launch_bounds__ (64)
+void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
+{
+  __shared__ int32_t stage[kStageWords];
+  __shared__ uint64_t rowbase[2][64];
+  constexpr int E = 16 / (int) sizeof (T);      // samples per 16-byte store
+  const SliceJob job = jobs[blockIdx.y];
+  const int lane = (int) threadIdx.x;
+  const int nslices = P.nh * P.nv;
+  const int s0 = blockIdx.x * 64, s = s0 + lane;
+  const bool active = s < nslices;
+  const int nvalid = min (64, nslices - s0);
+  const int sc = active ? s : nslices - 1;      // idle lanes shadow the last slice, read guard bits
+  const int sy = sc / P.nh, sx = sc - sy * P.nh;
+  // offset of slice s: s whole slices plus one extra byte per wrap of the accumulator
+  const uint32_t wraps = (uint32_t) (((uint64_t) sc * (uint32_t) P.remainder) / (uint32_t) P.denom);
+  const uint32_t wraps1 = (uint32_t) (((uint64_t) (sc + 1) * (uint32_t) P.remainder) / (uint32_t) P.denom);
+  const uint32_t offset = (uint32_t) sc * (uint32_t) P.n_bytes + wraps;
+  const uint32_t slice_bytes = (uint32_t) P.n_bytes + (wraps1 - wraps);
+
+  const uintptr_t addr = (uintptr_t) job.data;
+  BitReader yb;
+  yb.words = (const uint32_t *) (addr & ~(uintptr_t) 3);
+  const uint32_t lead = 8u * (uint32_t) (addr & 3);
+  const uint32_t buffer_end = lead + 8u * job.data_bytes;
+  yb.last = (buffer_end - 1u) >> 5;
+  yb.end = active ? lead + 8u * (offset + slice_bytes) : 0u;
+  yb.start (lead + 8u * offset);
+  const int base_index = (int) yb.bits (7);
+  const uint32_t field = 8u * (ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? (uint32_t) P.n_bytes : slice_bytes);
+  const int length_bits = field ? 32 - __clz ((int) field) : 0;         // ilog2up, :94-105
+  const uint32_t slice_y_length = yb.bits (length_bits);
+  BitReader uvb = yb;
+  yb.end = active ? min (yb.pos + slice_y_length, buffer_end) : 0u;     // schro_unpack_limit_bits_remaining
+  uvb.skip (slice_y_length);    // schro_unpack_skip_bits
+
+  const bool aligned = (((uintptr_t) job.comp[0] | (uintptr_t) job.comp[1] | (uintptr_t) job.comp[2]
+          | (uintptr_t) job.stride[0] | (uintptr_t) job.stride[1] | (uintptr_t) job.stride[2]) & 15) == 0;
+  const int nsub = 1 + 3 * P.depth;
+  BitReader b = yb;             // (one reader in registers: a reference to either would live in scratch)
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    if (k)
+      b = uvb;
+    const int iwt_w = k ? P.iwt_cw : P.iwt_lw, iwt_h = k ? P.iwt_ch : P.iwt_lh;
+    // luma alone, then U and V together (selected by value: indexing job.comp[] with k would
+    // put the job into scratch)
+    uint8_t *const plane[2] = { (uint8_t *) (k ? job.comp[1] : job.comp[0]), (uint8_t *) job.comp[2] };
+    const int plane_stride[2] = { k ? job.stride[1] : job.stride[0], job.stride[2] };
+#pragma unroll 1
+    for (int i = 0; i < nsub; i++) {
+      const int qi = min (max (base_index - P.quant_matrix[i], 0), 60);
+      const uint32_t qf = kQuant.factor[qi], qo = kQuant.offset[qi];
+      // schro_subband_get_frame_data + schro_frame_data_get_codeblock
+      const int position = subband_position (i);
+      const int shift = P.depth - (position >> 2);
+      const int w = iwt_w >> shift, h = iwt_h >> shift;
+      const int ebw = w / P.nh, ebh = h / P.nv;         // slice rectangle if the band divides evenly
+      const bool even = ebw * P.nh == w && ebh * P.nv == h;
+      const int xmin = even ? ebw * sx : (w * sx) / P.nh, xmax = even ? xmin + ebw : (w * (sx + 1)) / P.nh;
+      const int ymin = even ? ebh * sy : (h * sy) / P.nv, ymax = even ? ymin + ebh : (h * (sy + 1)) / P.nv;
+      const int bw = xmax - xmin;
+      uint8_t *dst[2];
+      size_t pitch[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        pitch[c] = (size_t) plane_stride[c] << shift;      // luma: c == 1 unused
+        dst[c] = plane[c] + ((position & 2) ? pitch[c] >> 1 : 0)
+            + ((position & 1) ? (size_t) w * sizeof (T) : 0) + (size_t) ymin * pitch[c] + (size_t) xmin * sizeof (T);
+      }
+      const int lpitch = ebw + 1;
+      if (even && aligned && ebw % E == 0 && (k + 1) * 64 * lpitch <= kStageWords) {
+        // ---- every lane has the same ebw x ebh rectangle: rows through LDS -------------
+        rowbase[0][lane] = (uint64_t) (uintptr_t) dst[0];
+        rowbase[1][lane] = (uint64_t) (uintptr_t) dst[1];
+        const int cpl = ebw / E;        // 16-byte chunks per lane and row
+        const uint32_t m_cpl = div_magic (cpl);
+        const int nchunk = nvalid * cpl;
+        int32_t *mine = stage + lane * lpitch;
+        size_t yoff[2] = { 0, 0 };
+#pragma unroll 1
+        for (int y = 0; y < ebh; y++) {
+#pragma unroll 1
+          for (int x = 0; x < ebw; x++) {
+            const int32_t v0 = b.sint ();
+            mine[x] = ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? dequant_s16 (v0, qf, qo) : dequant_int (v0, qf, qo);
+            if (k) {            // U and V values alternate
+              const int32_t v1 = b.sint ();
+              mine[64 * lpitch + x] = ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? dequant_s16 (v1, qf, qo) : dequant_int (v1, qf, qo);
+            }
+          }
+          __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
+          __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+          for (int c = 0; c <= k; c++) {
+#pragma unroll 1
+            for (int ch = lane; ch < nchunk; ch += 64) {
+              const int src = mdiv (ch, cpl, m_cpl), xc = ch - src * cpl;
+              const int32_t *from = stage + c * 64 * lpitch + src * lpitch + xc * E;
+              uint8_t *to = (uint8_t *) (uintptr_t) rowbase[c][src] + yoff[c] + (size_t) xc * 16;
+              u32x4 o;
+              if constexpr (E == 4) {
+                o = u32x4 { (uint32_t) from[0], (uint32_t) from[1], (uint32_t) from[2], (uint32_t) from[3] };
+              } else {
+                o = u32x4 { ((uint32_t) from[0] & 0xffffu) | ((uint32_t) from[1] << 16),
+                  ((uint32_t) from[2] & 0xffffu) | ((uint32_t) from[3] << 16),
+                  ((uint32_t) from[4] & 0xffffu) | ((uint32_t) from[5] << 16),
+                  ((uint32_t) from[6] & 0xffffu) | ((uint32_t) from[7] << 16) };
+              }
+              gstore < u32x4 > (to, o);
+            }
+          }
+          __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier ();     // the next row overwrites the staging
+          __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+          yoff[0] += pitch[0];
+          yoff[1] += pitch[1];
+        }
+        continue;
+      }
+      // ---- ragged rectangles, odd widths, unaligned planes: store as decoded -----------
+#pragma unroll 1
+      for (int y = ymin; y < ymax; y++) {
+#pragma unroll 1
+        for (int x = 0; x < bw; x++) {
+          const int32_t v0 = b.sint ();
+          const int32_t d0 = ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? dequant_s16 (v0, qf, qo) : dequant_int (v0, qf, qo);
+          if (active)
+            gstore < T > ((T *) dst[0] + x, (T) d0);
+          if (k) {              // U and V values alternate
+            const int32_t v1 = b.sint ();
+            const int32_t d1 = ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? dequant_s16 (v1, qf, qo) : dequant_int (v1, qf, qo);
+            if (active)
+              gstore < T > ((T *) dst[1] + x, (T) d1);
+          }
+        }
+        dst[0] += pitch[0];
+        dst[1] += pitch[1];
+      }
+    }
+  }
+}
+
+// ---- DC prediction ---------------------------------------------------------------------
+// x[j][i] += pred (x[j][i-1], x[j-1][i], x[j-1][i-1]): serial along rows AND columns, only
+// the anti-diagonals are independent.  One workgroup per band; thread r owns row band0 + r
+// and is one column behind thread r - 1, so what it needs from the row above was made in
+// the previous step (handed over through LDS) and the step before (kept in a register).
+constexpr int kDcRows = 1024;
+
+template < typename T > __device__ __forceinline__ int32_t dc_mean3 (int32_t a);
+template <> __device__ __forceinline__ int32_t dc_mean3 < int16_t > (int32_t a)
+{
+  return (a * 21845 + 10922) >> 16;     // schro_divide3, schroutils.h:64
+}
+template <> __device__ __forceinline__ int32_t dc_mean3 < int32_t > (int32_t a)
+{
+  // schro_divide (a, 3), schroutils.h:63: floor
+  const int32_t n = a < 0 ? (int32_t) ((uint32_t) a - 2u) : a;
+  return n / 3;
+}
+
+template < typename T >
+__global__ __launch_bounds__ (kDcRows)
+void dc_predict_kernel (const DcJob * __restrict__ jobs)
+{
+  __shared__ int32_t xchg[2][kDcRows];
+  const DcJob job = jobs[blockIdx.x];
+  const int r = threadIdx.x, R = blockDim.x;
+  const int w = job.w, h = job.h;
+  for (int band0 = 0; band0 < h; band0 += R) {
+    const int j = band0 + r;
+    const bool have_row = j < h;
+    T *line = (T *) ((uint8_t *) job.data + (size_t) j * job.stride);
+    const T *above = (const T *) ((const uint8_t *) job.data + (size_t) (j - 1) * job.stride);
+    int32_t left = 0, upleft = 0;
+    const int rows = min (R, h - band0);
+    const int steps = w + rows - 1;
+    for (int s = 0; s < steps; s++) {
+      const int x = s - r;
+      if (have_row && x >= 0 && x < w) {
+        const int32_t q = gload < T > (line + x);
+        int32_t v;
+        if (j == 0) {
+          v = x > 0 ? (int32_t) (T) ((uint32_t) q + (uint32_t) left) : q;
+        } else {
+          // the row above: finished by the previous band (global) or one step ahead (LDS)
+          const int32_t up = r == 0 ? (int32_t) gload < T > (above + x) : xchg[(s + 1) & 1][r - 1];
+          const int32_t pred = x == 0 ? up
+              : dc_mean3 < T > ((int32_t) ((uint32_t) left + (uint32_t) up + (uint32_t) upleft + 1u));
+          v = (int32_t) (T) ((uint32_t) q + (uint32_t) pred);
+          upleft = up;
+        }
+        gstore < T > (line + x, (T) v);
+        left = v;
+        xchg[s & 1][r] = v;
+      }
+      __syncthreads ();
+    }
+    __syncthreads ();           // rows of this band are in memory before the next reads them
+  }
+}
+
+int
+launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith)
+{
+  const dim3 grid ((unsigned) ((P.nh * P.nv + 63) / 64), (unsigned) njobs);
+  if (bpp == 4)
+    hipLaunchKernelGGL ((slice_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), 0, stream, d_jobs, P);
+  else if (arith == SCHRO_HIP_LOWDELAY_FAST16)
+    hipLaunchKernelGGL ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_FAST16 >), grid, dim3 (64), 0, stream, d_jobs, P);
+  else
+    hipLaunchKernelGGL ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_SLOW16 >), grid, dim3 (64), 0, stream, d_jobs, P);
+  const hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "slice kernel launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+int
+launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp)
+{
+  // whole waves; a band taller than kDcRows is walked in slabs
+  const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);
+  if (bpp == 4)
+    hipLaunchKernelGGL ((dc_predict_kernel < int32_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+  else
+    hipLaunchKernelGGL ((dc_predict_kernel < int16_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+  const hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "dc_predict kernel launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+}                               // namespace schro

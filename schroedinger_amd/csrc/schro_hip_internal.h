@@ -98,6 +98,32 @@ struct ObmcJob {
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
 };
 
+// One picture's slices (lowdelay.hip).
+struct SliceJob {
+  const uint8_t *data;
+  uint32_t data_bytes;
+  int pad;
+  void *comp[3];
+  int stride[3];
+  int pad2;
+};
+
+// What every slice of a launch shares (passed by value).
+struct SliceParams {
+  int depth;
+  int iwt_lw, iwt_lh, iwt_cw, iwt_ch;
+  int nh, nv;
+  int n_bytes, remainder, denom;        // slice_bytes_num / _denom split, schrolowdelay.c:601-602
+  int quant_matrix[SCHRO_HIP_LIMIT_SUBBANDS];
+};
+
+struct DcJob {
+  void *data;
+  int stride;
+  int w, h;
+  int pad;
+};
+
 constexpr int kMaxJobs = 256;
 
 // XCD-aware workgroup order.  The dispatcher deals workgroups round-robin over
@@ -233,6 +259,9 @@ void pack_tile_geometry (int *groups_x, int *rows);
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);
 void upsample_tile_geometry (int *tw, int *th);
+int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P,
+    int bpp, int arith);
+int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant);
 // fills the item-kernel geometry fields of a job (obmc.hip)

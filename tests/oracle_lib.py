@@ -51,8 +51,32 @@ def lib():
         L.oracle_pack_u8.restype = i
         L.oracle_pack_v210.argtypes = [vp, i, i, i, vp, i]
         L.oracle_pack_v210.restype = i
+        L.oracle_lowdelay_arith.argtypes = [C.POINTER(LowDelayParams), i]
+        L.oracle_lowdelay_arith.restype = i
+        L.oracle_lowdelay_decode.argtypes = [vp, C.c_int64, C.c_void_p * 3, C.c_int * 3, C.POINTER(LowDelayParams), i]
+        L.oracle_lowdelay_decode.restype = i
+        L.oracle_lowdelay_write.argtypes = [vp, C.c_int64, C.c_void_p * 3, C.c_int * 3, C.POINTER(LowDelayParams), i,
+                                            vp, i, i]
+        L.oracle_lowdelay_write.restype = i
+        L.oracle_dc_predict.argtypes = [vp, i, i, i, i]
+        L.oracle_dc_predict.restype = None
+        L.oracle_quant_factor.argtypes = [i]
+        L.oracle_quant_factor.restype = C.c_uint32
+        L.oracle_quant_offset_1_2.argtypes = [i]
+        L.oracle_quant_offset_1_2.restype = C.c_uint32
+        L.oracle_dequantise_var_s16.argtypes = [C.c_int16, i, i]
+        L.oracle_dequantise_var_s16.restype = C.c_int16
         _LIB = L
     return _LIB
+
+
+class LowDelayParams(C.Structure):
+    _fields_ = [("transform_depth", C.c_int),
+                ("iwt_luma_width", C.c_int), ("iwt_luma_height", C.c_int),
+                ("iwt_chroma_width", C.c_int), ("iwt_chroma_height", C.c_int),
+                ("n_horiz_slices", C.c_int), ("n_vert_slices", C.c_int),
+                ("slice_bytes_num", C.c_int), ("slice_bytes_denom", C.c_int),
+                ("quant_matrix", C.c_int * 19)]
 
 
 def ref_available():
@@ -236,3 +260,68 @@ def motion_render(mvs, params, k, ref1, ref2, residual, width, height):
         _ptr(acc), acc.strides[0], _ptr(out), out.strides[0], width, height)
     assert r == 0
     return out
+
+
+# ---- VC-2 low-delay transform data ----------------------------------------------
+
+LOWDELAY_FAST16, LOWDELAY_SLOW16, LOWDELAY_S32 = 0, 1, 2
+
+
+def _ld_params(P):
+    lp = LowDelayParams()
+    for name in ("transform_depth", "iwt_luma_width", "iwt_luma_height", "iwt_chroma_width",
+                 "iwt_chroma_height", "n_horiz_slices", "n_vert_slices", "slice_bytes_num",
+                 "slice_bytes_denom"):
+        setattr(lp, name, int(P[name]))
+    for k, q in enumerate(P["quant_matrix"]):
+        lp.quant_matrix[k] = int(q)
+    return lp
+
+
+def _ld_planes(planes):
+    comp = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    stride = (C.c_int * 3)(*[p.strides[0] for p in planes])
+    return comp, stride
+
+
+def lowdelay_arith(P, bpp):
+    return lib().oracle_lowdelay_arith(C.byref(_ld_params(P)), bpp)
+
+
+def lowdelay_slice_bytes(P):
+    """schrodecoder.c:2931-2932"""
+    return (P["slice_bytes_num"] * P["n_horiz_slices"] * P["n_vert_slices"]) // P["slice_bytes_denom"]
+
+
+def lowdelay_decode(data, planes, P):
+    """Decodes into the three planes (C-contiguous s16 / s32 arrays) in place."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    comp, stride = _ld_planes(planes)
+    r = lib().oracle_lowdelay_decode(_ptr(data), data.size, comp, stride, C.byref(_ld_params(P)),
+                                     planes[0].dtype.itemsize)
+    assert r == 0, r
+
+
+def lowdelay_write(planes, P, bpp, base_index, pad_bit=1, y_length_bias=0, nbytes=None):
+    """Slice bytes for QUANTISED values (int32 planes in the coefficient frame layout) of a
+    picture whose samples are bpp bytes."""
+    assert all(p.dtype == np.int32 for p in planes)
+    data = np.zeros(lowdelay_slice_bytes(P) if nbytes is None else nbytes, np.uint8)
+    base_index = np.ascontiguousarray(base_index, dtype=np.uint8)
+    assert base_index.size == P["n_horiz_slices"] * P["n_vert_slices"]
+    comp, stride = _ld_planes(planes)
+    r = lib().oracle_lowdelay_write(_ptr(data), data.size, comp, stride, C.byref(_ld_params(P)),
+                                    bpp, _ptr(base_index), pad_bit, y_length_bias)
+    assert r == 0, r
+    return data
+
+
+def dc_predict(a):
+    a = np.ascontiguousarray(a).copy()
+    lib().oracle_dc_predict(_ptr(a), a.strides[0], a.shape[1], a.shape[0], _bpp(a))
+    return a
+
+
+def quant_tables():
+    L = lib()
+    return ([L.oracle_quant_factor(q) for q in range(61)], [L.oracle_quant_offset_1_2(q) for q in range(61)])

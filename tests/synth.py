@@ -79,3 +79,48 @@ def motion_params(width, height, xblen, xbsep, prec, weights=(1, 1, 1), chroma=(
                 xbsep_luma=xbsep, ybsep_luma=ybsep, mv_precision=prec,
                 picture_weight_bits=weights[2], picture_weight_1=weights[0],
                 picture_weight_2=weights[1], chroma_h_shift=chroma[0], chroma_v_shift=chroma[1])
+
+
+# ---- VC-2 low-delay pictures ------------------------------------------------------
+
+# schro_tables_lowdelay_quants is the host's business (the ABI takes the matrix); these are
+# plausible matrices of the right length
+def lowdelay_params(width, height, chroma, depth, slice_w, slice_h, slice_bytes_num, slice_bytes_denom=1,
+                    quant_matrix=None):
+    """Parameter dict of a low-delay picture: iwt sizes padded to 2^depth
+    (schro_params_calculate_iwt_sizes, schroparams.c:121-140), slices of slice_w x slice_h
+    luma samples (counts rounded up)."""
+    cw, ch = -(-width // (1 << chroma[0])), -(-height // (1 << chroma[1]))
+    rnd = lambda v: -(-v // (1 << depth)) * (1 << depth)
+    if quant_matrix is None:
+        quant_matrix = [0] + [q for lvl in range(depth) for q in (min(4 + 2 * lvl, 12),) * 2 + (min(6 + 2 * lvl, 14),)]
+    return dict(transform_depth=depth, iwt_luma_width=rnd(width), iwt_luma_height=rnd(height),
+                iwt_chroma_width=rnd(cw), iwt_chroma_height=rnd(ch),
+                n_horiz_slices=max(1, rnd(width) // slice_w), n_vert_slices=max(1, rnd(height) // slice_h),
+                slice_bytes_num=slice_bytes_num, slice_bytes_denom=slice_bytes_denom,
+                quant_matrix=list(quant_matrix))
+
+
+def quantised_planes(P, seed=1, scale=3.0, big_every=0, big_range=1 << 31):
+    """Laplacian-ish quantised coefficients (mostly 0 / +-1, as in a real stream) as int32
+    planes in the frame layout; big_every > 0 sprinkles values below big_range that need
+    the long exp-Golomb path / wrap in 16 bits."""
+    out = []
+    for k in range(3):
+        w = P["iwt_chroma_width"] if k else P["iwt_luma_width"]
+        h = P["iwt_chroma_height"] if k else P["iwt_luma_height"]
+        r = lcg(2 * h * w, seed + 7 * k).astype(np.int64)
+        u = (r[: h * w] + 1) / 65537.0
+        mag = np.floor(-scale * np.log(u)).astype(np.int64)
+        v = np.where(r[h * w:] & 1, -mag, mag)
+        if big_every:
+            idx = np.arange(0, h * w, big_every)
+            big = ((r[idx] * 2654435761) >> 3) % big_range
+            v[idx] = np.where(r[idx] & 2, -big, big)
+        out.append(v.astype(np.int32).reshape(h, w))
+    return out
+
+
+def lowdelay_base_index(P, seed=1, lo=0, hi=40):
+    n = P["n_horiz_slices"] * P["n_vert_slices"]
+    return (lo + lcg(n, seed + 99) % (hi - lo + 1)).astype(np.uint8)

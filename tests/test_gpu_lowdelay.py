@@ -1,0 +1,176 @@
+"""GPU parity: VC-2 low-delay transform data (slice unpack + dequantise + DC prediction,
+schro_hip_lowdelay_batch through the C ABI) vs the CPU oracle's restatement of
+schro_decoder_decode_lowdelay_transform_data (schrolowdelay.c:559-762).  Bit-exact, for
+each of the reference's three slice decoders (s16 fast / s16 slow / s32)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Offset:
+    """A byte range inside a device buffer (slices need not start 4-byte aligned)."""
+
+    def __init__(self, plane, off, nbytes):
+        self.ptr, self.width = plane.ptr + off, nbytes
+
+
+def decode_gpu(ctx, pictures, P, bpp, misalign=0):
+    """pictures: slice byte arrays.  Returns per picture the three decoded planes."""
+    dt = np.int16 if bpp == 2 else np.int32
+    jobs, keep = [], []
+    for n, data in enumerate(pictures):
+        off = (misalign + n) % 4 if misalign else 0
+        raw = np.concatenate([np.full(off, 0xa5, np.uint8), data])
+        d = ctx.upload_bytes(raw)
+        planes = [ctx.plane(P["iwt_chroma_height"] if k else P["iwt_luma_height"],
+                            P["iwt_chroma_width"] if k else P["iwt_luma_width"], dt).fill(0x5a) for k in range(3)]
+        jobs.append((Offset(d, off, data.size), planes))
+        keep.append(d)
+    ctx.lowdelay_batch(jobs, P)
+    out = [[p.download() for p in planes] for _, planes in jobs]
+    for (_, planes), d in zip(jobs, keep):
+        d.free()
+        for p in planes:
+            p.free()
+    return out
+
+
+def decode_cpu(data, P, bpp):
+    planes = [np.full((P["iwt_chroma_height"] if k else P["iwt_luma_height"],
+                       P["iwt_chroma_width"] if k else P["iwt_luma_width"]), 0x5a5a5a5a & (0xffff if bpp == 2 else -1),
+                      np.int16 if bpp == 2 else np.int32) for k in range(3)]
+    O.lowdelay_decode(data, planes, P)
+    return planes
+
+
+def compare(got, want, what):
+    for k in range(3):
+        if not np.array_equal(got[k], want[k]):
+            bad = np.argwhere(got[k] != want[k])
+            raise AssertionError("%s component %d: %d mismatches, first at (y,x)=%s got %d want %d" % (
+                what, k, len(bad), tuple(bad[0]), got[k][tuple(bad[0])], want[k][tuple(bad[0])]))
+
+
+# w, h, chroma, depth, slice w, slice h, bytes num, denom, slices override
+GEOMETRIES = [
+    (64, 32, (1, 1), 2, 16, 8, 241, 2, None),
+    (64, 32, (0, 0), 1, 8, 8, 200, 1, None),
+    (128, 64, (1, 0), 3, 32, 8, 321, 3, None),
+    (72, 40, (1, 0), 2, 24, 10, 1000, 3, (5, 3)),       # ragged slice rectangles (slow decoder for s16)
+    (96, 64, (1, 1), 4, 32, 32, 2001, 4, (5, 3)),
+    (16, 16, (1, 1), 0, 8, 8, 150, 1, None),            # depth 0
+    (200, 24, (1, 1), 1, 8, 8, 90, 1, (25, 3)),         # more slices per row than a wave has lanes... of 3 rows
+    (1040, 16, (1, 0), 1, 16, 16, 255, 2, None),        # 65 slices in a row: two waves, field width changes (255/2)
+]
+
+
+@pytest.mark.parametrize("bpp", [2, 4])
+@pytest.mark.parametrize("geo", GEOMETRIES)
+def test_legal_streams(ctx, geo, bpp):
+    w, h, chroma, depth, sw, sh, num, den, override = geo
+    P = synth.lowdelay_params(w, h, chroma, depth, sw, sh, num, den)
+    if override:
+        P["n_horiz_slices"], P["n_vert_slices"] = override
+    assert ctx.lowdelay_arith(P, bpp) == O.lowdelay_arith(P, bpp)
+    pictures = []
+    for n in range(3):
+        q = synth.quantised_planes(P, seed=w + depth + 11 * n, scale=0.7 + 0.4 * n)
+        bi = synth.lowdelay_base_index(P, seed=h + n, lo=0, hi=44)
+        pictures.append(O.lowdelay_write(q, P, bpp, bi, pad_bit=n & 1))
+    got = decode_gpu(ctx, pictures, P, bpp, misalign=1)
+    for n, data in enumerate(pictures):
+        compare(got[n], decode_cpu(data, P, bpp), "picture %d" % n)
+
+
+@pytest.mark.parametrize("bpp", [2, 4])
+def test_long_codes_wrap_and_quantiser_range(ctx, bpp):
+    # values beyond the 32-bit decode window (|v| >= 65535), products that wrap in 16 / 32 bits,
+    # base indices up to 127 (quantiser index clamps at 60; schrolowdelay.c:140)
+    for override in (None, (5, 3)):
+        P = synth.lowdelay_params(96, 48, (1, 0), 2, 24, 12, 3000, 1)
+        if override:
+            P["n_horiz_slices"], P["n_vert_slices"] = override
+        q = synth.quantised_planes(P, seed=5, scale=1.5, big_every=13, big_range=1 << 31)
+        q[0][3, 5], q[0][7, 9], q[1][2, 2] = (1 << 31) - 1, -(1 << 31) + 1, 65535
+        bi = synth.lowdelay_base_index(P, seed=6, lo=0, hi=127)
+        data = O.lowdelay_write(q, P, bpp, bi)
+        got = decode_gpu(ctx, [data], P, bpp)
+        compare(got[0], decode_cpu(data, P, bpp), "override %s" % (override,))
+
+
+@pytest.mark.parametrize("bpp", [2, 4])
+def test_short_slices_and_corrupt_lengths(ctx, bpp):
+    # codes cut off by the end of the slice (guard bits), slice_y_length fields that point
+    # short of / beyond the luma codes and beyond the slice (the reference then reads the next
+    # slice's bytes; at the end of the buffer it would read out of bounds, we read guard bits)
+    P = synth.lowdelay_params(128, 32, (1, 1), 2, 16, 8, 49, 2)
+    q = synth.quantised_planes(P, seed=8, scale=2.5)
+    bi = synth.lowdelay_base_index(P, seed=9, lo=0, hi=30)
+    pictures = [O.lowdelay_write(q, P, bpp, bi, pad_bit=pad, y_length_bias=bias)
+                for pad in (0, 1) for bias in (0, -17, 23, 150, 4000)]
+    rnd = (synth.lcg(pictures[0].size, 4) & 0xff).astype(np.uint8)       # noise is a stream too
+    pictures += [rnd, np.zeros_like(rnd), np.full_like(rnd, 0xff)]
+    got = decode_gpu(ctx, pictures, P, bpp, misalign=2)
+    for n, data in enumerate(pictures):
+        compare(got[n], decode_cpu(data, P, bpp), "stream %d" % n)
+
+
+def test_golden_fixture(ctx):
+    z = np.load(os.path.join(HERE, "golden", "lowdelay_oracle.npz"))
+    names = ("transform_depth", "iwt_luma_width", "iwt_luma_height", "iwt_chroma_width", "iwt_chroma_height",
+             "n_horiz_slices", "n_vert_slices", "slice_bytes_num", "slice_bytes_denom")
+    for case, bpp in (("fast16", 2), ("slow16", 2), ("s32", 4)):
+        v = z[case + "_params"].tolist()
+        P = dict(zip(names, v[:9]), quant_matrix=v[9:])
+        got = decode_gpu(ctx, [z[case + "_slices"]], P, bpp)[0]
+        compare(got, [z["%s_comp%d" % (case, k)] for k in range(3)], case)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_dc_predict_alone(ctx, dtype):
+    shapes = [(1, 1), (1, 300), (300, 1), (64, 64), (65, 130), (540, 960), (1100, 37), (2100, 3)]
+    planes, want = [], []
+    for n, (h, w) in enumerate(shapes):
+        a = synth.image_s(h, w, dtype, seed=20 + n) * 5
+        if n % 2 and dtype == np.int16:
+            a = synth.full_range(h, w, dtype, seed=40 + n)           # int16 sums wrap
+        planes.append(ctx.upload(a))
+        want.append(O.dc_predict(a))
+    ctx.dc_predict_batch(planes)
+    for p, wnt, shp in zip(planes, want, shapes):
+        got = p.download()
+        assert np.array_equal(got, wnt), shp
+        p.free()
+
+
+def test_bad_arguments_are_refused(ctx):
+    P = synth.lowdelay_params(64, 32, (1, 1), 2, 16, 8, 100)
+    data = np.zeros(O.lowdelay_slice_bytes(P), np.uint8)
+    with pytest.raises(sa.SchroHipError):                    # buffer shorter than the slices
+        decode_gpu(ctx, [data[:-1]], P, 2)
+    bad = dict(P, iwt_luma_width=66)
+    with pytest.raises(sa.SchroHipError):                    # not a multiple of 2^depth
+        decode_gpu(ctx, [data], bad, 2)
+    bad = dict(P, slice_bytes_denom=0)
+    with pytest.raises(sa.SchroHipError):
+        decode_gpu(ctx, [data], bad, 2)
+
+
+def test_8k_422_10bit_configuration(ctx):
+    # BASELINE config 5: 7680x4320 4:2:2, s32 coefficients, 3 levels, 32x8-sample slices
+    # (240 x 540 = 129600 slices), about 2.4 bits per sample
+    P = synth.lowdelay_params(7680, 4320, (1, 0), 3, 32, 8, 155, 1)
+    q = synth.quantised_planes(P, seed=31, scale=0.9)
+    bi = synth.lowdelay_base_index(P, seed=32, lo=4, hi=28)
+    data = O.lowdelay_write(q, P, 4, bi)
+    del q
+    got = decode_gpu(ctx, [data], P, 4)
+    compare(got[0], decode_cpu(data, P, 4), "8K")
