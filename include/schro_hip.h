@@ -397,6 +397,12 @@ typedef struct {
 int schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
     const SchroHipFrame * transform_frame, const SchroHipParams * params);
 
+/* schro_decoder_decode_lowdelay_transform_data (picture), schrolowdelay.c:746-762, with
+ * picture->transform_frame on the device: `slices` is picture->lowdelay_buffer->data (host),
+ * copied to the device compressed; the frame's format picks s16 / s32.  Synchronous. */
+int schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame,
+    const void *slices, size_t slices_bytes, const SchroHipLowDelayParams * params);
+
 /* schro_upsampled_gpuframe_upsample (schrogpuframe.h:27) replacement:
  * dest (device, is_upsampled) <- half-pel images of src (device u8). */
 int schro_upsampled_hipframe_upsample (SchroHipFrame * dest,

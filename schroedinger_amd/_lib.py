@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
     "schro_hip_pack_v210_batch",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
+    "schro_hip_decode_lowdelay_transform_data",
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
@@ -183,6 +184,8 @@ def load():
     L.schro_hip_lowdelay_arith.restype = i
     L.schro_hip_lowdelay_batch.argtypes = [vp, C.POINTER(LowDelayPicture), i, C.POINTER(LowDelayParams), i]
     L.schro_hip_lowdelay_batch.restype = i
+    L.schro_hip_decode_lowdelay_transform_data.argtypes = [C.POINTER(Frame), vp, C.c_size_t, C.POINTER(LowDelayParams)]
+    L.schro_hip_decode_lowdelay_transform_data.restype = i
     L.schro_hip_dc_predict_batch.argtypes = [vp, C.POINTER(DcPlane), i, i]
     L.schro_hip_dc_predict_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]

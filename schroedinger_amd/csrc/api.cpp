@@ -1203,6 +1203,41 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
 }
 
 int
+schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const void *slices,
+    size_t slices_bytes, const SchroHipLowDelayParams * params)
+{
+  SCHRO_HIP_REQUIRE (transform_frame && transform_frame->domain && slices && params,
+      "decode_lowdelay_transform_data: bad arguments");
+  SchroHipContext *ctx = transform_frame->domain;
+  const int bpp = format_bpp (transform_frame->format);
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "decode_lowdelay_transform_data: the frame must be s16 or s32");
+  for (int k = 0; k < 3; k++)
+    SCHRO_HIP_REQUIRE ((k ? params->iwt_chroma_width : params->iwt_luma_width) <= transform_frame->components[k].width
+        && (k ? params->iwt_chroma_height : params->iwt_luma_height) <= transform_frame->components[k].height,
+        "decode_lowdelay_transform_data: component %d smaller than the iwt size", k);
+  // picture->lowdelay_buffer goes to the device as it is: compressed
+  void *d_slices = schro_hip_domain_alloc (ctx, slices_bytes ? slices_bytes : 1);
+  if (!d_slices)
+    return SCHRO_HIP_ENOMEM;
+  int r = 0;
+  if (hipMemcpyAsync (d_slices, slices, slices_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    r = set_error (SCHRO_HIP_EDEVICE, "decode_lowdelay_transform_data: copy of %zu bytes failed", slices_bytes);
+  if (!r) {
+    SchroHipLowDelayPicture pic;
+    pic.slices = (const uint8_t *) d_slices;
+    pic.slices_bytes = slices_bytes;
+    for (int k = 0; k < 3; k++) {
+      pic.comp[k] = transform_frame->components[k].data;
+      pic.stride[k] = transform_frame->components[k].stride;
+    }
+    r = schro_hip_lowdelay_batch (ctx, &pic, 1, params, bpp);
+  }
+  const int rs = schro_hip_synchronize (ctx);   // the host buffer and d_slices are free again
+  schro_hip_domain_free (ctx, d_slices);
+  return r ? r : rs;
+}
+
+int
 schro_upsampled_hipframe_upsample (SchroHipFrame * dest, const SchroHipFrame * src)
 {
   SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain

@@ -317,7 +317,7 @@ void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
 // the anti-diagonals are independent.  One workgroup per band; thread r owns row band0 + r
 // and is one column behind thread r - 1, so what it needs from the row above was made in
 // the previous step (handed over through LDS) and the step before (kept in a register).
-constexpr int kDcRows = 1024;
+constexpr int kDcRows = 576;        // rows of a band = threads of the workgroup (LDS: 128 bytes of window per row)
 
 template < typename T > __device__ __forceinline__ int32_t dc_mean3 (int32_t a);
 template <> __device__ __forceinline__ int32_t dc_mean3 < int16_t > (int32_t a)
@@ -331,14 +331,218 @@ template <> __device__ __forceinline__ int32_t dc_mean3 < int32_t > (int32_t a)
   return n / 3;
 }
 
+// sample e of a 16-byte piece / the piece with sample e replaced (e is a compile-time index)
+template < typename T, int e > __device__ __forceinline__ int32_t
+piece_get (const u32x4 & v)
+{
+  if constexpr (sizeof (T) == 4)
+    return (int32_t) v[e];
+  else
+    return (int16_t) (v[e >> 1] >> (16 * (e & 1)));
+}
+
+template < typename T, int e > __device__ __forceinline__ void
+piece_set (u32x4 & v, int32_t s)
+{
+  if constexpr (sizeof (T) == 4)
+    v[e] = (uint32_t) s;
+  else if constexpr ((e & 1) == 0)
+    v[e >> 1] = (uint32_t) s & 0xffffu;
+  else
+    v[e >> 1] |= (uint32_t) s << 16;
+}
+
+struct DcRow {
+  int32_t left, upleft;
+};
+
+// one 16-byte piece of a row: E samples, serially
+template < typename T, int e = 0 >
+__device__ __forceinline__ void
+dc_piece (const u32x4 & in, const u32x4 & up, u32x4 & out, DcRow & st, bool first_row, bool first_piece)
+{
+  constexpr int E = 16 / (int) sizeof (T);
+  if constexpr (e < E) {
+    const int32_t q = piece_get < T, e > (in);
+    int32_t v;
+    if (first_row) {
+      v = (e > 0 || !first_piece) ? (int32_t) (T) ((uint32_t) q + (uint32_t) st.left) : q;
+    } else {
+      const int32_t u = piece_get < T, e > (up);
+      const int32_t pred = (e == 0 && first_piece) ? u
+          : dc_mean3 < T > ((int32_t) ((uint32_t) st.left + (uint32_t) u + (uint32_t) st.upleft + 1u));
+      v = (int32_t) (T) ((uint32_t) q + (uint32_t) pred);
+      st.upleft = u;
+    }
+    st.left = v;
+    piece_set < T, e > (out, v);
+    dc_piece < T, e + 1 > (in, up, out, st, first_row, first_piece);
+  }
+}
+
+template < typename T, int e = 0 >
+__device__ __forceinline__ void
+store_some (T * to, const u32x4 & v, int n)
+{
+  constexpr int E = 16 / (int) sizeof (T);
+  if constexpr (e < E) {
+    if (e < n)
+      gstore < T > (to + e, (T) piece_get < T, e > (v));
+    store_some < T, e + 1 > (to, v, n);
+  }
+}
+
+// workgroup barrier that orders LDS only: __syncthreads () would also wait for the row
+// pieces in flight (it fences global memory too)
+__device__ __forceinline__ void
+lds_barrier ()
+{
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier ();
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Thread r owns row band0 + r and works in 16-byte pieces (E samples), one piece per step,
+// one piece behind thread r - 1: the piece of the row above was finished in the previous
+// step and comes through LDS (xv).
+//
+// Memory side.  The rows of an LL band lie 2^depth frame rows apart, so a wave whose lanes
+// each fetch or store the piece of their own row touches 64 cache lines per instruction;
+// with one such load and store per step the texture path, at about a line per clock, was
+// the whole step (0.85 us).  Rows are therefore moved in groups of kDcGroup pieces -- 128
+// contiguous bytes per row, 8 lanes per row, 8 rows per instruction -- through an LDS window
+// slot[row][k]: at the top of a group every thread issues the loads of its share of the
+// NEXT group's window into registers (two thirds of a microsecond of L2 latency that the 8
+// steps of the group cover), the steps work in place on the window, and the end of the
+// group flushes the window to memory and refills it from the registers.  The window of
+// band row ri for the group that starts at step S0 holds pieces S0 - ri ... + 7 (the pieces
+// thread ri works on in those steps); staged row 0 is the row above the band (pieces S0 ...,
+// read by thread 0 of a later band, never flushed).
+constexpr int kDcGroup = 8;
+constexpr int kDcShare = kDcGroup + 1;  // window slots per thread: (rows + 1) * kDcGroup / rows, rounded up
+constexpr int kDcPitch = kDcGroup + 1;  // slots per window row in LDS: 144 bytes, so that the lanes' own slots spread over the banks
+
+template < typename T >
+struct DcBand {
+  static constexpr int E = 16 / (int) sizeof (T);
+  int w, rows, npieces, steps;
+  int r;
+  // this thread's share of the window: slot q = r + R * m lives in staged row q / kDcGroup
+  // (0: the row above the band) at position q % kDcGroup -- fixed for the band, worked out once
+  T *row[kDcShare];
+  int pbase[kDcShare];          // piece held by the slot in the group that starts at step 0
+  int lslot[kDcShare];          // slot index, or -1: beyond the window / the row above (never flushed)
+  int kpos[kDcShare];
+
+  __device__ __forceinline__ void setup (const DcJob & job, int band0, int R)
+  {
+#pragma unroll
+    for (int m = 0; m < kDcShare; m++) {
+      const int q = r + R * m, qc = min (q, (rows + 1) * kDcGroup - 1);
+      const int i = qc / kDcGroup, k = qc - i * kDcGroup, ri = i - 1;
+      row[m] = (T *) ((uint8_t *) job.data + (size_t) min (max (band0 + ri, 0), job.h - 1) * job.stride);
+      pbase[m] = (i == 0 ? 0 : -ri) + k;
+      kpos[m] = k;
+      const int at = i * kDcPitch + k;
+      lslot[m] = q < (rows + 1) * kDcGroup ? (i == 0 ? -2 - at : at) : -1;  // -2 - at: fill only
+    }
+  }
+  __device__ __forceinline__ void load_window (int S0, u32x4 * regs) const
+  {
+#pragma unroll
+    for (int m = 0; m < kDcShare; m++)
+      regs[m] = gload < u32x4 > (row[m] + (size_t) min (max (pbase[m] + S0, 0), npieces - 1) * E);
+  }
+  // window of the group that started at S0 out to memory, the next group's (regs) in
+  __device__ __forceinline__ void turn_window (u32x4 * slot, int S0, const u32x4 * regs, bool flush) const
+  {
+#pragma unroll
+    for (int m = 0; m < kDcShare; m++) {
+      const int q = lslot[m];
+      if (q == -1)
+        continue;
+      const int p = pbase[m] + S0;
+      // (the slots that a step of this group worked on)
+      if (flush && q >= 0 && p >= 0 && p < npieces && S0 + kpos[m] < steps) {
+        const u32x4 v = slot[q];
+        T *to = row[m] + (size_t) p * E;
+        const int n = w - p * E;
+        if (n >= E)
+          gstore < u32x4 > (to, v);
+        else
+          store_some < T > (to, v, n);  // the band's row ends inside this piece
+      }
+    }
+    lds_barrier ();             // every slot read before it is refilled
+#pragma unroll
+    for (int m = 0; m < kDcShare; m++) {
+      const int q = lslot[m];
+      if (q != -1)
+        slot[q >= 0 ? q : -2 - q] = regs[m];
+    }
+    lds_barrier ();
+  }
+};
+
+template < typename T, int k = 0 >
+__device__ __forceinline__ void
+dc_group_steps (const DcBand < T > &b, int j, int S0, u32x4 * slot, u32x4 (*xv)[kDcRows], DcRow & st)
+{
+  if constexpr (k < kDcGroup) {
+    const int S = S0 + k;
+    if (S < b.steps) {          // uniform
+      const int p = S - b.r;
+      if (b.r < b.rows && p >= 0 && p < b.npieces) {
+        u32x4 *mine = slot + (b.r + 1) * kDcPitch + k;
+        u32x4 up = { 0, 0, 0, 0 }, out = { 0, 0, 0, 0 };
+        if (j > 0)
+          up = b.r == 0 ? slot[k] : xv[(S + 1) & 1][b.r - 1];
+        dc_piece < T > (*mine, up, out, st, j == 0, p == 0);
+        *mine = out;
+        xv[S & 1][b.r] = out;
+      }
+      lds_barrier ();
+    }
+    dc_group_steps < T, k + 1 > (b, j, S0, slot, xv, st);
+  }
+}
+
 template < typename T >
 __global__ __launch_bounds__ (kDcRows)
 void dc_predict_kernel (const DcJob * __restrict__ jobs)
 {
-  __shared__ int32_t xchg[2][kDcRows];
+  __shared__ u32x4 slot[(kDcRows + 1) * kDcPitch];
+  __shared__ u32x4 xv[2][kDcRows];
+  constexpr int E = 16 / (int) sizeof (T);
   const DcJob job = jobs[blockIdx.x];
   const int r = threadIdx.x, R = blockDim.x;
   const int w = job.w, h = job.h;
+  if ((((uintptr_t) job.data | (uintptr_t) job.stride) & 15) == 0) {
+    // (a stride that is a multiple of 16 also means whole pieces can be read at a row's end)
+    for (int band0 = 0; band0 < h; band0 += R) {
+      DcBand < T > b;
+      b.w = w;
+      b.rows = min (R, h - band0);
+      b.npieces = (w + E - 1) / E;
+      b.steps = b.npieces + b.rows - 1;
+      b.r = r;
+      b.setup (job, band0, R);
+      const int j = band0 + r;
+      DcRow st = { 0, 0 };
+      u32x4 regs[kDcShare];
+      b.load_window (0, regs);
+      b.turn_window (slot, 0, regs, false);
+      for (int S0 = 0; S0 < b.steps; S0 += kDcGroup) {
+        b.load_window (S0 + kDcGroup, regs);
+        dc_group_steps < T > (b, j, S0, slot, xv, st);
+        b.turn_window (slot, S0, regs, true);
+      }
+      __syncthreads ();         // the band's rows are in memory before the next band reads its last one
+    }
+    return;
+  }
+  // ---- planes that are not 16-byte aligned: sample by sample -------------------------------
+  int32_t (*xchg)[kDcRows] = reinterpret_cast < int32_t (*)[kDcRows] > (&xv[0][0]);
   for (int band0 = 0; band0 < h; band0 += R) {
     const int j = band0 + r;
     const bool have_row = j < h;
@@ -368,7 +572,7 @@ void dc_predict_kernel (const DcJob * __restrict__ jobs)
       }
       __syncthreads ();
     }
-    __syncthreads ();           // rows of this band are in memory before the next reads them
+    __syncthreads ();
   }
 }
 

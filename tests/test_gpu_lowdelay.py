@@ -151,6 +151,37 @@ def test_dc_predict_alone(ctx, dtype):
         p.free()
 
 
+def test_intra_picture_through_the_frame_layer(ctx):
+    # a low-delay picture the way a patched schrodecoder.c would run it: compressed slices ->
+    # transform frame on the device (schro_decoder_decode_lowdelay_transform_data), inverse
+    # wavelet in place of x_wavelet_transform, u8 picture (schrodecoder.c:1788-1790)
+    import ctypes as C
+    from schroedinger_amd import frames
+    w, h, depth, filt = 160, 96, 3, 1
+    P = synth.lowdelay_params(w, h, (1, 0), depth, 16, 16, 400)
+    for bpp, fmt in ((2, sa.FORMAT_S16_422), (4, sa.FORMAT_S32_422)):
+        dt = np.int16 if bpp == 2 else np.int32
+        q = synth.quantised_planes(P, seed=12 + bpp, scale=1.1)
+        data = O.lowdelay_write(q, P, bpp, synth.lowdelay_base_index(P, seed=3, lo=0, hi=20))
+        tf = frames.DeviceFrame(ctx, fmt, P["iwt_luma_width"], P["iwt_luma_height"])
+        sa.check(ctx.lib.schro_hip_decode_lowdelay_transform_data(
+            tf.ptr(), data.ctypes.data_as(C.c_void_p), data.size, C.byref(ctx.lowdelay_params(P))))
+        coeffs = decode_cpu(data, P, bpp)
+        got = tf.download()
+        for k in range(3):
+            assert np.array_equal(got[k], coeffs[k]), (bpp, k)
+        params = frames.make_params(wavelet_filter_index=filt, transform_depth=depth,
+                                    iwt_luma_width=P["iwt_luma_width"], iwt_luma_height=P["iwt_luma_height"],
+                                    iwt_chroma_width=P["iwt_chroma_width"], iwt_chroma_height=P["iwt_chroma_height"])
+        frame = frames.DeviceFrame(ctx, fmt, P["iwt_luma_width"], P["iwt_luma_height"])
+        sa.check(ctx.lib.schro_frame_inverse_iwt_transform_hip(frame.ptr(), tf.ptr(), C.byref(params)))
+        pix = frame.download()
+        for k in range(3):
+            assert np.array_equal(pix[k], O.inverse_iwt(coeffs[k].astype(dt), depth, filt)), (bpp, k)
+        frame.unref()
+        tf.unref()
+
+
 def test_bad_arguments_are_refused(ctx):
     P = synth.lowdelay_params(64, 32, (1, 1), 2, 16, 8, 100)
     data = np.zeros(O.lowdelay_slice_bytes(P), np.uint8)
