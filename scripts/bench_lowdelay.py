@@ -5,13 +5,15 @@ inverse wavelet per picture with the library's own HIP events, checks the coeffi
 planes against the CPU oracle and times the oracle on the host for the same picture.
 Prints one JSON line.  (bench.py measures the metric of record, config 4.)"""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402  (checker + CPU number only)
 import schroedinger_amd as sa  # noqa: E402
 import synth  # noqa: E402
