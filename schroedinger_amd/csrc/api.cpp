@@ -178,6 +178,7 @@ schro_hip_context_new (int device)
   ctx->scratch_size = 0;
   ctx->arg_clock = 0;
   memset (ctx->arg_slots, 0, sizeof (ctx->arg_slots));
+  memset (ctx->order_slots, 0, sizeof (ctx->order_slots));
   ctx->profile = false;
   ctx->ev_used = 0;
   ctx->h_args = nullptr;
@@ -210,6 +211,9 @@ schro_hip_context_free (SchroHipContext * ctx)
     (void) hipFree (s.ptr);
   if (ctx->scratch)
     (void) hipFree (ctx->scratch);
+  for (int k = 0; k < SchroHipContext::kOrderSlots; k++)
+    if (ctx->order_slots[k].d)
+      (void) hipFree (ctx->order_slots[k].d);
   for (int k = 0; k < SchroHipContext::kArgSlots; k++)
     if (ctx->arg_slots[k].copied)
       (void) hipEventDestroy (ctx->arg_slots[k].copied);
@@ -899,6 +903,89 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
   return launch_upsample (ctx->stream, (const UpsampleJob *) d_jobs, nplanes, tile_base);
 }
 
+// The order in which an OBMC launch walks its tiles.  Workgroups go to the 8 XCDs round
+// robin and xcd_tile_id () gives every XCD one contiguous run of positions; with the plain
+// plane-by-plane list such a run is about one picture of a batch, so every XCD pulls BOTH
+// reference images of every picture through its own 4 MiB L2 -- for the 8 pictures between
+// two anchors, which share their references, 8 times the same 100 MB.  Here position v of the
+// order holds tile (job << 16 | tile): sorted by the tile's vertical position in its plane,
+// then by reference, so an XCD's run is a horizontal stripe of ALL the pictures and the tiles
+// that read the same reference rows follow each other.  Built on the host, kept on the
+// device, found again by a hash of the geometry and references of the launch.
+static int
+obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int variant, int total,
+    const uint32_t ** d_order)
+{
+  *d_order = nullptr;
+  static const bool enabled = !getenv ("SCHRO_HIP_OBMC_ORDER") || atoi (getenv ("SCHRO_HIP_OBMC_ORDER")) != 0;
+  if (!enabled || variant != 1 || jobs.size () < 2 || jobs.size () > 0xffff)
+    return 0;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h] (uint64_t v) {
+    for (int k = 0; k < 8; k++) {
+      h ^= (v >> (8 * k)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  std::vector < int >tiles_y (jobs.size ());
+  for (size_t j = 0; j < jobs.size (); j++) {
+    int tx;
+    obmc_tiles (variant, jobs[j].w, jobs[j].h, jobs[j].xoff, &tx, &tiles_y[j]);
+    if (tx * tiles_y[j] > 0xffff)
+      return 0;
+    mix ((uint64_t) tx);
+    mix ((uint64_t) tiles_y[j]);
+    mix ((uint64_t) (uintptr_t) jobs[j].ref[0]);
+  }
+  SchroHipContext::OrderSlot * slot = nullptr, *lru = &ctx->order_slots[0];
+  for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
+    SchroHipContext::OrderSlot & o = ctx->order_slots[k];
+    if (o.d && o.hash == h && o.count == (size_t) total)
+      slot = &o;
+    if (o.last_use < lru->last_use)
+      lru = &o;
+  }
+  if (!slot) {
+    struct Key {
+      uint32_t row;             // vertical position, 1/64 of the plane
+      uintptr_t ref;
+      uint32_t entry;
+    };
+    std::vector < Key > keys;
+    keys.reserve ((size_t) total);
+    for (size_t j = 0; j < jobs.size (); j++)
+      for (int ty = 0; ty < tiles_y[j]; ty++)
+        for (int tx = 0; tx < jobs[j].tiles_x; tx++)
+          keys.push_back (Key { (uint32_t) (ty * 64 / tiles_y[j]), (uintptr_t) jobs[j].ref[0],
+              (uint32_t) (j << 16) | (uint32_t) (ty * jobs[j].tiles_x + tx) });
+    if (keys.size () != (size_t) total)
+      return set_error (SCHRO_HIP_EINVAL, "obmc tile order: %zu tiles, %d expected", keys.size (), total);
+    std::stable_sort (keys.begin (), keys.end (),[](const Key & a, const Key & b) {
+          return a.row != b.row ? a.row < b.row : a.ref < b.ref;
+        });
+    std::vector < uint32_t > table (keys.size ());
+    for (size_t k = 0; k < keys.size (); k++)
+      table[k] = keys[k].entry;
+    // the slot's old table may still be read by a launch in flight
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+    slot = lru;
+    if (slot->cap < table.size ()) {
+      if (slot->d)
+        SCHRO_HIP_CHECK (hipFree (slot->d));
+      slot->d = nullptr;
+      slot->cap = 0;
+      SCHRO_HIP_CHECK (hipMalloc ((void **) &slot->d, table.size () * sizeof (uint32_t)));
+      slot->cap = table.size ();
+    }
+    SCHRO_HIP_CHECK (hipMemcpy (slot->d, table.data (), table.size () * sizeof (uint32_t), hipMemcpyHostToDevice));
+    slot->hash = h;
+    slot->count = table.size ();
+  }
+  slot->last_use = ++ctx->arg_clock;
+  *d_order = slot->d;
+  return 0;
+}
+
 int
 schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, int nplanes)
 {
@@ -986,10 +1073,14 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     int r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
     if (r)
       return r;
+    const uint32_t *d_order;
+    r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order);
+    if (r)
+      return r;
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
       r = launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec,
-          variant);
+          variant, d_order);
     }
     if (r)
       return r;

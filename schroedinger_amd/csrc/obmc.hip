@@ -673,7 +673,7 @@ item_class (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, c
 
 template < int PC >
 __global__ __launch_bounds__ (kThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
-void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
+void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   __shared__ __attribute__ ((aligned (16))) int acc[(kFTH / 2) * kAccStride];   // rows y and y + 16 per word
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
@@ -686,8 +686,11 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   __shared__ __attribute__ ((aligned (16))) uint8_t s_stage[PC == 0 ? 1 : kThreads / 64][PC == 0 ? 16 : kItemStage];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  const ObmcJob job = jobs[find_job (jobs, njobs, bid)];
-  const int t = bid - job.tile_base;
+  // which tile: position bid of the host's tile order (obmc_tile_order: the same rows of all
+  // pictures that share references side by side), or of the plain plane-by-plane list
+  const uint32_t entry = order ? __builtin_amdgcn_readfirstlane (gload < uint32_t > (order + bid)) : 0u;
+  const ObmcJob job = jobs[order ? (int) (entry >> 16) : find_job (jobs, njobs, bid)];
+  const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
   const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x_lo = tx * kFTW, y_lo = ty * kFTH;
@@ -929,11 +932,12 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs)
 
 template < int PC >
 int
-launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant)
+launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant,
+    const uint32_t * d_order)
 {
   if (variant == 1)
     hipLaunchKernelGGL ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), 0, stream,
-        d_jobs, njobs);
+        d_jobs, njobs, d_order);
   else
     hipLaunchKernelGGL ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,
         stream, d_jobs, njobs);
@@ -986,12 +990,12 @@ obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 
 int
 launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec,
-    int variant)
+    int variant, const uint32_t * d_order)
 {
   switch (prec == 0 ? 0 : (prec == 1 ? 1 : 2)) {
-    case 0: return launch_one < 0 > (stream, d_jobs, njobs, total_tiles, variant);
-    case 1: return launch_one < 1 > (stream, d_jobs, njobs, total_tiles, variant);
-    default: return launch_one < 2 > (stream, d_jobs, njobs, total_tiles, variant);
+    case 0: return launch_one < 0 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
+    case 1: return launch_one < 1 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
+    default: return launch_one < 2 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
   }
 }
 

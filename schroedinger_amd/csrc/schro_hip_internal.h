@@ -263,7 +263,7 @@ int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const
     int bpp, int arith);
 int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
-    int total_tiles, int prec, int variant);
+    int total_tiles, int prec, int variant, const uint32_t * d_order);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
@@ -313,6 +313,17 @@ struct SchroHipContext {
   };
   std::vector < EvPair > ev_pool;
   size_t ev_used;
+
+  // OBMC tile orders (api.cpp obmc_tile_order): device tables of job << 16 | tile, cached by
+  // the geometry and references of the launch they were built for
+  struct OrderSlot {
+    uint64_t hash;
+    uint32_t *d;
+    size_t cap, count;
+    uint64_t last_use;
+  };
+  static constexpr int kOrderSlots = 8;
+  OrderSlot order_slots[kOrderSlots];
 
   // grow-only scratch for intermediate LL bands
   void *scratch;
