@@ -1,0 +1,61 @@
+"""GPU parity on a real stream (BASELINE config 2): the reference's testsuite/test_stream.drc.
+Coefficients and motion vectors of its first pictures (tests/golden/stream_pictures.npz, decoded
+from the stream by oracle/dirac_stream.py) go through the HIP path -- inverse wavelet, intra
+convert, OBMC from the pictures the GPU itself decoded before -- and every picture must equal
+the oracle's, whose first three frames are bit-identical to the reference decoder's
+(schro_frame_md5 recorded in SURVEY.md 8(c)); the digests of the GPU's frames are checked too."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import schroedinger_amd as sa
+import stream_lib as S
+
+sys.path.insert(0, os.path.join(S.ROOT, "oracle"))
+import dirac_stream as D  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stream_pictures_through_the_gpu(ctx):
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    md5 = json.load(open(os.path.join(S.GOLDEN, "stream_md5.json")))
+    decoded = {}                                         # picture number -> device u8 planes
+    digests = {}
+    for n in range(8):
+        tag = "p%d_" % n
+        number, num_refs, is_ref, zero_residual = [int(v) for v in z[tag + "number"][:4]]
+        refs = [int(v) for v in z[tag + "number"][4:]]
+        assert not zero_residual
+        depth, wavelet = [int(v) for v in z[tag + "transform"]]
+        want = [z[tag + "out%d" % k] for k in range(3)]
+        co = [ctx.upload(z[tag + "coeff%d" % k]) for k in range(3)]
+        res = [ctx.plane(c.height, c.width, np.int16) for c in co]
+        ctx.iiwt_batch(list(zip(co, res)), depth, wavelet)
+        out = [ctx.plane(w.shape[0], w.shape[1], np.uint8).fill(0x11) for w in want]
+        if num_refs == 0:
+            ctx.convert_u8_batch(list(zip(res, out)))
+        else:
+            P = dict(zip(S.PARAM_KEYS, [int(v) for v in z[tag + "params"]]))
+            assert P["mv_precision"] == 0                # the stream is full-pel
+            d_mv = ctx.upload_bytes(z[tag + "mv"])
+            jobs = []
+            for k in range(3):
+                r1 = decoded[refs[0]][k]
+                r2 = decoded[refs[1]][k] if num_refs > 1 else r1
+                jobs.append(sa.obmc_plane(d_mv, P, k, r1, r2, res[k], out[k]))
+            ctx.obmc_batch(jobs)
+        got = [o.download() for o in out]
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), "coded picture %d (number %d) component %d" % (n, number, k)
+        digests[number] = D.frame_md5(got)
+        decoded[number] = out                            # later pictures predict from the GPU's own output
+        for p in co + res:
+            p.free()
+    # the GPU's frames 0, 1, 2 carry the reference decoder's digests
+    assert [digests[k] for k in (0, 1, 2)] == md5["reference"]
+    for number, d in digests.items():
+        assert d == md5["oracle"][number]
