@@ -21,12 +21,20 @@
  *     schedule (oracle/ref_driver.c) and by the reference's own test design
  *     (testsuite/wavelet_2d.c: forward->inverse perfect reconstruction and a
  *     scalar column-then-row model built on testsuite/common.c synth());
- *   - the reference holds NO golden vectors / known-answer data for this
- *     path, and the full reference library cannot be built
- *     here without writing stand-ins for liborc, so OBMC composition is
- *     "parity unpinned by reference output": it is cross-checked by two
- *     independent formulations only (block scatter here vs per-pixel gather
- *     in tests/ and on the GPU).
+ *   - END TO END, BY REFERENCE OUTPUT: the reference's own testsuite/test_stream.drc
+ *     (committed as tests/golden/test_stream.drc) decoded with oracle/dirac_stream.py
+ *     (bitstream front end, test infrastructure like everything here) + this library
+ *     gives, for the first three output frames -- an intra picture (DD(9,7), depth 4) and
+ *     two B pictures (LeGall(5,3) residual, 12x12/8x8 OBMC from an intra and a P
+ *     picture, full-pel, 4:2:2) -- exactly the schro_frame_md5 digests the reference
+ *     decoder produced for that stream (tests/test_oracle_stream.py).
+ *     That pins the COMPOSITION of inverse wavelet, block prediction from one and two
+ *     references, OBMC weighting, residual add and clamp for that configuration;
+ *   - not covered by that stream, hence still pinned only kernel-by-kernel and by two
+ *     independent formulations: sub-pel vectors (the half-pel upsample and the
+ *     quarter / eighth-pel blend), non-default reference weights, 4:2:0 / 4:4:4,
+ *     filters 2-6, s32; the full reference library cannot be built here without
+ *     writing stand-ins for liborc, and the reference holds no other known answers.
  */
 #ifndef SCHRO_ORACLE_H
 #define SCHRO_ORACLE_H

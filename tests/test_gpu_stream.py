@@ -59,3 +59,41 @@ def test_stream_pictures_through_the_gpu(ctx):
     assert [digests[k] for k in (0, 1, 2)] == md5["reference"]
     for number, d in digests.items():
         assert d == md5["oracle"][number]
+
+
+def test_whole_stream_through_the_gpu(ctx):
+    # all 100 pictures (4 intra-started chains, P and B pictures): bitstream decoded by the oracle's
+    # front end, every pixel stage on the GPU, references = the GPU's own earlier output
+    md5 = json.load(open(os.path.join(S.GOLDEN, "stream_md5.json")))["oracle"]
+    decoded, count = {}, 0
+    for rec in S.decode_stream(S.load_stream(), S.load_tables()):
+        number, refs = rec["number"], rec["refs"]
+        want = rec["out"]
+        out = [ctx.plane(w.shape[0], w.shape[1], np.uint8).fill(0x11) for w in want]
+        if rec["zero_residual"]:
+            res = [ctx.upload(np.zeros(w.shape, np.int16)) for w in want]
+            co = []
+        else:
+            co = [ctx.upload(c) for c in rec["coeffs"]]
+            res = [ctx.plane(c.height, c.width, np.int16) for c in co]
+            ctx.iiwt_batch(list(zip(co, res)), rec["depth"], rec["wavelet"])
+        if rec["num_refs"] == 0:
+            ctx.convert_u8_batch(list(zip(res, out)))
+        else:
+            d_mv = ctx.upload_bytes(rec["mv"])
+            jobs = [sa.obmc_plane(d_mv, rec["params"], k, decoded[refs[0]][k],
+                                  decoded[refs[1] if len(refs) > 1 else refs[0]][k], res[k], out[k]) for k in range(3)]
+            ctx.obmc_batch(jobs)
+        got = [o.download() for o in out]
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), "picture %d component %d" % (number, k)
+        assert D.frame_md5(got) == md5[number]
+        for p in co + res:
+            p.free()
+        if rec["is_ref"]:
+            decoded[number] = out
+        else:
+            for p in out:
+                p.free()
+        count += 1
+    assert count == 100
