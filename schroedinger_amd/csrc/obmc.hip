@@ -344,7 +344,7 @@ acc_add_wrap (int *word, int high, int value)
 template < int PC >
 __device__ __forceinline__ void
 obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const TileCtx & tc,
-    const int *s_wx, const int *s_wy, int *acc)
+    const int *s_wx, const int *s_wy, int *acc, bool exact)
 {
   const int prec = job.prec;
   const int y = bi.by + row, xs = bi.bx + 4 * seg;
@@ -357,9 +357,37 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
     for (int r = 0; r < 2; r++) {
       if (!(mode & (r + 1)))
         continue;
-      for (int e = 0; e < 4; e++)
-        val[r][e] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h,
-            bi.fx[r] + (4 * seg + e) * (1 << prec), bi.fy[r] + row * (1 << prec), prec);
+      if constexpr (PC == 2) {
+        // the four pixels are 8 eighth-pels apart: they share the blend weights and read nine
+        // adjacent half-pel columns of two rows (each clamped on its own, as fetch_ref does)
+        const int sx = bi.fx[r] + 4 * seg * (1 << prec), sy = bi.fy[r] + row * (1 << prec);
+        const int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
+        const int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
+        const uint8_t *rows[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int Y = clampi (hy + k, 0, 2 * job.h - 2);
+          rows[k] = job.ref[r] + (size_t) (Y >> 3) * 8 * (size_t) job.ref_stride[r] + (size_t) ((Y & 7) * 16);
+        }
+        int p[2][9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const int X = clampi (hx + j, 0, 2 * job.w - 2);
+          const int col = (X >> 4) * 128 + (X & 15);
+          p[0][j] = gload < uint8_t > (rows[0] + col);
+          p[1][j] = gload < uint8_t > (rows[1] + col);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int v = (4 - ry) * ((4 - rx) * p[0][2 * e] + rx * p[0][2 * e + 1])
+              + ry * ((4 - rx) * p[1][2 * e] + rx * p[1][2 * e + 1]);
+          val[r][e] = (v + 8) >> 4;
+        }
+      } else {
+        for (int e = 0; e < 4; e++)
+          val[r][e] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h,
+              bi.fx[r] + (4 * seg + e) * (1 << prec), bi.fy[r] + row * (1 << prec), prec);
+      }
     }
     for (int e = 0; e < 4; e++)
       pred[e] = mode == 3 ? (val[0][e] + val[1][e] + 1) >> 1 : (mode == 1 ? val[0][e] : val[1][e]);
@@ -380,7 +408,11 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
       wx += s_wx[2 * job.xoff - idx - 1];
     if (x >= tc.xfold_hi)
       wx += s_wx[2 * (job.xblen - job.xoff) - idx - 1];
-    acc_add_wrap (arow + x, yrel & (kFTH / 2), pred[e] * wx * wy);
+    // plain add into the row's half of the word unless some sum of the tile may wrap (see the kernel)
+    if (exact)
+      acc_add_wrap (arow + x, yrel & (kFTH / 2), pred[e] * wx * wy);
+    else
+      atomicAdd (arow + x, (pred[e] * wx * wy) << (yrel & (kFTH / 2)));
   }
 }
 
@@ -839,6 +871,17 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
       if (wide_dc)
         s_wide = 1;
       key = (clamped || fold || wide_dc || yblen * nseg > kItemWCap) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
+      if (key == 4) {
+        // the rim path works from the clamped fetch origins (it has no use for the window
+        // offsets and blend weights): keep them, so that it need not read the vectors again
+        int fx, fy;
+        mv_origin (job, bx, by, v01, v23, 0, &fx, &fy);
+        info.off[0] = fx;
+        info.off[1] = fy;
+        mv_origin (job, bx, by, v01, v23, 1, &fx, &fy);
+        info.wpk[0] = (uint32_t) fx;
+        info.wpk[1] = (uint32_t) fy;
+      }
       rank = atomicAdd (&s_cnt[key], 1);
     }
     __syncthreads ();
@@ -915,14 +958,11 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
         bi.mode_dc = hb.mode_dc;
-        {
-          const int i = fdiv (bi.bx + xoff, xbsep), jj = fdiv (bi.by + yoff, ybsep);
-          const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
-          const uint32_t v01 = gload < uint32_t > (mvp + 12), v23 = gload < uint32_t > (mvp + 16);
-          mv_origin (job, bi.bx, bi.by, v01, v23, 0, &bi.fx[0], &bi.fy[0]);
-          mv_origin (job, bi.bx, bi.by, v01, v23, 1, &bi.fx[1], &bi.fy[1]);
-        }
-        obmc_item_slow < PC > (job, bi, r2, s2, tc, s_wx, s_wy, acc);
+        bi.fx[0] = hb.off[0];   // (kept by the decode for rim blocks)
+        bi.fy[0] = hb.off[1];
+        bi.fx[1] = (int) hb.wpk[0];
+        bi.fy[1] = (int) hb.wpk[1];
+        obmc_item_slow < PC > (job, bi, r2, s2, tc, s_wx, s_wy, acc, exact);
       }
     }
   }
