@@ -945,11 +945,12 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
     // ---- picture-rim blocks: exact clamp / fold path -----------------------------
     {
       const int per_block = yblen * nseg;
+      const uint32_t m_per_block = div_magic (per_block);     // (uniform: once per workgroup)
       const int nslow = cbase[5] - cbase[4];
       for (int item = tid; item < nslow * per_block; item += kThreads) {
-        const int b = fdiv (item, per_block);
+        const int b = mdiv (item, per_block, m_per_block);
         const int rem = item - b * per_block;
-        const int r2 = fdiv (rem, nseg), s2 = rem - r2 * nseg;
+        const int r2 = mdiv (rem, nseg, job.m_nseg), s2 = rem - r2 * nseg;
         const HotBlk & hb = s_hot[cbase[4] + b];
         BlkInfo bi;
         bi.bx = hb.x + x_lo;
