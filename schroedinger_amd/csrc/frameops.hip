@@ -197,51 +197,62 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   }
   __syncthreads ();
 
-  const int g = tid % (kUpTW / 4);      // pixel group: pixels x0 + 4g .. +3 (LDS dword g + 1)
-  const int gx = x0 + 4 * g;
-  if (gx >= w)
+  // Phase 3: horizontal half-pel samples, interleave, store.  One lane = 8 pixels of one row =
+  // one 16-byte tile row of HP row 2y and the one of row 2y + 1 right behind it (32 contiguous
+  // bytes); the lanes of four neighbouring rows are neighbours, so four lanes write one whole
+  // 128-byte line (rows 2y .. 2y+7 of a tile) instead of eight lanes writing 8-byte pieces
+  // of sixteen.
+  static_assert (kThreads == (kUpTW / 8) * kUpTH, "one lane per 8 pixels of the tile");
+  const int ly = (tid & 3) | ((tid >> 6) << 2), g8 = (tid >> 2) & (kUpTW / 8 - 1);
+  const int gx = x0 + 8 * g8, gy = y0 + ly;
+  if (gx >= w || gy >= h)
     return;
+  const int gd = 2 * g8;                // LDS dword of the 4 pixels left of this lane's
+  uint32_t c0[2], c2[2], d1[2], d3[2];
+  {
+    const uint32_t a0 = s0[ly + 3][gd], a1 = s0[ly + 3][gd + 1], a2 = s0[ly + 3][gd + 2], a3 = s0[ly + 3][gd + 3];
+    const uint32_t b0 = s2[ly][gd], b1 = s2[ly][gd + 1], b2 = s2[ly][gd + 2], b3 = s2[ly][gd + 3];
+    int p1[8], p3[8];
+    mas8_row4 (a0, a1, a2, p1);
+    mas8_row4 (a1, a2, a3, p1 + 4);
+    mas8_row4 (b0, b1, b2, p3);
+    mas8_row4 (b1, b2, b3, p3 + 4);
+    c0[0] = a1;
+    c0[1] = a2;
+    c2[0] = b1;
+    c2[1] = b2;
 #pragma unroll
-  for (int half = 0; half < kUpTH / 8; half++) {
-    const int ly = tid / (kUpTW / 4) + 8 * half;
-    const int gy = y0 + ly;
-    if (gy >= h)
-      continue;
-    const uint32_t c0 = s0[ly + 3][g + 1], c2 = s2[ly][g + 1];
-    int p1[4], p3[4];
-    mas8_row4 (s0[ly + 3][g], c0, s0[ly + 3][g + 2], p1);
-    mas8_row4 (s2[ly][g], c2, s2[ly][g + 2], p3);
-    uint32_t d1 = 0, d3 = 0;
+    for (int half = 0; half < 2; half++) {
+      d1[half] = d3[half] = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
-      // schro_frame_mc_edgeextend_horiz overwrites it the same way)
-      const bool lastcol = gx + e >= w - 1;
-      int v1 = lastcol ? (int) ((c0 >> (8 * e)) & 0xff) : p1[e];
-      int v3 = lastcol ? (int) ((c2 >> (8 * e)) & 0xff) : p3[e];
-      if (gy >= h - 1)
-        v3 = v1;                // last row of the hv-half comes from the h-half (schroframe.c:2028)
-      d1 |= (uint32_t) v1 << (8 * e);
-      d3 |= (uint32_t) v3 << (8 * e);
-    }
-    // interleave: even HP row = (integer, h-half) pairs, odd row = (v-half, hv-half)
-    const uint2 even = make_uint2 (__builtin_amdgcn_perm (d1, c0, 0x05010400u),
-        __builtin_amdgcn_perm (d1, c0, 0x07030602u));
-    const uint2 odd = make_uint2 (__builtin_amdgcn_perm (d3, c2, 0x05010400u),
-        __builtin_amdgcn_perm (d3, c2, 0x07030602u));
-    // tiled 16x8 (include/schro_hip.h): rows 2gy and 2gy+1 are in the same tile, 2gx is a
-    // multiple of 8, so each 8-byte piece stays inside one 16-byte tile row
-    uint8_t *de = job.dst + hp_offset (2 * gx, 2 * gy, job.dst_stride);
-    uint8_t *dod = de + 16;
-    if (gx + 4 <= w && (((uintptr_t) de | (uintptr_t) dod) & 7) == 0) {
-      gstore < u32x2 > (de, (u32x2) { even.x, even.y });
-      gstore < u32x2 > (dod, (u32x2) { odd.x, odd.y });
-    } else {
-      const uint64_t ev = even.x | ((uint64_t) even.y << 32), ov = odd.x | ((uint64_t) odd.y << 32);
-      for (int e = 0; e < 8 && gx + e / 2 < w; e++) {
-        gstore < uint8_t > (de + e, (uint8_t) (ev >> (8 * e)));
-        gstore < uint8_t > (dod + e, (uint8_t) (ov >> (8 * e)));
+      for (int e = 0; e < 4; e++) {
+        // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
+        // schro_frame_mc_edgeextend_horiz overwrites it the same way)
+        const bool lastcol = gx + 4 * half + e >= w - 1;
+        int v1 = lastcol ? (int) ((c0[half] >> (8 * e)) & 0xff) : p1[4 * half + e];
+        int v3 = lastcol ? (int) ((c2[half] >> (8 * e)) & 0xff) : p3[4 * half + e];
+        if (gy >= h - 1)
+          v3 = v1;              // last row of the hv-half comes from the h-half (schroframe.c:2028)
+        d1[half] |= (uint32_t) v1 << (8 * e);
+        d3[half] |= (uint32_t) v3 << (8 * e);
       }
+    }
+  }
+  // interleave: even HP row = (integer, h-half) pairs, odd row = (v-half, hv-half)
+  const u32x4 even = { __builtin_amdgcn_perm (d1[0], c0[0], 0x05010400u), __builtin_amdgcn_perm (d1[0], c0[0], 0x07030602u),
+    __builtin_amdgcn_perm (d1[1], c0[1], 0x05010400u), __builtin_amdgcn_perm (d1[1], c0[1], 0x07030602u) };
+  const u32x4 odd = { __builtin_amdgcn_perm (d3[0], c2[0], 0x05010400u), __builtin_amdgcn_perm (d3[0], c2[0], 0x07030602u),
+    __builtin_amdgcn_perm (d3[1], c2[1], 0x05010400u), __builtin_amdgcn_perm (d3[1], c2[1], 0x07030602u) };
+  // tiled 16x8 (include/schro_hip.h): 2 gx is a multiple of 16 -- one tile row --, rows 2 gy
+  // and 2 gy + 1 are in the same tile, 16 bytes apart
+  uint8_t *de = job.dst + hp_offset (2 * gx, 2 * gy, job.dst_stride);
+  if (gx + 8 <= w && (((uintptr_t) de) & 15) == 0) {
+    gstore < u32x4 > (de, even);
+    gstore < u32x4 > (de + 16, odd);
+  } else {
+    for (int e = 0; e < 16 && gx + e / 2 < w; e++) {
+      gstore < uint8_t > (de + e, (uint8_t) (even[e >> 2] >> (8 * (e & 3))));
+      gstore < uint8_t > (de + 16 + e, (uint8_t) (odd[e >> 2] >> (8 * (e & 3))));
     }
   }
 }
