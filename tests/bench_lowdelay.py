@@ -3,7 +3,8 @@
 s32 coefficients, 3-level Haar (no shift).  Times slice decode, DC prediction and the
 inverse wavelet per picture with the library's own HIP events, checks the coefficient
 planes against the CPU oracle and times the oracle on the host for the same picture.
-Prints one JSON line.  (bench.py measures the metric of record, config 4.)"""
+Prints one JSON line.  (bench.py measures the metric of record, config 4.)  Lives under tests/
+because it needs the oracle as input generator and checker: `python3 tests/bench_lowdelay.py`."""
 import json
 import os
 import sys
@@ -13,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # (this directory)
 import oracle_lib as O  # noqa: E402  (checker + CPU number only)
 import schroedinger_amd as sa  # noqa: E402
 import synth  # noqa: E402
