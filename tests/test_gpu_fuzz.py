@@ -3,6 +3,8 @@ sets, precisions, weights and slice layouts inside what the reference accepts, e
 bit for bit with the CPU oracle.  The hand-picked cases of the other test files follow the
 reference's own test design; these look for what nobody thought of (tile edges, odd strides,
 planes narrower than a tile, batches of unlike planes in one launch)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,10 +16,15 @@ from test_gpu_obmc import run_case
 
 pytestmark = pytest.mark.gpu
 
+# SCHRO_FUZZ_SCALE multiplies the number of draws, SCHRO_FUZZ_SEED shifts the seeds (a long campaign
+# is `SCHRO_FUZZ_SCALE=50 SCHRO_FUZZ_SEED=7 pytest tests/test_gpu_fuzz.py -m gpu`)
+SCALE = int(os.environ.get("SCHRO_FUZZ_SCALE", "1"))
+SEED = int(os.environ.get("SCHRO_FUZZ_SEED", "0"))
+
 
 def test_iiwt_random_batches(ctx):
-    rng = np.random.default_rng(101)
-    for rnd in range(150):
+    rng = np.random.default_rng(101 + SEED)
+    for rnd in range(150 * SCALE):
         filt = int(rng.integers(0, 7))
         depth = int(rng.integers(1, 5))
         dtype = [np.int16, np.int32][int(rng.integers(0, 2))]
@@ -47,8 +54,8 @@ def test_iiwt_random_batches(ctx):
 
 
 def test_upsample_and_convert_random(ctx):
-    rng = np.random.default_rng(202)
-    for rnd in range(80):
+    rng = np.random.default_rng(202 + SEED)
+    for rnd in range(80 * SCALE):
         h, w = int(rng.integers(1, 150)), int(rng.integers(1, 400))
         pic = synth.picture_u8(h, w, seed=int(rng.integers(1, 1 << 20)), blur=bool(rng.integers(0, 2)))
         src, dst = ctx.upload(pic), ctx.hp_plane(h, w)
@@ -73,9 +80,9 @@ def test_upsample_and_convert_random(ctx):
 
 
 def test_obmc_random_geometry(ctx):
-    rng = np.random.default_rng(303)
+    rng = np.random.default_rng(303 + SEED)
     seps = [4, 8, 12, 16, 24, 32]
-    for rnd in range(200):
+    for rnd in range(200 * SCALE):
         sep = seps[int(rng.integers(0, len(seps)))]
         blen = sep + 4 * int(rng.integers(0, sep // 4 + 1))
         blen = min(blen, 2 * sep, 64)
@@ -90,8 +97,8 @@ def test_obmc_random_geometry(ctx):
 
 
 def test_lowdelay_random_layouts(ctx):
-    rng = np.random.default_rng(404)
-    for rnd in range(150):
+    rng = np.random.default_rng(404 + SEED)
+    for rnd in range(150 * SCALE):
         depth = int(rng.integers(0, 5))
         unit = 1 << depth
         chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
