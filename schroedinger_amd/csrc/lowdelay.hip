@@ -36,27 +36,47 @@ make_quant_tables ()
 static __device__ const QuantTables kQuant = make_quant_tables ();
 
 // MSB-first bit reader over global memory; bits at or beyond `end` read as 1 (the guard bit
-// of schro_unpack_init_with_data (..., 1), schrolowdelay.c:126).  Three big-endian dwords
-// are held: the third is fetched a whole dword (a dozen codes) before its first bit is
-// needed, so the fetch -- an L2 round trip, 64 lanes read 64 different slices -- overlaps
-// the decode instead of stalling it at every 32-bit boundary.
+// of schro_unpack_init_with_data (..., 1), schrolowdelay.c:126).  The 64 lanes of a wave
+// read 64 different slices, and the coefficients the kernel streams out keep pushing the
+// slice bytes out of L2 (rocprofv3: with a dword fetched per 32 bits the kernel pulled 1.8 GB
+// through FETCH_SIZE for 80 MB of slices): a lane therefore fetches its slice in aligned
+// 16-byte pieces, one piece ahead of the piece it is reading, and hands the dwords out of
+// the two pieces it holds.
 struct BitReader {
-  const uint32_t *words;        // 4-byte aligned
-  uint32_t pos, end;            // bit positions from words[0]
-  uint32_t last;                // index of the last dword that holds a byte of the buffer
-  uint32_t w0, w1, w2, widx;
+  const uint32_t *base;         // 16-byte aligned
+  uint32_t pos, end;            // bit positions from base[0]
+  uint32_t last_piece;          // the piece that holds the last byte of the buffer
+  uint32_t w0, w1, widx;        // big-endian dwords widx and widx + 1
+  u32x4 res, nxt;               // pieces pidx and pidx + 1 as they lie in memory
+  uint32_t pidx;
 
-  __device__ __forceinline__ uint32_t fetch (uint32_t i) const
+  __device__ __forceinline__ u32x4 fetch_piece (uint32_t pi) const
   {
-    return __builtin_bswap32 (gload < uint32_t > (words + min (i, last)));
+    return gload < u32x4 > (base + 4u * min (pi, last_piece));
+  }
+  static __device__ __forceinline__ uint32_t pick (const u32x4 & v, uint32_t k)
+  {
+    return __builtin_bswap32 (k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w);
+  }
+  // dword j, which lies in piece pidx or pidx + 1; moves on to the next piece when it does
+  __device__ __forceinline__ uint32_t take (uint32_t j)
+  {
+    if ((j >> 2) != pidx) {
+      res = nxt;
+      pidx++;
+      nxt = fetch_piece (pidx + 1);
+    }
+    return pick (res, j & 3u);
   }
   __device__ __forceinline__ void start (uint32_t p)
   {
     pos = p;
     widx = p >> 5;
-    w0 = fetch (widx);
-    w1 = fetch (widx + 1);
-    w2 = fetch (widx + 2);
+    pidx = widx >> 2;
+    res = fetch_piece (pidx);
+    nxt = fetch_piece (pidx + 1);
+    w0 = pick (res, widx & 3u);
+    w1 = take (widx + 1);
   }
   __device__ __forceinline__ void skip (uint32_t n)
   {
@@ -70,8 +90,7 @@ struct BitReader {
     const uint32_t wi = pos >> 5;
     if (wi != widx) {           // a code is at most 32 bits here: one dword further
       w0 = w1;
-      w1 = w2;
-      w2 = fetch (wi + 2);
+      w1 = take (wi + 1);
       widx = wi;
     }
     uint32_t v = __funnelshift_l (w1, w0, pos & 31u);
@@ -190,10 +209,10 @@ void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
 
   const uintptr_t addr = (uintptr_t) job.data;
   BitReader yb;
-  yb.words = (const uint32_t *) (addr & ~(uintptr_t) 3);
-  const uint32_t lead = 8u * (uint32_t) (addr & 3);
+  yb.base = (const uint32_t *) (addr & ~(uintptr_t) 15);
+  const uint32_t lead = 8u * (uint32_t) (addr & 15);
   const uint32_t buffer_end = lead + 8u * job.data_bytes;
-  yb.last = (buffer_end - 1u) >> 5;
+  yb.last_piece = (buffer_end - 1u) >> 7;
   yb.end = active ? lead + 8u * (offset + slice_bytes) : 0u;
   yb.start (lead + 8u * offset);
   const int base_index = (int) yb.bits (7);
@@ -278,7 +297,9 @@ void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
                   ((uint32_t) from[4] & 0xffffu) | ((uint32_t) from[5] << 16),
                   ((uint32_t) from[6] & 0xffffu) | ((uint32_t) from[7] << 16) };
               }
-              gstore < u32x4 > (to, o);
+              // streamed: written once, read by a later kernel; a normal store would push the
+              // slice bytes this wave still has to read out of L2
+              __builtin_nontemporal_store (o, (SCHRO_GLOBAL u32x4 *) to);
             }
           }
           __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
