@@ -97,3 +97,49 @@ def test_whole_stream_through_the_gpu(ctx):
                 p.free()
         count += 1
     assert count == 100
+
+
+def test_scaled_vectors_through_the_sub_pel_kernels(ctx):
+    # as tests/test_oracle_stream.py::test_scaled_vectors_through_the_sub_pel_path: the stream's
+    # blocks with mv_precision p and vectors << p, through the GPU's half-pel upsample and the
+    # half- / quarter- / eighth-pel OBMC kernels, must reproduce the full-pel picture
+    import oracle_lib as O
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    out = {int(z["p%d_number" % n][0]): [z["p%d_out%d" % (n, k)] for k in range(3)] for n in range(8)}
+    for n in (1, 2, 5):
+        tag = "p%d_" % n
+        refs = [int(v) for v in z[tag + "number"][4:]]
+        depth, wavelet = [int(v) for v in z[tag + "transform"]]
+        P = dict(zip(S.PARAM_KEYS, [int(v) for v in z[tag + "params"]]))
+        res_np = [O.inverse_iwt(z[tag + "coeff%d" % k], depth, wavelet) for k in range(3)]
+        base = z[tag + "mv"].copy()
+        vec = (base["flags"] & 3) != 0
+        base["v"][vec, 0:2] &= ~1                        # chroma vectors = luma >> 1 (4:2:2)
+        want = []
+        for k in range(3):
+            u = [O.UpComp(out[r][k], upsample=False) for r in refs]
+            shape = out[refs[0]][k].shape
+            want.append(O.motion_render(base, O.MotionParams(**P), k, u[0], u[1] if len(u) > 1 else None,
+                                        res_np[k], shape[1], shape[0]))
+        res = [ctx.upload(r) for r in res_np]
+        plain = {r: [ctx.upload(out[r][k]) for k in range(3)] for r in refs}
+        hp = {r: [ctx.hp_plane(*out[r][k].shape) for k in range(3)] for r in refs}
+        ctx.upsample_batch([(plain[r][k], hp[r][k]) for r in refs for k in range(3)])
+        for prec in (1, 2, 3):
+            mv = base.copy()
+            mv["v"][vec] = mv["v"][vec] << prec
+            d_mv = ctx.upload_bytes(mv)
+            Pp = dict(P, mv_precision=prec)
+            outs = [ctx.plane(w.shape[0], w.shape[1], np.uint8).fill(0x22) for w in want]
+            jobs = [sa.obmc_plane(d_mv, Pp, k, hp[refs[0]][k], hp[refs[1] if len(refs) > 1 else refs[0]][k],
+                                  res[k], outs[k]) for k in range(3)]
+            ctx.obmc_batch(jobs)
+            for k in range(3):
+                assert np.array_equal(outs[k].download(), want[k]), (n, prec, k)
+                outs[k].free()
+            d_mv.free()
+        for r in refs:
+            for p in plain[r] + hp[r]:
+                p.free()
+        for p in res:
+            p.free()

@@ -40,3 +40,41 @@ def test_fixture_pictures_are_what_the_oracle_decodes():
             assert np.array_equal(z[tag + "coeff%d" % k], rec["coeffs"][k])
         if rec["num_refs"]:
             assert np.array_equal(z[tag + "mv"], rec["mv"])
+
+
+def test_scaled_vectors_through_the_sub_pel_path():
+    # The stream is full-pel, so its reference-pinned pictures say nothing about the half-pel
+    # images or the sub-pel fetch.  But a picture rendered with mv_precision p and its vectors
+    # multiplied by 2^p must come out identical (integer positions of the upsampled reference
+    # are the reference's own samples, the blend degenerates to a copy): that runs the real
+    # stream's blocks through get_block's prec 1 / 2 / 3 branches and the upsampled planes.
+    import oracle_lib as O
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    out = {int(z["p%d_number" % n][0]): [z["p%d_out%d" % (n, k)] for k in range(3)] for n in range(8)}
+    for n in (1, 2, 5):                                  # a P picture and two B pictures
+        tag = "p%d_" % n
+        refs = [int(v) for v in z[tag + "number"][4:]]
+        depth, wavelet = [int(v) for v in z[tag + "transform"]]
+        P = dict(zip(S.PARAM_KEYS, [int(v) for v in z[tag + "params"]]))
+        res = [O.inverse_iwt(z[tag + "coeff%d" % k], depth, wavelet) for k in range(3)]
+        # chroma vectors are the luma vectors >> the chroma shift (4:2:2 here): keep dx even so
+        # that scaling the vector and shifting it commute, and take the full-pel rendering of
+        # these vectors (the reference-pinned code path) as the expectation
+        base = z[tag + "mv"].copy()
+        vec = (base["flags"] & 3) != 0                   # DC blocks keep their DC values
+        base["v"][vec, 0:2] &= ~1
+        want = []
+        for k in range(3):
+            u = [O.UpComp(out[r][k], upsample=False) for r in refs]
+            shape = z[tag + "out%d" % k].shape
+            want.append(O.motion_render(base, O.MotionParams(**P), k, u[0], u[1] if len(u) > 1 else None,
+                                        res[k], shape[1], shape[0]))
+        for prec in (1, 2, 3):
+            mv = base.copy()
+            mv["v"][vec] = mv["v"][vec] << prec
+            op = O.MotionParams(**dict(P, mv_precision=prec))
+            for k in range(3):
+                u = [O.UpComp(out[r][k], upsample=True) for r in refs]
+                got = O.motion_render(mv, op, k, u[0], u[1] if len(u) > 1 else None, res[k],
+                                      want[k].shape[1], want[k].shape[0])
+                assert np.array_equal(got, want[k]), (n, prec, k)
