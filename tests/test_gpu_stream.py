@@ -143,3 +143,20 @@ def test_scaled_vectors_through_the_sub_pel_kernels(ctx):
                 p.free()
         for p in res:
             p.free()
+
+
+def test_s32_wavelet_on_stream_coefficients(ctx):
+    # as the CPU test of the same name: the GPU's s32 inverse wavelet on the stream's real
+    # coefficients against the s16 result the digests pin
+    import oracle_lib as O
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    for n in (0, 1, 2):
+        depth, wavelet = [int(v) for v in z["p%d_transform" % n]]
+        co = [z["p%d_coeff%d" % (n, k)] for k in range(3)]
+        src = [ctx.upload(c.astype(np.int32)) for c in co]
+        dst = [ctx.plane(c.shape[0], c.shape[1], np.int32) for c in co]
+        ctx.iiwt_batch(list(zip(src, dst)), depth, wavelet)
+        for k in range(3):
+            assert np.array_equal(dst[k].download(), O.inverse_iwt(co[k], depth, wavelet).astype(np.int32)), (n, k)
+        for p in src + dst:
+            p.free()

@@ -78,3 +78,18 @@ def test_scaled_vectors_through_the_sub_pel_path():
                 got = O.motion_render(mv, op, k, u[0], u[1] if len(u) > 1 else None, res[k],
                                       want[k].shape[1], want[k].shape[0])
                 assert np.array_equal(got, want[k]), (n, prec, k)
+
+
+def test_s32_wavelet_on_stream_coefficients():
+    # the s32 kernels (schroorc.orc:1815-2164) on real coefficients, whose values stay far inside
+    # 16 bits at every lifting step of these two filters, must agree with the s16 kernels that
+    # the stream digests pin
+    import oracle_lib as O
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    for n in (0, 1, 2):
+        depth, wavelet = [int(v) for v in z["p%d_transform" % n]]
+        for k in range(3):
+            co = z["p%d_coeff%d" % (n, k)]
+            want = O.inverse_iwt(co, depth, wavelet)
+            got = O.inverse_iwt(co.astype(np.int32), depth, wavelet)
+            assert np.array_equal(got, want.astype(np.int32)), (n, k)
