@@ -160,3 +160,31 @@ def test_s32_wavelet_on_stream_coefficients(ctx):
             assert np.array_equal(dst[k].download(), O.inverse_iwt(co[k], depth, wavelet).astype(np.int32)), (n, k)
         for p in src + dst:
             p.free()
+
+
+def test_equivalent_weights_take_the_general_weight_kernel(ctx):
+    # picture weights (2, 2, bits 2) predict exactly what the default (1, 1, bits 1) predicts, but
+    # send the launch to the per-pixel general-weight kernel: the stream's pictures must not change
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    out = {int(z["p%d_number" % n][0]): [z["p%d_out%d" % (n, k)] for k in range(3)] for n in range(8)}
+    import oracle_lib as O
+    for n in (1, 2):
+        tag = "p%d_" % n
+        refs = [int(v) for v in z[tag + "number"][4:]]
+        depth, wavelet = [int(v) for v in z[tag + "transform"]]
+        P = dict(zip(S.PARAM_KEYS, [int(v) for v in z[tag + "params"]]))
+        P.update(picture_weight_1=2, picture_weight_2=2, picture_weight_bits=2)
+        d_mv = ctx.upload_bytes(z[tag + "mv"])
+        keep, jobs, outs = [], [], []
+        for k in range(3):
+            res = ctx.upload(O.inverse_iwt(z[tag + "coeff%d" % k], depth, wavelet))
+            r = [ctx.upload(out[x][k]) for x in refs]
+            o = ctx.plane(out[refs[0]][k].shape[0], out[refs[0]][k].shape[1], np.uint8).fill(0x33)
+            jobs.append(sa.obmc_plane(d_mv, P, k, r[0], r[1] if len(r) > 1 else r[0], res, o))
+            outs.append(o)
+            keep += [res, o] + r
+        ctx.obmc_batch(jobs)
+        for k in range(3):
+            assert np.array_equal(outs[k].download(), z[tag + "out%d" % k]), (n, k)
+        for p in keep + [d_mv]:
+            p.free()

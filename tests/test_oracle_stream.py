@@ -93,3 +93,25 @@ def test_s32_wavelet_on_stream_coefficients():
             want = O.inverse_iwt(co, depth, wavelet)
             got = O.inverse_iwt(co.astype(np.int32), depth, wavelet)
             assert np.array_equal(got, want.astype(np.int32)), (n, k)
+
+
+def test_equivalent_weights_take_the_general_weight_arithmetic():
+    # picture_weight (2, 2, bits 2) is the same prediction as the default (1, 1, bits 1), but the
+    # reference computes it with its general-weight block arithmetic (schromotion8.c:391-397,
+    # 44-73, 621-650) instead of avgub: the stream's pictures must not change
+    import oracle_lib as O
+    z = np.load(os.path.join(S.GOLDEN, "stream_pictures.npz"))
+    out = {int(z["p%d_number" % n][0]): [z["p%d_out%d" % (n, k)] for k in range(3)] for n in range(8)}
+    for n in (1, 2):
+        tag = "p%d_" % n
+        refs = [int(v) for v in z[tag + "number"][4:]]
+        depth, wavelet = [int(v) for v in z[tag + "transform"]]
+        P = dict(zip(S.PARAM_KEYS, [int(v) for v in z[tag + "params"]]))
+        P.update(picture_weight_1=2, picture_weight_2=2, picture_weight_bits=2)
+        for k in range(3):
+            res = O.inverse_iwt(z[tag + "coeff%d" % k], depth, wavelet)
+            u = [O.UpComp(out[r][k], upsample=False) for r in refs]
+            want = z[tag + "out%d" % k]
+            got = O.motion_render(z[tag + "mv"], O.MotionParams(**P), k, u[0], u[1] if len(u) > 1 else None,
+                                  res, want.shape[1], want.shape[0])
+            assert np.array_equal(got, want), (n, k)
