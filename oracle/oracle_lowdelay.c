@@ -21,7 +21,8 @@
  * golden slice data and schrolowdelay.c / schrounpack.c do not compile here (they include
  * schro.h -> orc/orc.h; no stand-ins).  Pinned pieces: the 16-bit dequantisation of the
  * fast path against the compiled orc_dequantise_var_s16_ip (oracle/_ref), the tables
- * against the reference's constants.
+ * against the reference's constants, the exp-Golomb reader against the reader that parses the
+ * reference's test stream (oracle/dirac_stream.py, validated by that stream's digests).
  *
  * The reference's SchroUnpack is a 32-bit shift register over a byte pointer with a count
  * of bits left; what a caller observes is "bit number pos of the buffer, or the guard bit

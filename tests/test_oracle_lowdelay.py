@@ -211,3 +211,34 @@ def test_golden_fixture_is_what_the_oracle_decodes():
         assert O.lowdelay_arith(P, bpp) == {"fast16": 0, "slow16": 1, "s32": 2}[case]
         for k in range(3):
             assert np.array_equal(planes[k], z["%s_comp%d" % (case, k)])
+
+
+def test_slice_codes_read_by_the_stream_validated_reader():
+    # oracle/dirac_stream.py's Bits is the reader that parses the reference's test stream (whose
+    # decoded frames carry the reference decoder's digests): the same interleaved exp-Golomb
+    # reader, restated independently of oracle_lowdelay.c.  The codes of a written slice, read
+    # with it, must be the quantised values that went in -- header fields included.
+    import sys
+    sys.path.insert(0, os.path.join(O.ROOT, "oracle"))
+    import dirac_stream as D
+    P = synth.lowdelay_params(32, 16, (1, 1), 1, 16, 8, 400)
+    q = synth.quantised_planes(P, seed=21, scale=2.0, big_every=7, big_range=1 << 20)
+    bi = synth.lowdelay_base_index(P, seed=5, lo=0, hi=127)
+    data = O.lowdelay_write(q, P, 2, bi)
+    nh, nv, depth = P["n_horiz_slices"], P["n_vert_slices"], P["transform_depth"]
+    for s in range(nh * nv):
+        sy, sx = divmod(s, nh)
+        b = D.Bits(bytes(data[400 * s:400 * (s + 1)]))
+        assert b.bits(7) == bi[s]
+        ylen = b.bits(12)                               # ilog2up (8 * 400) = 12
+        start = b.p
+        for k in range(2):
+            for i in range(1 + 3 * depth):
+                bands = [subband_view(q[k + c], depth, i) for c in range(k + 1)]
+                h, w = bands[0].shape
+                for y in range(h * sy // nv, h * (sy + 1) // nv):
+                    for x in range(w * sx // nh, w * (sx + 1) // nh):
+                        for band in bands:
+                            assert b.sint() == band[y, x]
+            if k == 0:
+                assert b.p - start == ylen
