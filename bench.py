@@ -121,11 +121,37 @@ def cpu_baseline(wl, cores):
     return cores * W * H / dt / 1e6, ok
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, popen=None):
+    """Start n rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, gloo
+    rendezvous on 127.0.0.1), wait for all of them, return the largest exit code.  Rank 0's
+    stdout is this process's stdout, so the one JSON line comes out as usual."""
+    import subprocess
+    popen = popen or subprocess.Popen
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                           stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
@@ -134,9 +160,25 @@ def main():
                          "pair costs ~8 us per launch, 5 %% of a step if every launch is bracketed)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.
+        # It has not touched HIP (nothing GPU-side is imported above), starts N fresh rank
+        # processes -- one per device, the shape of the reference's one exec-domain thread per
+        # device, schroasync-pthread.c:362-390 -- and exits with the worst of their codes.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import schroedinger_amd as sa
+    ndev = sa.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py rank %d: needs a HIP device; there is no CPU fallback" % rank)
+    if world > ndev:
+        raise SystemExit("bench.py rank %d: %d ranks but only %d HIP device(s); one rank per GPU"
+                         % (rank, world, ndev))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch
@@ -145,10 +187,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    import schroedinger_amd as sa
-    if sa.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-    ctx = sa.Context(local_rank % sa.device_count())
+    ctx = sa.Context(local_rank)
     wl = Workload(ctx, args.frames, seed=1 + 1000 * rank)
 
     def barrier():
