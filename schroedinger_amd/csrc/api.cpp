@@ -211,9 +211,14 @@ schro_hip_context_free (SchroHipContext * ctx)
     (void) hipFree (s.ptr);
   if (ctx->scratch)
     (void) hipFree (ctx->scratch);
-  for (int k = 0; k < SchroHipContext::kOrderSlots; k++)
+  for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
     if (ctx->order_slots[k].d)
       (void) hipFree (ctx->order_slots[k].d);
+    if (ctx->order_slots[k].h)
+      (void) hipHostFree (ctx->order_slots[k].h);
+    if (ctx->order_slots[k].copied)
+      (void) hipEventDestroy (ctx->order_slots[k].copied);
+  }
   for (int k = 0; k < SchroHipContext::kArgSlots; k++)
     if (ctx->arg_slots[k].copied)
       (void) hipEventDestroy (ctx->arg_slots[k].copied);
@@ -910,15 +915,22 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
 // two anchors, which share their references, 8 times the same 100 MB.  Here position v of the
 // order holds tile (job << 16 | tile): sorted by the tile's vertical position in its plane,
 // then by reference, so an XCD's run is a horizontal stripe of ALL the pictures and the tiles
-// that read the same reference rows follow each other.  Built on the host, kept on the
-// device, found again by a hash of the geometry and references of the launch.
+// that read the same reference rows follow each other.
+//
+// The table depends on the launch's tile geometry and on WHICH jobs share a reference, not
+// on where the references live: "reference" is the index of the first job of the launch with
+// the same first reference, so a decoder whose reference frames move through a pool from
+// GOP to GOP finds its table again.  A new table goes to the device with an asynchronous
+// copy from the slot's pinned mirror on the context's stream -- behind the kernels that
+// still read the slot's old table, ahead of the launch that wants the new one; the stream
+// is never drained here.
 static int
 obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int variant, int total,
     const uint32_t ** d_order)
 {
   *d_order = nullptr;
   static const bool enabled = !getenv ("SCHRO_HIP_OBMC_ORDER") || atoi (getenv ("SCHRO_HIP_OBMC_ORDER")) != 0;
-  if (!enabled || variant != 1 || jobs.size () < 2 || jobs.size () > 0xffff)
+  if (!enabled || variant < 1 || jobs.size () < 2 || jobs.size () > 0xffff)
     return 0;
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h] (uint64_t v) {
@@ -928,14 +940,20 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     }
   };
   std::vector < int >tiles_y (jobs.size ());
+  std::vector < uint32_t > ref_class (jobs.size ());
+  mix ((uint64_t) variant);
   for (size_t j = 0; j < jobs.size (); j++) {
     int tx;
     obmc_tiles (variant, jobs[j].w, jobs[j].h, jobs[j].xoff, &tx, &tiles_y[j]);
     if (tx * tiles_y[j] > 0xffff)
       return 0;
+    size_t first = 0;
+    while (jobs[first].ref[0] != jobs[j].ref[0])
+      first++;
+    ref_class[j] = (uint32_t) first;
     mix ((uint64_t) tx);
     mix ((uint64_t) tiles_y[j]);
-    mix ((uint64_t) (uintptr_t) jobs[j].ref[0]);
+    mix ((uint64_t) first);
   }
   SchroHipContext::OrderSlot * slot = nullptr, *lru = &ctx->order_slots[0];
   for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
@@ -948,7 +966,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
   if (!slot) {
     struct Key {
       uint32_t row;             // vertical position, 1/64 of the plane
-      uintptr_t ref;
+      uint32_t ref;
       uint32_t entry;
     };
     std::vector < Key > keys;
@@ -956,30 +974,42 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     for (size_t j = 0; j < jobs.size (); j++)
       for (int ty = 0; ty < tiles_y[j]; ty++)
         for (int tx = 0; tx < jobs[j].tiles_x; tx++)
-          keys.push_back (Key { (uint32_t) (ty * 64 / tiles_y[j]), (uintptr_t) jobs[j].ref[0],
+          keys.push_back (Key { (uint32_t) (ty * 64 / tiles_y[j]), ref_class[j],
               (uint32_t) (j << 16) | (uint32_t) (ty * jobs[j].tiles_x + tx) });
     if (keys.size () != (size_t) total)
       return set_error (SCHRO_HIP_EINVAL, "obmc tile order: %zu tiles, %d expected", keys.size (), total);
     std::stable_sort (keys.begin (), keys.end (),[](const Key & a, const Key & b) {
           return a.row != b.row ? a.row < b.row : a.ref < b.ref;
         });
-    std::vector < uint32_t > table (keys.size ());
-    for (size_t k = 0; k < keys.size (); k++)
-      table[k] = keys[k].entry;
-    // the slot's old table may still be read by a launch in flight
-    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
     slot = lru;
-    if (slot->cap < table.size ()) {
+    if (slot->copy_pending) {   // the mirror's previous upload: long done unless tables churn
+      SCHRO_HIP_CHECK (hipEventSynchronize (slot->copied));
+      slot->copy_pending = false;
+    }
+    if (slot->cap < keys.size ()) {
+      // grow-only; hipFree waits for the work that may still read the old table
       if (slot->d)
         SCHRO_HIP_CHECK (hipFree (slot->d));
+      if (slot->h)
+        SCHRO_HIP_CHECK (hipHostFree (slot->h));
       slot->d = nullptr;
+      slot->h = nullptr;
       slot->cap = 0;
-      SCHRO_HIP_CHECK (hipMalloc ((void **) &slot->d, table.size () * sizeof (uint32_t)));
-      slot->cap = table.size ();
+      const size_t cap = keys.size () + keys.size () / 4;
+      SCHRO_HIP_CHECK (hipMalloc ((void **) &slot->d, cap * sizeof (uint32_t)));
+      SCHRO_HIP_CHECK (hipHostMalloc ((void **) &slot->h, cap * sizeof (uint32_t), hipHostMallocDefault));
+      slot->cap = cap;
     }
-    SCHRO_HIP_CHECK (hipMemcpy (slot->d, table.data (), table.size () * sizeof (uint32_t), hipMemcpyHostToDevice));
+    if (!slot->copied)
+      SCHRO_HIP_CHECK (hipEventCreateWithFlags (&slot->copied, hipEventDisableTiming));
+    for (size_t k = 0; k < keys.size (); k++)
+      slot->h[k] = keys[k].entry;
+    SCHRO_HIP_CHECK (hipMemcpyAsync (slot->d, slot->h, keys.size () * sizeof (uint32_t), hipMemcpyHostToDevice,
+            ctx->stream));
+    SCHRO_HIP_CHECK (hipEventRecord (slot->copied, ctx->stream));
+    slot->copy_pending = true;
     slot->hash = h;
-    slot->count = table.size ();
+    slot->count = keys.size ();
   }
   slot->last_use = ++ctx->arg_clock;
   *d_order = slot->d;
@@ -1018,6 +1048,10 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       SCHRO_HIP_REQUIRE (pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
       SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
           "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
+      // bits 0 with a gain other than 1: the reference's edge-block ROUND_SHIFT is
+      // 1 << (0 - 1), an undefined shift (schromotion8.c:391-397) -- nothing to be exact to
+      SCHRO_HIP_REQUIRE (pl.picture_weight_bits > 0 || pl.picture_weight_1 + pl.picture_weight_2 == 1,
+          "obmc_batch: picture_weight_bits 0 needs weights that sum to 1");
       ObmcJob j;
       memset (&j, 0, sizeof (j));
       const int hs = pl.component ? pl.chroma_h_shift : 0, vs = pl.component ? pl.chroma_v_shift : 0;

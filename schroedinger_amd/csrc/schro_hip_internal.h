@@ -319,8 +319,11 @@ struct SchroHipContext {
   struct OrderSlot {
     uint64_t hash;
     uint32_t *d;
+    uint32_t *h;                // pinned mirror the table is uploaded from
     size_t cap, count;
     uint64_t last_use;
+    hipEvent_t copied;          // the slot's last upload
+    bool copy_pending;
   };
   static constexpr int kOrderSlots = 8;
   OrderSlot order_slots[kOrderSlots];

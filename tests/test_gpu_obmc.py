@@ -79,6 +79,16 @@ def test_weighted_prediction(ctx, weights, prec):
         run_case(ctx, 96, 64, blk[0], blk[1], prec, weights, (1, 1), 24 << prec, 5)
 
 
+def test_picture_weight_bits_zero(ctx):
+    # bits 0: weights that sum to 1 go through (no rounding term anywhere); any other sum would
+    # need the reference's 1 << (bits - 1) with bits 0 (schromotion8.c:391-397) and is refused
+    for prec in (0, 2):
+        run_case(ctx, 96, 64, 12, 8, prec, (1, 0, 0), (1, 1), 24 << prec, 11)
+        run_case(ctx, 96, 64, 12, 8, prec, (2, -1, 0), (1, 1), 24 << prec, 12)
+    with pytest.raises(sa.SchroHipError, match="picture_weight_bits 0"):
+        run_case(ctx, 96, 64, 12, 8, 0, (2, 1, 0), (1, 1), 24, 13)
+
+
 def test_dc_values_outside_8_bits(ctx):
     # A DC value outside [-128, 127] makes the reference's s16 accumulator wrap (interior
     # blocks multiply the 16-bit dc + 128; edge blocks store it into a uint8_t).  No legal
@@ -140,3 +150,41 @@ def test_illegal_block_parameters_are_refused(ctx):
     for (blen, bsep) in [(10, 8), (12, 6), (8, 12), (40, 16)]:
         with pytest.raises(sa.SchroHipError):
             run_case(ctx, 96, 64, blen, bsep, 0, (1, 1, 1), (1, 1), 4, 3)
+
+
+def test_rotating_references_in_a_batch(ctx):
+    # A decoder's references move through a frame pool: the same batch shape comes back with
+    # other reference pointers every GOP.  The tile-order table is keyed on which jobs SHARE
+    # a reference, not on addresses: three launches of a two-picture batch with the
+    # references rotated through three buffers, each checked against the oracle.
+    w, h, prec = 320, 128, 2
+    P = synth.motion_params(w, h, 12, 8, prec, (1, 1, 1), (1, 1))
+    op = O.MotionParams(**P)
+    dims = [comp_size(w, h, k, (1, 1)) for k in range(3)]
+    pics = [[synth.picture_u8(ch, cw, seed=40 + 10 * r + k) for k, (cw, ch) in enumerate(dims)]
+            for r in range(3)]
+    ups = [[O.UpComp(p, upsample=True) for p in comps] for comps in pics]
+    hp = []
+    for comps in pics:
+        row = []
+        for p in comps:
+            d, g = ctx.upload(p), ctx.hp_plane(*p.shape)
+            ctx.upsample_batch([(d, g)])
+            row.append(g)
+        hp.append(row)
+    mvs = [synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 40, seed=60 + f) for f in range(2)]
+    d_mvs = [ctx.upload_bytes(m) for m in mvs]
+    res = [[synth.image_s(ch, cw, np.int16, seed=70 + 3 * f + k) for k, (cw, ch) in enumerate(dims)]
+           for f in range(2)]
+    d_res = [[ctx.upload(r) for r in rf] for rf in res]
+    for rot in range(3):
+        jobs, outs = [], []
+        for f in range(2):
+            a, b = (rot + f) % 3, (rot + f + 1) % 3
+            for k, (cw, ch) in enumerate(dims):
+                out = ctx.plane(ch, cw, np.uint8).fill(0x55)
+                jobs.append(sa.obmc_plane(d_mvs[f], P, k, hp[a][k], hp[b][k], d_res[f][k], out))
+                outs.append((out, O.motion_render(mvs[f], op, k, ups[a][k], ups[b][k], res[f][k], cw, ch)))
+        ctx.obmc_batch(jobs)
+        for n, (out, want) in enumerate(outs):
+            assert np.array_equal(out.download(), want), "rotation %d plane %d" % (rot, n)
