@@ -924,6 +924,43 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
 // copy from the slot's pinned mirror on the context's stream -- behind the kernels that
 // still read the slot's old table, ahead of the launch that wants the new one; the stream
 // is never drained here.
+// scratch runs only: SCHRO_HIP_OBMC_STAMPS=1 gives the staged kernel a buffer for per-phase
+// cycle stamps; schro_hip_obmc_stamps_dump () prints their medians
+static unsigned long long *g_stamps;
+static unsigned long long *
+obmc_stamp_buffer ()
+{
+  static const bool on = getenv ("SCHRO_HIP_OBMC_STAMPS") != nullptr;
+  if (on && !g_stamps) {
+    if (hipMalloc ((void **) &g_stamps, 16384 * 16 * 8) != hipSuccess)
+      g_stamps = nullptr;
+    else
+      (void) hipMemset (g_stamps, 0, 16384 * 16 * 8);
+  }
+  return g_stamps;
+}
+
+extern "C" void
+schro_hip_obmc_stamps_dump (void)
+{
+  if (!g_stamps)
+    return;
+  (void) hipDeviceSynchronize ();
+  std::vector < unsigned long long >h (16384 * 16);
+  (void) hipMemcpy (h.data (), g_stamps, h.size () * 8, hipMemcpyDeviceToHost);
+  for (int n = 1; n <= 9; n++) {
+    std::vector < unsigned long long >v;
+    for (int b = 0; b < 16384; b++)
+      if (h[b * 16 + 9])
+        v.push_back (h[b * 16 + n]);
+    if (v.empty ())
+      continue;
+    std::sort (v.begin (), v.end ());
+    fprintf (stderr, "stamp %d: median %llu  p10 %llu  p90 %llu  (n=%zu)\n", n, v[v.size () / 2], v[v.size () / 10],
+        v[v.size () * 9 / 10], v.size ());
+  }
+}
+
 static int
 obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int variant, int total,
     const uint32_t ** d_order)
@@ -1027,80 +1064,96 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   auto variant_of = [](const SchroHipObmcPlane & pl) {
     return (pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1 && pl.picture_weight_bits == 1) ? 1 : 0;
   };
-  // one launch per (precision class, kernel variant) group, keeping plane order
+  // SCHRO_HIP_OBMC_KERNEL=staged: default weights and half-pel references whose block geometry
+  // fits its tables run the LDS-staged kernel (obmc_stage.hip) instead of the item kernel.
+  // Bit-exact and far fewer instructions, but measured slower on 8 x 2160p (r02: luma 0.60 ms
+  // vs 0.275 ms): 77 KB of LDS per tile leave two workgroups per CU to hide a chain of seven
+  // barrier phases with two global round trips in it.
+  static const bool use_staged = getenv ("SCHRO_HIP_OBMC_KERNEL") && strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "staged") == 0;
+  std::vector < ObmcJob > all (nplanes);
+  std::vector < int >key (nplanes);
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipObmcPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
+    SCHRO_HIP_REQUIRE (pl.mv_precision >= 0 && pl.mv_precision <= 3,
+        "obmc_batch: mv_precision %d out of range", pl.mv_precision);
+    SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
+    SCHRO_HIP_REQUIRE (pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
+    SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
+        "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
+    // bits 0 with a gain other than 1: the reference's edge-block ROUND_SHIFT is
+    // 1 << (0 - 1), an undefined shift (schromotion8.c:391-397) -- nothing to be exact to
+    SCHRO_HIP_REQUIRE (pl.picture_weight_bits > 0 || pl.picture_weight_1 + pl.picture_weight_2 == 1,
+        "obmc_batch: picture_weight_bits 0 needs weights that sum to 1");
+    ObmcJob & j = all[p];
+    memset (&j, 0, sizeof (j));
+    const int hs = pl.component ? pl.chroma_h_shift : 0, vs = pl.component ? pl.chroma_v_shift : 0;
+    // schromotion8.c:730-764
+    j.xbsep = pl.xbsep_luma >> hs;
+    j.ybsep = pl.ybsep_luma >> vs;
+    j.xblen = pl.xblen_luma >> hs;
+    j.yblen = pl.yblen_luma >> vs;
+    // schro_params_verify_block_params, schroparams.c:241-272
+    SCHRO_HIP_REQUIRE (((pl.xblen_luma | pl.yblen_luma | pl.xbsep_luma | pl.ybsep_luma) & 3) == 0,
+        "obmc_batch: plane %d: luma block sizes and separations must be multiples of 4", p);
+    SCHRO_HIP_REQUIRE (j.xbsep > 0 && j.ybsep > 0 && j.xblen >= j.xbsep && j.yblen >= j.ybsep
+        && j.xblen <= 2 * j.xbsep && j.yblen <= 2 * j.ybsep && j.xblen <= 64 && j.yblen <= 64,
+        "obmc_batch: plane %d block geometry %dx%d sep %dx%d unsupported", p, j.xblen, j.yblen,
+        j.xbsep, j.ybsep);
+    j.xoff = (j.xblen - j.xbsep) / 2;
+    j.yoff = (j.yblen - j.ybsep) / 2;
+    SCHRO_HIP_REQUIRE (pl.width >= j.xblen && pl.height >= j.yblen,
+        "obmc_batch: plane %d smaller than one block", p);
+    j.nbx = pl.x_num_blocks;
+    j.nby = pl.y_num_blocks;
+    SCHRO_HIP_REQUIRE (j.nbx > 0 && j.nby > 0, "obmc_batch: plane %d has no blocks", p);
+    // schromotion8.c:794-797
+    j.max_x_blocks = std::min (j.nbx - 1, (pl.width - j.xoff) / j.xbsep);
+    j.max_y_blocks = std::min (j.nby - 1, (pl.height - j.yoff) / j.ybsep);
+    j.mv_shift_x = hs;
+    j.mv_shift_y = vs;
+    j.prec = pl.mv_precision;
+    j.wbits = pl.picture_weight_bits;
+    j.w1 = pl.picture_weight_1;
+    j.w2 = pl.picture_weight_2;
+    j.comp = pl.component;
+    j.mvs = (const uint8_t *) pl.mvs;
+    j.ref[0] = pl.ref1;
+    j.ref_stride[0] = pl.ref1_stride;
+    j.ref[1] = pl.ref2 ? pl.ref2 : pl.ref1;
+    j.ref_stride[1] = pl.ref2 ? pl.ref2_stride : pl.ref1_stride;
+    j.residual = pl.residual;
+    j.residual_stride = pl.residual_stride;
+    j.res_bpp = pl.residual_bpp;
+    j.out = pl.out;
+    j.out_stride = pl.out_stride;
+    j.w = pl.width;
+    j.h = pl.height;
+    const int variant = variant_of (pl);
+    const int nd = (variant == 1 && use_staged) ? obmc_stage_nd (j) : 0;
+    key[p] = pl.mv_precision | (variant << 4) | (nd << 8);
+  }
+  // one launch per (precision class, kernel) group, keeping plane order
   std::vector < char >done (nplanes, 0);
   for (int first = 0; first < nplanes; first++) {
     if (done[first])
       continue;
     const int prec = planes[first].mv_precision;
-    const int variant = variant_of (planes[first]);
+    const int nd = key[first] >> 8;
+    const int variant = nd ? 2 : ((key[first] >> 4) & 15);
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
     for (int p = first; p < nplanes; p++) {
-      const SchroHipObmcPlane & pl = planes[p];
-      if (done[p] || pl.mv_precision != prec || variant_of (pl) != variant)
+      if (done[p] || key[p] != key[first])
         continue;
       done[p] = 1;
-      SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
-      SCHRO_HIP_REQUIRE (pl.mv_precision >= 0 && pl.mv_precision <= 3,
-          "obmc_batch: mv_precision %d out of range", pl.mv_precision);
-      SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
-      SCHRO_HIP_REQUIRE (pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
-      SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
-          "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
-      // bits 0 with a gain other than 1: the reference's edge-block ROUND_SHIFT is
-      // 1 << (0 - 1), an undefined shift (schromotion8.c:391-397) -- nothing to be exact to
-      SCHRO_HIP_REQUIRE (pl.picture_weight_bits > 0 || pl.picture_weight_1 + pl.picture_weight_2 == 1,
-          "obmc_batch: picture_weight_bits 0 needs weights that sum to 1");
-      ObmcJob j;
-      memset (&j, 0, sizeof (j));
-      const int hs = pl.component ? pl.chroma_h_shift : 0, vs = pl.component ? pl.chroma_v_shift : 0;
-      // schromotion8.c:730-764
-      j.xbsep = pl.xbsep_luma >> hs;
-      j.ybsep = pl.ybsep_luma >> vs;
-      j.xblen = pl.xblen_luma >> hs;
-      j.yblen = pl.yblen_luma >> vs;
-      // schro_params_verify_block_params, schroparams.c:241-272
-      SCHRO_HIP_REQUIRE (((pl.xblen_luma | pl.yblen_luma | pl.xbsep_luma | pl.ybsep_luma) & 3) == 0,
-          "obmc_batch: plane %d: luma block sizes and separations must be multiples of 4", p);
-      SCHRO_HIP_REQUIRE (j.xbsep > 0 && j.ybsep > 0 && j.xblen >= j.xbsep && j.yblen >= j.ybsep
-          && j.xblen <= 2 * j.xbsep && j.yblen <= 2 * j.ybsep && j.xblen <= 64 && j.yblen <= 64,
-          "obmc_batch: plane %d block geometry %dx%d sep %dx%d unsupported", p, j.xblen, j.yblen,
-          j.xbsep, j.ybsep);
-      j.xoff = (j.xblen - j.xbsep) / 2;
-      j.yoff = (j.yblen - j.ybsep) / 2;
-      SCHRO_HIP_REQUIRE (pl.width >= j.xblen && pl.height >= j.yblen,
-          "obmc_batch: plane %d smaller than one block", p);
-      j.nbx = pl.x_num_blocks;
-      j.nby = pl.y_num_blocks;
-      SCHRO_HIP_REQUIRE (j.nbx > 0 && j.nby > 0, "obmc_batch: plane %d has no blocks", p);
-      // schromotion8.c:794-797
-      j.max_x_blocks = std::min (j.nbx - 1, (pl.width - j.xoff) / j.xbsep);
-      j.max_y_blocks = std::min (j.nby - 1, (pl.height - j.yoff) / j.ybsep);
-      j.mv_shift_x = hs;
-      j.mv_shift_y = vs;
-      j.prec = pl.mv_precision;
-      j.wbits = pl.picture_weight_bits;
-      j.w1 = pl.picture_weight_1;
-      j.w2 = pl.picture_weight_2;
-      j.comp = pl.component;
-      j.mvs = (const uint8_t *) pl.mvs;
-      j.ref[0] = pl.ref1;
-      j.ref_stride[0] = pl.ref1_stride;
-      j.ref[1] = pl.ref2 ? pl.ref2 : pl.ref1;
-      j.ref_stride[1] = pl.ref2 ? pl.ref2_stride : pl.ref1_stride;
-      j.residual = pl.residual;
-      j.residual_stride = pl.residual_stride;
-      j.res_bpp = pl.residual_bpp;
-      j.out = pl.out;
-      j.out_stride = pl.out_stride;
-      j.w = pl.width;
-      j.h = pl.height;
+      ObmcJob j = all[p];
       int tiles_y;
-      obmc_tiles (variant, pl.width, pl.height, j.xoff, &j.tiles_x, &tiles_y);
+      obmc_tiles (variant, j.w, j.h, j.xoff, &j.tiles_x, &tiles_y);
       j.tile_base = tile_base;
       tile_base += j.tiles_x * tiles_y;
       obmc_item_geometry (&j);
+      j.stamps = obmc_stamp_buffer ();
       jobs.push_back (j);
     }
     void *d_jobs;
@@ -1113,8 +1166,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       return r;
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec,
-          variant, d_order);
+      r = nd ? launch_obmc_stage (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
+          : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
     }
     if (r)
       return r;

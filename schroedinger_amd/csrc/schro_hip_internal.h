@@ -96,6 +96,7 @@ struct ObmcJob {
   // ceil (2^32 / d) for mdiv ()
   int nseg, nch, lpi, item_bytes, ipw, chunk_cap;
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
+  unsigned long long *stamps;   // scratch runs only (SCHRO_HIP_OBMC_STAMPS): per-workgroup phase stamps
 };
 
 // One picture's slices (lowdelay.hip).
@@ -264,6 +265,10 @@ int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const
 int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order);
+// staged kernel (obmc_stage.hip): prediction dwords per block row, 0 = geometry not supported
+int obmc_stage_nd (const ObmcJob & job);
+int launch_obmc_stage (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
+    const uint32_t * d_order);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
