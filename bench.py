@@ -46,25 +46,20 @@ def coeff_plane(h, w, seed):
     return c.astype(np.int16)
 
 
-class Workload:
-    def __init__(self, ctx, frames, seed):
+class BatchSet:
+    """One picture batch in flight: its references' half-pel images, coefficient frames,
+    motion fields, residual frames and output pictures -- all resident in HBM."""
+
+    def __init__(self, wl, seed):
         import schroedinger_amd as sa
-        self.ctx, self.frames = ctx, frames
-        self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
-        dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
-        self.dims = dims
-        # two references (planar u8) + their half-pel images
-        self.ref_np = [[synth.picture_u8(h, w, seed=seed + 100 + 10 * r + k) for k, (h, w) in
-                        enumerate(dims)] for r in range(2)]
-        self.ref = [[ctx.upload(p) for p in comps] for comps in self.ref_np]
+        ctx, dims = wl.ctx, wl.dims
         self.hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
-        self.up_pairs = [(self.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
+        self.up_pairs = [(wl.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
         self.iwt_pairs, self.obmc_jobs = [], []
         self.coeff_np, self.mv_np, self.out = [], [], []
         base = {}
-        for f in range(frames):
-            mv = synth.motion_field(self.P["x_num_blocks"], self.P["y_num_blocks"], 64,
-                                    seed=seed + 2 + f)
+        for f in range(wl.frames):
+            mv = synth.motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 64, seed=seed + 2 + f)
             d_mv = ctx.upload_bytes(mv)
             self.mv_np.append(mv)
             co_f, out_f = [], []
@@ -77,18 +72,54 @@ class Workload:
                 d_res = ctx.plane(h, w, np.int16)
                 out = ctx.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
-                self.obmc_jobs.append(sa.obmc_plane(d_mv, self.P, k, self.hp[0][k], self.hp[1][k],
-                                                    d_res, out))
+                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[0][k], self.hp[1][k], d_res, out))
                 co_f.append(co)
                 out_f.append(out)
             self.coeff_np.append(co_f)
             self.out.append(out_f)
 
+
+class Workload:
+    """`queues` picture batches in flight.  With two queues batch k's OBMC (issue-bound) runs on
+    queue 1 beside batch k + 1's upsample + inverse wavelet (HBM-bound) on queue 0; the marks
+    are the decoder's stage dependencies (OBMC after its wavelet; a batch's frames are rewritten
+    only after the OBMC that read them)."""
+
+    def __init__(self, ctx, frames, seed, queues=2):
+        self.ctx, self.frames, self.queues = ctx, frames, queues
+        self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
+        dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+        self.dims = dims
+        # two references (planar u8), shared by the batches as between two anchors of a GOP
+        self.ref_np = [[synth.picture_u8(h, w, seed=seed + 100 + 10 * r + k) for k, (h, w) in
+                        enumerate(dims)] for r in range(2)]
+        self.ref = [[ctx.upload(p) for p in comps] for comps in self.ref_np]
+        self.sets = [BatchSet(self, seed + 50 * s) for s in range(queues)]
+        s0 = self.sets[0]
+        self.coeff_np, self.mv_np, self.out = s0.coeff_np, s0.mv_np, s0.out
+        self.k = 0
+
     def step(self):
-        c = self.ctx
-        c.upsample_batch(self.up_pairs)
-        c.iiwt_batch(self.iwt_pairs, DEPTH, FILTER)
-        c.obmc_batch(self.obmc_jobs)
+        c, k = self.ctx, self.k
+        self.k += 1
+        if self.queues == 1:
+            b = self.sets[0]
+            c.upsample_batch(b.up_pairs)
+            c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
+            c.obmc_batch(b.obmc_jobs)
+            return
+        s = k % self.queues
+        b = self.sets[s]
+        c.select_queue(0)
+        c.queue_wait_mark(8 + s)            # the OBMC that last read this batch's frames
+        c.upsample_batch(b.up_pairs)
+        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
+        c.queue_mark(s)
+        c.select_queue(1)
+        c.queue_wait_mark(s)
+        c.obmc_batch(b.obmc_jobs)
+        c.queue_mark(8 + s)
+        c.select_queue(0)
 
 
 def cpu_baseline(wl, cores):
@@ -153,6 +184,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
+    ap.add_argument("--queues", type=int, default=2, choices=(1, 2),
+                    help="picture batches in flight per GPU (2: OBMC of one beside the wavelet of the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
     ap.add_argument("--profile-every", type=int, default=4,
@@ -188,7 +221,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = sa.Context(local_rank)
-    wl = Workload(ctx, args.frames, seed=1 + 1000 * rank)
+    wl = Workload(ctx, args.frames, seed=1 + 1000 * rank, queues=args.queues)
 
     def barrier():
         ctx.synchronize()
@@ -269,7 +302,8 @@ def main():
             "dtype": "s16", "data": "synthetic",
             "config": {"workload": "2160p 4:2:0 inter pictures: 3-level DD(9,7) IIWT s16 + "
                        "half-pel upsample of 2 refs + 12x12/8x8 quarter-pel OBMC + add/clamp",
-                       "frames_per_step_per_gpu": args.frames, "width": W, "height": H,
+                       "frames_per_step_per_gpu": args.frames, "batches_in_flight": args.queues,
+                       "width": W, "height": H,
                        "sharding": "pictures across GPUs, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

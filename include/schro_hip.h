@@ -87,9 +87,31 @@ int schro_hip_download_2d (SchroHipContext * ctx, void *dst, int dst_stride,
     const void *src, int src_stride, int row_bytes, int height);
 int schro_hip_memset (SchroHipContext * ctx, void *dst, int value,
     size_t bytes);
+/* waits for everything enqueued on both queues */
 int schro_hip_synchronize (SchroHipContext * ctx);
-/* the context's hipStream_t, for hosts that enqueue their own work or events */
+/* the selected queue's hipStream_t, for hosts that enqueue their own work or events */
 void *schro_hip_stream (SchroHipContext * ctx);
+
+/* Two in-order queues per context.  The reference's scheduler runs the stages of different
+ * pictures on several worker threads at once (schroasync-pthread.c:320-390,
+ * schro_decoder_async_schedule, schrodecoder.c:1546-1682); on this domain the same
+ * concurrency is two queues: the inverse wavelet is HBM-bound, OBMC is issue-bound, so
+ * picture batch k's schro_hip_obmc_batch on one queue and batch k+1's schro_hip_iiwt_batch /
+ * schro_hip_upsample_batch on the other run side by side.  Every call of this header goes to
+ * the selected queue (0 after schro_hip_context_new); schro_hip_queue_wait makes the work
+ * enqueued LATER on `waiter` start after everything enqueued SO FAR on `signaller` (the
+ * render_ok / wavelet-done dependencies of schrodecoder.c:1589-1660). */
+#define SCHRO_HIP_QUEUES 2
+int schro_hip_context_select_queue (SchroHipContext * ctx, int queue);
+int schro_hip_context_queue (SchroHipContext * ctx);
+int schro_hip_queue_wait (SchroHipContext * ctx, int waiter, int signaller);
+/* finer than "everything so far": schro_hip_queue_mark records mark m (0 .. 15) behind the work
+ * enqueued so far on the SELECTED queue; schro_hip_queue_wait_mark makes the selected queue's
+ * later work wait for the most recent recording of m (no-op if m was never recorded).  E.g.
+ * batch k + 2's wavelet may overwrite batch k's residual frames once batch k's OBMC is done. */
+#define SCHRO_HIP_MARKS 16
+int schro_hip_queue_mark (SchroHipContext * ctx, int mark);
+int schro_hip_queue_wait_mark (SchroHipContext * ctx, int mark);
 
 /* HIP-event timing of everything enqueued between begin and end on the
  * context stream; schro_hip_timer_end synchronises and returns milliseconds

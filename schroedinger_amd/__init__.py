@@ -124,6 +124,22 @@ class Context:
     def synchronize(self):
         check(self.lib.schro_hip_synchronize(self.h))
 
+    def select_queue(self, q):
+        """Calls that follow are enqueued on in-order queue q (0 or 1)."""
+        check(self.lib.schro_hip_context_select_queue(self.h, q))
+
+    def queue_mark(self, mark):
+        """Record mark (0..15) behind the work enqueued so far on the selected queue."""
+        check(self.lib.schro_hip_queue_mark(self.h, mark))
+
+    def queue_wait_mark(self, mark):
+        """Later work on the selected queue waits for the latest recording of `mark`."""
+        check(self.lib.schro_hip_queue_wait_mark(self.h, mark))
+
+    def queue_wait(self, waiter, signaller):
+        """Later work on `waiter` starts after everything enqueued so far on `signaller`."""
+        check(self.lib.schro_hip_queue_wait(self.h, waiter, signaller))
+
     def timer_begin(self):
         check(self.lib.schro_hip_timer_begin(self.h))
 

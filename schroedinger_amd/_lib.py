@@ -16,6 +16,8 @@ EXPORTED_SYMBOLS = [
     "schro_hip_domain_alloc", "schro_hip_domain_free", "schro_hip_domain_bytes",
     "schro_hip_upload_2d", "schro_hip_download_2d", "schro_hip_memset",
     "schro_hip_synchronize", "schro_hip_stream",
+    "schro_hip_context_select_queue", "schro_hip_context_queue", "schro_hip_queue_wait",
+    "schro_hip_queue_mark", "schro_hip_queue_wait_mark",
     "schro_hip_timer_begin", "schro_hip_timer_end",
     "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
@@ -160,6 +162,16 @@ def load():
     L.schro_hip_synchronize.restype = i
     L.schro_hip_stream.argtypes = [vp]
     L.schro_hip_stream.restype = vp
+    L.schro_hip_context_select_queue.argtypes = [vp, i]
+    L.schro_hip_context_select_queue.restype = i
+    L.schro_hip_context_queue.argtypes = [vp]
+    L.schro_hip_context_queue.restype = i
+    L.schro_hip_queue_wait.argtypes = [vp, i, i]
+    L.schro_hip_queue_wait.restype = i
+    L.schro_hip_queue_mark.argtypes = [vp, i]
+    L.schro_hip_queue_mark.restype = i
+    L.schro_hip_queue_wait_mark.argtypes = [vp, i]
+    L.schro_hip_queue_wait_mark.restype = i
     L.schro_hip_timer_begin.argtypes = [vp]
     L.schro_hip_timer_begin.restype = i
     L.schro_hip_timer_end.argtypes = [vp]

@@ -49,8 +49,10 @@ push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
       h = (h ^ b[i]) * 1099511628211ull;
   }
   ctx->arg_clock++;
-  int victim = 0;
-  for (int k = 0; k < SchroHipContext::kArgSlots; k++) {
+  constexpr int per_queue = SchroHipContext::kArgSlots / SchroHipContext::kQueues;
+  const int k0 = ctx->cur * per_queue;
+  int victim = k0;
+  for (int k = k0; k < k0 + per_queue; k++) {
     SchroHipContext::ArgSlot & sl = ctx->arg_slots[k];
     if (sl.bytes == bytes && sl.hash == h
         && memcmp (ctx->h_args + (size_t) k * SchroHipContext::kArgSlotBytes, host, bytes) == 0) {
@@ -83,16 +85,18 @@ push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
 int
 ensure_scratch (SchroHipContext * ctx, size_t bytes)
 {
-  if (bytes <= ctx->scratch_size)
+  void *&scratch = ctx->scratch_q[ctx->cur];
+  size_t & size = ctx->scratch_size_q[ctx->cur];
+  if (bytes <= size)
     return 0;
-  if (ctx->scratch) {
+  if (scratch) {
     SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
-    SCHRO_HIP_CHECK (hipFree (ctx->scratch));
-    ctx->scratch = nullptr;
-    ctx->scratch_size = 0;
+    SCHRO_HIP_CHECK (hipFree (scratch));
+    scratch = nullptr;
+    size = 0;
   }
-  SCHRO_HIP_CHECK (hipMalloc (&ctx->scratch, bytes));
-  ctx->scratch_size = bytes;
+  SCHRO_HIP_CHECK (hipMalloc (&scratch, bytes));
+  size = bytes;
   return 0;
 }
 
@@ -174,8 +178,14 @@ schro_hip_context_new (int device)
   SchroHipContext *ctx = new SchroHipContext ();
   ctx->device = device;
   ctx->domain_bytes = 0;
-  ctx->scratch = nullptr;
-  ctx->scratch_size = 0;
+  for (int q = 0; q < SchroHipContext::kQueues; q++) {
+    ctx->scratch_q[q] = nullptr;
+    ctx->scratch_size_q[q] = 0;
+    ctx->streams[q] = nullptr;
+    ctx->queue_ev[q] = nullptr;
+  }
+  ctx->cur = 0;
+  memset (ctx->marks, 0, sizeof (ctx->marks));
   ctx->arg_clock = 0;
   memset (ctx->arg_slots, 0, sizeof (ctx->arg_slots));
   memset (ctx->order_slots, 0, sizeof (ctx->order_slots));
@@ -183,8 +193,12 @@ schro_hip_context_new (int device)
   ctx->ev_used = 0;
   ctx->h_args = nullptr;
   ctx->d_args = nullptr;
-  bool ok = hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking) == hipSuccess
-      && hipEventCreate (&ctx->ev_begin) == hipSuccess
+  bool ok = true;
+  for (int q = 0; ok && q < SchroHipContext::kQueues; q++)
+    ok = hipStreamCreateWithFlags (&ctx->streams[q], hipStreamNonBlocking) == hipSuccess
+        && hipEventCreateWithFlags (&ctx->queue_ev[q], hipEventDisableTiming) == hipSuccess;
+  ctx->stream = ctx->streams[0];
+  ok = ok && hipEventCreate (&ctx->ev_begin) == hipSuccess
       && hipEventCreate (&ctx->ev_end) == hipSuccess
       && hipHostMalloc ((void **) &ctx->h_args, SchroHipContext::kArgSlots * SchroHipContext::kArgSlotBytes,
           hipHostMallocDefault) == hipSuccess
@@ -206,11 +220,14 @@ schro_hip_context_free (SchroHipContext * ctx)
   if (!ctx)
     return;
   (void) hipSetDevice (ctx->device);
-  (void) hipStreamSynchronize (ctx->stream);
+  for (int q = 0; q < SchroHipContext::kQueues; q++)
+    if (ctx->streams[q])
+      (void) hipStreamSynchronize (ctx->streams[q]);
   for (auto & s : ctx->slots)
     (void) hipFree (s.ptr);
-  if (ctx->scratch)
-    (void) hipFree (ctx->scratch);
+  for (int q = 0; q < SchroHipContext::kQueues; q++)
+    if (ctx->scratch_q[q])
+      (void) hipFree (ctx->scratch_q[q]);
   for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
     if (ctx->order_slots[k].d)
       (void) hipFree (ctx->order_slots[k].d);
@@ -232,7 +249,15 @@ schro_hip_context_free (SchroHipContext * ctx)
   }
   (void) hipEventDestroy (ctx->ev_begin);
   (void) hipEventDestroy (ctx->ev_end);
-  (void) hipStreamDestroy (ctx->stream);
+  for (int m = 0; m < SchroHipContext::kMarks; m++)
+    if (ctx->marks[m])
+      (void) hipEventDestroy (ctx->marks[m]);
+  for (int q = 0; q < SchroHipContext::kQueues; q++) {
+    if (ctx->queue_ev[q])
+      (void) hipEventDestroy (ctx->queue_ev[q]);
+    if (ctx->streams[q])
+      (void) hipStreamDestroy (ctx->streams[q]);
+  }
   delete ctx;
 }
 
@@ -318,7 +343,65 @@ int
 schro_hip_synchronize (SchroHipContext * ctx)
 {
   SCHRO_HIP_REQUIRE (ctx, "synchronize: no context");
-  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (int q = 0; q < SchroHipContext::kQueues; q++)
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[q]));
+  return 0;
+}
+
+// Queues.  The reference's scheduler runs the stages of different pictures on several worker
+// threads at once (schroasync-pthread.c:320-390); on a GPU domain the same concurrency is two
+// in-order queues: select one, enqueue a picture batch's stage calls, and order stages of
+// different queues with schro_hip_queue_wait where one consumes what the other produced.
+int
+schro_hip_context_select_queue (SchroHipContext * ctx, int queue)
+{
+  SCHRO_HIP_REQUIRE (ctx && queue >= 0 && queue < SchroHipContext::kQueues, "select_queue: queue %d out of range", queue);
+  ctx->cur = queue;
+  ctx->stream = ctx->streams[queue];
+  return 0;
+}
+
+int
+schro_hip_context_queue (SchroHipContext * ctx)
+{
+  return ctx ? ctx->cur : -1;
+}
+
+// Marks: a finer dependency than "everything so far".  Picture batch k + 2's wavelet may
+// overwrite batch k's residual frames once batch k's OBMC is done -- not batch k + 1's, which
+// is what is last on that queue by then.
+int
+schro_hip_queue_mark (SchroHipContext * ctx, int mark)
+{
+  SCHRO_HIP_REQUIRE (ctx && mark >= 0 && mark < SchroHipContext::kMarks, "queue_mark: mark %d out of range", mark);
+  (void) hipSetDevice (ctx->device);
+  if (!ctx->marks[mark])
+    SCHRO_HIP_CHECK (hipEventCreateWithFlags (&ctx->marks[mark], hipEventDisableTiming));
+  SCHRO_HIP_CHECK (hipEventRecord (ctx->marks[mark], ctx->stream));
+  return 0;
+}
+
+int
+schro_hip_queue_wait_mark (SchroHipContext * ctx, int mark)
+{
+  SCHRO_HIP_REQUIRE (ctx && mark >= 0 && mark < SchroHipContext::kMarks, "queue_wait_mark: mark %d out of range", mark);
+  if (!ctx->marks[mark])
+    return 0;                   // never set: nothing to wait for
+  (void) hipSetDevice (ctx->device);
+  SCHRO_HIP_CHECK (hipStreamWaitEvent (ctx->stream, ctx->marks[mark], 0));
+  return 0;
+}
+
+int
+schro_hip_queue_wait (SchroHipContext * ctx, int waiter, int signaller)
+{
+  SCHRO_HIP_REQUIRE (ctx && waiter >= 0 && waiter < SchroHipContext::kQueues && signaller >= 0
+      && signaller < SchroHipContext::kQueues, "queue_wait: bad arguments");
+  if (waiter == signaller)
+    return 0;
+  (void) hipSetDevice (ctx->device);
+  SCHRO_HIP_CHECK (hipEventRecord (ctx->queue_ev[signaller], ctx->streams[signaller]));
+  SCHRO_HIP_CHECK (hipStreamWaitEvent (ctx->streams[waiter], ctx->queue_ev[signaller], 0));
   return 0;
 }
 
@@ -406,13 +489,13 @@ iiwt_fused_group (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int np
     const void *ll = pl.src;
     int ll_stride = (pl.src_stride << (top - 1)) * 2;
     if (top < depth) {
-      ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + top];
+      ll = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + top];
       ll_stride = scratch_stride[(size_t) p * depth + top];
     }
     void *dst = pl.dst;
     int dst_stride = pl.dst_stride;
     if (fb > 0) {
-      dst = (char *) ctx->scratch + scratch_off[(size_t) p * depth + fb];
+      dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + fb];
       dst_stride = scratch_stride[(size_t) p * depth + fb];
     }
     const int w = pl.width >> fb, h = pl.height >> fb;
@@ -545,7 +628,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       const char *ll = base;
       int ll_stride = vstride * 2;
       if (level < depth - 1) {
-        ll = (const char *) ctx->scratch + scratch_off[(size_t) p * depth + level + 1];
+        ll = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level + 1];
         ll_stride = scratch_stride[(size_t) p * depth + level + 1];
       }
       j.sb[0] = ll;
@@ -560,7 +643,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         j.dst = pl.dst;
         j.dst_stride = pl.dst_stride;
       } else {
-        j.dst = (char *) ctx->scratch + scratch_off[(size_t) p * depth + level];
+        j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level];
         j.dst_stride = scratch_stride[(size_t) p * depth + level];
       }
       j.w = w;
@@ -992,8 +1075,10 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     mix ((uint64_t) tiles_y[j]);
     mix ((uint64_t) first);
   }
-  SchroHipContext::OrderSlot * slot = nullptr, *lru = &ctx->order_slots[0];
-  for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
+  constexpr int per_queue = SchroHipContext::kOrderSlots / SchroHipContext::kQueues;
+  const int k0 = ctx->cur * per_queue;
+  SchroHipContext::OrderSlot * slot = nullptr, *lru = &ctx->order_slots[k0];
+  for (int k = k0; k < k0 + per_queue; k++) {
     SchroHipContext::OrderSlot & o = ctx->order_slots[k];
     if (o.d && o.hash == h && o.count == (size_t) total)
       slot = &o;

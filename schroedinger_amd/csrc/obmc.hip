@@ -908,8 +908,11 @@ int
 launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant,
     const uint32_t * d_order)
 {
+  // SCHRO_HIP_OBMC_LDS_PAD (bytes of unused dynamic LDS): fewer workgroups per CU than the
+  // five that fit, to leave registers for a kernel on the other queue (experiments)
+  static const int lds_pad = getenv ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (getenv ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
   if (variant == 1)
-    hipLaunchKernelGGL ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), 0, stream,
+    hipLaunchKernelGGL ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), lds_pad, stream,
         d_jobs, njobs, d_order);
   else
     hipLaunchKernelGGL ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,

@@ -279,6 +279,18 @@ void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y
 
 struct SchroHipContext {
   int device;
+  // Two in-order queues (HIP streams) per context: the pixel path of one batch of pictures is
+  // HBM-bound in the inverse wavelet and issue-bound in OBMC, so a decoder that runs batch k's
+  // OBMC on one queue and batch k+1's wavelet + upsample on the other keeps both busy.  Calls
+  // go to the selected queue; `stream` is always streams[cur].  Job-table slots, tile-order
+  // slots and the wavelet's scratch are per queue, so a launch on one queue never has its
+  // tables rewritten by a copy enqueued on the other.
+  static constexpr int kQueues = 2;
+  hipStream_t streams[kQueues];
+  hipEvent_t queue_ev[kQueues];
+  static constexpr int kMarks = 16;
+  hipEvent_t marks[kMarks];     // schro_hip_queue_mark / _wait_mark, created on first use
+  int cur;
   hipStream_t stream;
   hipEvent_t ev_begin, ev_end;
 
@@ -330,12 +342,13 @@ struct SchroHipContext {
     hipEvent_t copied;          // the slot's last upload
     bool copy_pending;
   };
-  static constexpr int kOrderSlots = 8;
+  static constexpr int kOrderSlots = 8;         // kOrderSlots / kQueues per queue
   OrderSlot order_slots[kOrderSlots];
 
-  // grow-only scratch for intermediate LL bands
-  void *scratch;
-  size_t scratch_size;
+  // grow-only scratch for intermediate LL bands, one per queue
+  void *scratch_q[kQueues];
+  size_t scratch_size_q[kQueues];
+  void *&scratch_ref () { return scratch_q[cur]; }
 };
 
 namespace schro {
