@@ -107,9 +107,10 @@ def test_register_form_tile_edges(ctx, filt, small, monkeypatch):
 
 
 def test_baseline_size_s32_haar0(ctx):
-    # BASELINE config 4 shape class: s32, Haar (no shift), 4:2:2 chroma plane 3840x4320 is
-    # large for the CPU oracle; one 3840x2160 s32 plane pins the kernel, the full-size case is
-    # covered by the round-trip property below.
+    # BASELINE config 5 shape class: s32, Haar (no shift), 3 levels, on one 3840x2160 plane
+    # against the oracle, plus the forward -> inverse round trip.  The full 7680x4320 4:2:2
+    # picture goes through slices -> wavelet -> v210 in
+    # tests/test_gpu_lowdelay.py::test_config5_whole_pixel_path_8k.
     img = synth.image_s(2160, 3840, np.int32, seed=9) * 4   # 10-bit range
     co = O.forward_iwt(img, 3, 3)
     got = gpu_iiwt(ctx, co, 3, 3)

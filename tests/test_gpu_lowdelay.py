@@ -205,3 +205,32 @@ def test_8k_422_10bit_configuration(ctx):
     del q
     got = decode_gpu(ctx, [data], P, 4)
     compare(got[0], decode_cpu(data, P, 4), "8K")
+
+
+def test_config5_whole_pixel_path_8k(ctx):
+    # BASELINE config 5 end to end on the device, against the oracle's chain on the host:
+    # slices -> coefficients (+ DC prediction) -> 3-level Haar (no shift) s32 inverse wavelet
+    # -> v210 copy-out, at 7680x4320 4:2:2 (what tests/bench_lowdelay.py times).
+    W, H, depth, filt = 7680, 4320, 3, 3
+    P = synth.lowdelay_params(W, H, (1, 0), depth, 32, 8, 155, 1)
+    q = synth.quantised_planes(P, seed=41, scale=0.9)
+    bi = synth.lowdelay_base_index(P, seed=42, lo=4, hi=28)
+    data = O.lowdelay_write(q, P, 4, bi)
+    del q
+    dims = [(P["iwt_luma_height"], P["iwt_luma_width"])] + [(P["iwt_chroma_height"], P["iwt_chroma_width"])] * 2
+    d = ctx.upload_bytes(data)
+    co = [ctx.plane(h, w, np.int32).fill(0x5a) for (h, w) in dims]
+    px = [ctx.plane(h, w, np.int32) for (h, w) in dims]
+    v210 = ctx.plane(H, 16 * (-(-W // 6)), np.uint8).fill(0x5a)
+    ctx.lowdelay_batch([(d, co)], P)
+    ctx.iiwt_batch(list(zip(co, px)), depth, filt)
+    ctx.pack_v210_batch([(px, 1, 0, v210, W, H)])
+    got_px = [p.download() for p in px]
+    got_v210 = v210.download()
+    for p in [d, v210] + co + px:
+        p.free()
+    want_co = decode_cpu(data, P, 4)
+    want_px = [O.inverse_iwt(c, depth, filt) for c in want_co]
+    for k in range(3):
+        assert np.array_equal(got_px[k], want_px[k]), "component %d after the inverse wavelet" % k
+    assert np.array_equal(got_v210, O.pack_v210(want_px, 1, 0, W, H))
