@@ -56,12 +56,13 @@ class BatchSet:
         self.hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
         self.up_pairs = [(wl.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
         self.iwt_pairs, self.obmc_jobs = [], []
-        self.coeff_np, self.mv_np, self.out = [], [], []
+        self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         base = {}
         for f in range(wl.frames):
             mv = synth.motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 64, seed=seed + 2 + f)
             d_mv = ctx.upload_bytes(mv)
             self.mv_np.append(mv)
+            self.mv_dev.append(d_mv)
             co_f, out_f = [], []
             for k, (h, w) in enumerate(dims):
                 key = (k, f % 4)        # 4 distinct coefficient sets, uploaded to distinct buffers
@@ -98,8 +99,11 @@ class Workload:
         s0 = self.sets[0]
         self.coeff_np, self.mv_np, self.out = s0.coeff_np, s0.mv_np, s0.out
         self.k = 0
+        self.prev_alone = False
 
-    def step(self):
+    def step(self, alone=False):
+        """alone: this step's launches share the device with no other step's (the steps whose
+        launches bench.py brackets with events, so that a kernel's duration is its own)."""
         c, k = self.ctx, self.k
         self.k += 1
         if self.queues == 1:
@@ -111,6 +115,9 @@ class Workload:
         s = k % self.queues
         b = self.sets[s]
         c.select_queue(0)
+        if alone or self.prev_alone:
+            c.queue_wait(0, 1)              # the previous batch's OBMC has finished
+        self.prev_alone = alone
         c.queue_wait_mark(8 + s)            # the OBMC that last read this batch's frames
         c.upsample_batch(b.up_pairs)
         c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
@@ -122,34 +129,109 @@ class Workload:
         c.select_queue(0)
 
 
-def cpu_baseline(wl, cores):
-    """The oracle on `cores` pictures (one per thread, the reference's own
-    picture-level parallelism), also used to check the GPU output of frame 0."""
+def cpu_baseline(wl, cores, reps=10):
+    """The oracle on `cores` threads, `reps` pictures each (one picture per thread at a time:
+    the reference's own picture-level parallelism), also used to check the GPU output of
+    frame 0."""
     import oracle_lib as O      # cpu_baseline leg only
     O.lib()
     ups = [[O.UpComp(p, upsample=False) for p in comps] for comps in wl.ref_np]
     results = [None] * cores
 
-    def one(i):
-        f = i % wl.frames
-        outs = []
-        for k, (h, w) in enumerate(wl.dims):
-            res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
-            outs.append(O.motion_render(wl.mv_np[f], O.MotionParams(**wl.P), k, ups[0][k], ups[1][k],
-                                        res, w, h))
-        results[i] = outs
+    def one(i, n=1):
+        for rep in range(n):
+            f = (i + rep) % wl.frames
+            outs = []
+            for k, (h, w) in enumerate(wl.dims):
+                res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
+                outs.append(O.motion_render(wl.mv_np[f], O.MotionParams(**wl.P), k, ups[0][k], ups[1][k],
+                                            res, w, h))
+            if rep == 0:
+                results[i] = outs
 
     t0 = time.perf_counter()
     for comps in ups:                      # reference upsampling, once per reference
         ths = [threading.Thread(target=lambda u=u: O.lib().oracle_upcomp_upsample(u.c)) for u in comps]
         [t.start() for t in ths]
         [t.join() for t in ths]
-    ths = [threading.Thread(target=one, args=(i,)) for i in range(cores)]
+    ths = [threading.Thread(target=one, args=(i, reps)) for i in range(cores)]
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
     ok = all(np.array_equal(wl.out[0][k].download(), results[0][k]) for k in range(3))
-    return cores * W * H / dt / 1e6, ok
+    # one picture on one thread (upsampled references already there): the single-thread figure
+    t1 = time.perf_counter()
+    one(0)
+    single = W * H / (time.perf_counter() - t1) / 1e6
+    return cores * reps * W * H / dt / 1e6, ok, single
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def iiwt_1080p(ctx, frames=8, steps=30):
+    """BASELINE config 2: 3-level DD(9,7) inverse wavelet of 1920x1080 s16 pictures (4:2:0; the
+    chroma coefficient frames are 960x544, padded to a multiple of 2^depth as the reference
+    does, schroparams.c:75-92).  Median of `steps` batches of `frames` pictures, HIP events."""
+    dims = [(1080, 1920), (544, 960), (544, 960)]
+    pairs = []
+    for f in range(frames):
+        for k, (h, w) in enumerate(dims):
+            pairs.append((ctx.upload(coeff_plane(h, w, 300 + 3 * f + k)), ctx.plane(h, w, np.int16)))
+    for _ in range(5):
+        ctx.iiwt_batch(pairs, DEPTH, FILTER)
+    ts = []
+    for _ in range(steps):
+        ctx.timer_begin()
+        ctx.iiwt_batch(pairs, DEPTH, FILTER)
+        ts.append(ctx.timer_end())
+    for a, b in pairs:
+        a.free()
+        b.free()
+    ms = float(np.median(ts))
+    samples = frames * sum(h * w for h, w in dims)
+    return {"workload": "3-level DD(9,7) IIWT, %d x 1920x1080 4:2:0 s16 per launch set" % frames,
+            "median_ms": round(ms, 4), "Mpix_per_s": round(frames * 1920 * 1080 / ms / 1e3, 1),
+            "alg_GBs": round(4 * samples / (ms * 1e-3) / 1e9, 1),
+            "frac_of_8TBs": round(4 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def pcie_inclusive(wl, steps=3):
+    """The same step with the host hand-over in it: coefficient frames and motion vectors go up
+    (dense s16 coefficients: what a core-syntax decoder without device-side dequantisation
+    uploads), the u8 pictures come down; pageable host memory, one queue."""
+    c, b = wl.ctx, wl.sets[0]
+    c.select_queue(0)
+    c.synchronize()
+    h2d = sum(co.nbytes for cf in b.coeff_np for co in cf) + sum(m.nbytes for m in b.mv_np)
+    d2h = sum(o.nbytes for of in b.out for o in of)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n = 0
+        for f in range(wl.frames):
+            for k in range(3):
+                b.iwt_pairs[n][0].upload(b.coeff_np[f][k])
+                n += 1
+        for f in range(wl.frames):
+            b.mv_dev[f].upload(np.ascontiguousarray(b.mv_np[f]).view(np.uint8).reshape(1, -1))
+        c.upsample_batch(b.up_pairs)
+        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
+        c.obmc_batch(b.obmc_jobs)
+        for of in b.out:
+            for o in of:
+                o.download()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 3), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
+            "h2d_MB": round(h2d / 1e6, 1), "d2h_MB": round(d2h / 1e6, 1),
+            "host_GBs": round((h2d + d2h) / dt / 1e9, 1),
+            "note": "pageable host buffers, synchronous 2-D copies, one queue; never `value`"}
 
 
 def free_port():
@@ -188,9 +270,10 @@ def main():
                     help="picture batches in flight per GPU (2: OBMC of one beside the wavelet of the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
-    ap.add_argument("--profile-every", type=int, default=4,
-                    help="bracket the launches of every n-th timed step with HIP events (an event "
-                         "pair costs ~8 us per launch, 5 %% of a step if every launch is bracketed)")
+    ap.add_argument("--profile-every", type=int, default=10,
+                    help="bracket the launches of every n-th timed step with HIP events; such a step "
+                         "runs alone on the device (no other batch beside it), so a kernel's duration "
+                         "is its own")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -239,7 +322,7 @@ def main():
         sample = i % max(args.profile_every, 1) == 0
         ctx.profile_enable(sample)
         profiled_steps += sample
-        wl.step()
+        wl.step(alone=sample)
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -311,13 +394,28 @@ def main():
                          "avg_launch_ms": round(d_avg, 4)},
             "kernels": kernels,
         }
+        if world == 1:
+            # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
+            out["iiwt_1080p"] = iiwt_1080p(ctx)
+            out["pcie_inclusive"] = pcie_inclusive(wl)
+            # one batch at a time on one queue, every step timed by itself: median
+            wl.queues = 1
+            ts = []
+            for _ in range(30):
+                ctx.timer_begin()
+                wl.step()
+                ts.append(ctx.timer_end())
+            out["one_batch_in_flight"] = {"median_ms_per_step": round(float(np.median(ts)), 4),
+                                          "Mpix_per_s": round(args.frames * W * H / float(np.median(ts)) / 1e3, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or min(8, os.cpu_count() or 1)
-            v, ok = cpu_baseline(wl, cores)
+            cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share
+            v, ok, single = cpu_baseline(wl, cores)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpix/s", "cores": cores,
-                                   "kind": "port",
-                                   "sample": "%d pictures (one per thread) of the same workload + the "
-                                   "two reference upsamples, oracle/ C port, gcc -O3" % cores}
+                                   "kind": "port", "single_thread": round(single, 2),
+                                   "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+                                   "sample": "%d pictures (%d threads x 10, one picture per thread at a "
+                                   "time) of the same workload + the two reference upsamples, oracle/ C "
+                                   "port, gcc -O3" % (10 * cores, cores)}
             out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):

@@ -357,9 +357,55 @@ int schro_hip_obmc_batch (SchroHipContext * ctx,
 
 /* ---- frame layer: the reference's stage boundary ------------------------- */
 
-/* Field-for-field SchroFrameData (schroframe.h:58-67) */
+/* The structs of this layer are LAYOUT-IDENTICAL to the reference's (same members, same
+ * order, same offsets on LP64): a SchroFrame * / SchroParams * / SchroMotion * /
+ * SchroMemoryDomain * of schroedinger 1.0.11 can be passed where this header says
+ * SchroHipFrame * / SchroHipParams * / SchroHipMotion * / SchroHipMemoryDomain *.  The offsets
+ * below were recorded from the reference's own headers by scripts/ref_layout.py
+ * (tests/golden/ref_layout.json) and are pinned here by _Static_assert; where the
+ * reference's headers are present, tests/c/layout_check.c compares member by member. */
+
+#define SCHRO_HIP_FRAME_CACHE_SIZE 32   /* SCHRO_FRAME_CACHE_SIZE, schroframe.h:56 */
+#define SCHRO_HIP_LIMIT_TRANSFORM_DEPTH 6       /* schrolimits.h:50 */
+#define SCHRO_HIP_LIMIT_BLOCK_SIZE 64   /* schrolimits.h:67 */
+#define SCHRO_HIP_MEMORY_DOMAIN_SLOTS 1000      /* schrodomain.h:11 */
+/* schrodomain.h:34-36 defines CPU 0x1, CUDA 0x2, OPENGL 0x4; the next free bit */
+#define SCHRO_MEMORY_DOMAIN_HIP 0x0008
+
+/* SchroMemoryDomain (schrodomain.h:13-28): the reference's slot cache
+ * (schro_memory_domain_alloc, schrodomain.c:58-137) calls alloc / free of this table, so
+ * schro_frame_new_and_alloc (domain, ...) (schroframe.c:172-188) hands out device frames
+ * when `domain` came from schro_memory_domain_new_hip.  alloc / free take no domain argument
+ * (the reference's signature): they use the HIP domain of the calling thread's current
+ * device.  The members after `slots` are private to this library. */
+typedef struct _SchroHipMemoryDomain {
+  void *mutex;                  /* SchroMutex *: the reference host creates and owns it */
+  unsigned int flags;           /* SCHRO_MEMORY_DOMAIN_HIP */
+  void *(*alloc) (int size);
+  void *(*alloc_2d) (int depth, int width, int height);
+  void (*free) (void *ptr, int size);
+  struct {
+    unsigned int flags;
+    void *ptr;
+    int size;
+    void *priv;
+  } slots[SCHRO_HIP_MEMORY_DOMAIN_SLOTS];
+  /* -- end of the reference's struct -- */
+  SchroHipContext *ctx;
+} SchroHipMemoryDomain;
+
+/* schro_memory_domain_new_cuda (schrocuda.h:9) replacement: a context on `device` (its queues,
+ * caches) behind a SchroMemoryDomain-shaped handle.  schro_hip_domain_context gives the context
+ * for the plane-layer calls; schro_memory_domain_free_hip releases both. */
+SchroHipMemoryDomain *schro_memory_domain_new_hip (int device);
+void schro_memory_domain_free_hip (SchroHipMemoryDomain * domain);
+SchroHipContext *schro_hip_domain_context (SchroHipMemoryDomain * domain);
+/* the domain of a context made with schro_hip_context_new */
+SchroHipMemoryDomain *schro_hip_context_domain (SchroHipContext * ctx);
+
+/* SchroFrameData (schroframe.h:58-67) */
 typedef struct {
-  int format;
+  int format;                   /* SchroFrameFormat */
   void *data;
   int stride;
   int width;
@@ -369,22 +415,166 @@ typedef struct {
   int v_shift;
 } SchroHipFrameData;
 
-/* The part of SchroFrame (schroframe.h:69-94) this boundary reads.  Device
- * frames come from schro_hip_frame_new_and_alloc; host frames are views the
- * caller fills from its SchroFrame. */
-typedef struct {
+/* SchroFrame (schroframe.h:69-94).  domain == NULL: host memory; a HIP domain: `data` of
+ * every component is a device pointer.  An upsampled device frame (is_upsampled) holds the
+ * tiled half-pel images in its components and keeps its integer-pel source frame in
+ * virt_frame1. */
+typedef struct _SchroHipFrame SchroHipFrame;
+struct _SchroHipFrame {
   int refcount;
-  SchroHipContext *domain;      /* NULL: host memory */
+  void (*free) (SchroHipFrame * frame, void *priv);
+  SchroHipMemoryDomain *domain;
   void *regions[3];
+  void *priv;
+
   int format;
   int width;
   int height;
+
   SchroHipFrameData components[3];
+
+  int is_virtual;
+  int cached_lines[3][SCHRO_HIP_FRAME_CACHE_SIZE];
+  SchroHipFrame *virt_frame1;
+  SchroHipFrame *virt_frame2;
+  void (*render_line) (SchroHipFrame * frame, void *dest, int component, int i);
+  void *virt_priv;
+  void *virt_priv2;
+
   int extension;
-  int is_upsampled;             /* device: components hold half-pel images */
-  int upsample_done;
-  void *priv;                   /* device: the integer-pel source frame of an upsampled frame */
-} SchroHipFrame;
+  int cache_offset[3];
+  int is_upsampled;
+  int upsample_done;            /* schro_bool */
+};
+
+/* SchroGlobalMotion, SchroParams (schroparams.h:18-74) */
+typedef struct {
+  int b0, b1, a_exp, a00, a01, a10, a11, c_exp, c0, c1;
+} SchroHipGlobalMotion;
+
+typedef struct {
+  void *video_format;           /* SchroVideoFormat * */
+  int is_noarith;
+  int wavelet_filter_index;
+  int transform_depth;
+  int horiz_codeblocks[SCHRO_HIP_LIMIT_TRANSFORM_DEPTH + 1];
+  int vert_codeblocks[SCHRO_HIP_LIMIT_TRANSFORM_DEPTH + 1];
+  int codeblock_mode_index;
+  int num_refs;
+  int have_global_motion;
+  int xblen_luma;
+  int yblen_luma;
+  int xbsep_luma;
+  int ybsep_luma;
+  int mv_precision;
+  SchroHipGlobalMotion global_motion[2];
+  int picture_pred_mode;
+  int picture_weight_bits;
+  int picture_weight_1;
+  int picture_weight_2;
+  int is_lowdelay;
+  int n_horiz_slices;
+  int n_vert_slices;
+  int slice_bytes_num;
+  int slice_bytes_denom;
+  int quant_matrix[3 * SCHRO_HIP_LIMIT_TRANSFORM_DEPTH + 1];
+  int iwt_chroma_width;
+  int iwt_chroma_height;
+  int iwt_luma_width;
+  int iwt_luma_height;
+  int x_num_blocks;
+  int y_num_blocks;
+  int x_offset;
+  int y_offset;
+} SchroHipParams;
+
+/* SchroMotion (schromotion.h:53-86); schro_motion_render_hip reads src1, src2,
+ * motion_vectors and params, as schro_motion_render_u8 does (schromotion8.c:700-730) */
+typedef struct {
+  SchroHipFrame *src1;          /* device; plain u8 if mv_precision == 0 else upsampled */
+  SchroHipFrame *src2;          /* may be NULL */
+  void *motion_vectors;         /* HOST SchroMotionVector array (schromotion.h:20-37) */
+  SchroHipParams *params;
+  int ref_weight_precision;
+  int ref1_weight;
+  int ref2_weight;
+  int mv_precision;
+  int xoffset;
+  int yoffset;
+  int xbsep;
+  int ybsep;
+  int xblen;
+  int yblen;
+  SchroHipFrameData block;
+  SchroHipFrameData alloc_block;
+  SchroHipFrameData obmc_weight;
+  SchroHipFrameData alloc_block_ref[2];
+  SchroHipFrameData block_ref[2];
+  int weight_x[SCHRO_HIP_LIMIT_BLOCK_SIZE];
+  int weight_y[SCHRO_HIP_LIMIT_BLOCK_SIZE];
+  int width;
+  int height;
+  int max_fast_x;
+  int max_fast_y;
+  int simple_weight;            /* schro_bool */
+  int oneref_noscale;
+} SchroHipMotion;
+
+#if defined(__LP64__) || defined(_LP64)
+#include <stddef.h>
+#ifdef __cplusplus
+#define SCHRO_HIP_LAYOUT(t, m, off) static_assert (offsetof (t, m) == (off), #t "." #m)
+#define SCHRO_HIP_SIZE(t, n) static_assert (sizeof (t) == (n), #t)
+#else
+#define SCHRO_HIP_LAYOUT(t, m, off) _Static_assert (offsetof (t, m) == (off), #t "." #m)
+#define SCHRO_HIP_SIZE(t, n) _Static_assert (sizeof (t) == (n), #t)
+#endif
+/* numbers: tests/golden/ref_layout.json (scripts/ref_layout.py, from the reference's headers) */
+SCHRO_HIP_SIZE (SchroHipFrameData, 40);
+SCHRO_HIP_LAYOUT (SchroHipFrameData, data, 8);
+SCHRO_HIP_LAYOUT (SchroHipFrameData, stride, 16);
+SCHRO_HIP_LAYOUT (SchroHipFrameData, v_shift, 36);
+SCHRO_HIP_SIZE (SchroHipFrame, 648);
+SCHRO_HIP_LAYOUT (SchroHipFrame, free, 8);
+SCHRO_HIP_LAYOUT (SchroHipFrame, domain, 16);
+SCHRO_HIP_LAYOUT (SchroHipFrame, regions, 24);
+SCHRO_HIP_LAYOUT (SchroHipFrame, priv, 48);
+SCHRO_HIP_LAYOUT (SchroHipFrame, format, 56);
+SCHRO_HIP_LAYOUT (SchroHipFrame, width, 60);
+SCHRO_HIP_LAYOUT (SchroHipFrame, height, 64);
+SCHRO_HIP_LAYOUT (SchroHipFrame, components, 72);
+SCHRO_HIP_LAYOUT (SchroHipFrame, is_virtual, 192);
+SCHRO_HIP_LAYOUT (SchroHipFrame, cached_lines, 196);
+SCHRO_HIP_LAYOUT (SchroHipFrame, virt_frame1, 584);
+SCHRO_HIP_LAYOUT (SchroHipFrame, render_line, 600);
+SCHRO_HIP_LAYOUT (SchroHipFrame, extension, 624);
+SCHRO_HIP_LAYOUT (SchroHipFrame, is_upsampled, 640);
+SCHRO_HIP_LAYOUT (SchroHipFrame, upsample_done, 644);
+SCHRO_HIP_SIZE (SchroHipParams, 336);
+SCHRO_HIP_LAYOUT (SchroHipParams, wavelet_filter_index, 12);
+SCHRO_HIP_LAYOUT (SchroHipParams, transform_depth, 16);
+SCHRO_HIP_LAYOUT (SchroHipParams, num_refs, 80);
+SCHRO_HIP_LAYOUT (SchroHipParams, have_global_motion, 84);
+SCHRO_HIP_LAYOUT (SchroHipParams, xblen_luma, 88);
+SCHRO_HIP_LAYOUT (SchroHipParams, mv_precision, 104);
+SCHRO_HIP_LAYOUT (SchroHipParams, picture_weight_bits, 192);
+SCHRO_HIP_LAYOUT (SchroHipParams, is_lowdelay, 204);
+SCHRO_HIP_LAYOUT (SchroHipParams, slice_bytes_num, 216);
+SCHRO_HIP_LAYOUT (SchroHipParams, quant_matrix, 224);
+SCHRO_HIP_LAYOUT (SchroHipParams, iwt_chroma_width, 300);
+SCHRO_HIP_LAYOUT (SchroHipParams, iwt_luma_width, 308);
+SCHRO_HIP_LAYOUT (SchroHipParams, x_num_blocks, 316);
+SCHRO_HIP_LAYOUT (SchroHipParams, y_offset, 328);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, flags, 8);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, alloc, 16);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, alloc_2d, 24);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, free, 32);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, slots, 40);
+SCHRO_HIP_LAYOUT (SchroHipMemoryDomain, ctx, 32040);
+SCHRO_HIP_LAYOUT (SchroHipMotion, motion_vectors, 16);
+SCHRO_HIP_LAYOUT (SchroHipMotion, params, 24);
+SCHRO_HIP_LAYOUT (SchroHipMotion, ref_weight_precision, 32);
+#endif
 
 /* schro_frame_new_and_alloc (schroframe.c:60-191) on the device domain:
  * planar Y,U,V, stride = round-up-64 (width * bytes); upsampled == 1
@@ -396,28 +586,14 @@ void schro_hip_frame_unref (SchroHipFrame * frame);
 
 /* schro_frame_to_gpu / schro_gpuframe_to_cpu (schrogpuframe.h:17-18):
  * whole-frame copies, all three components, synchronous on return. */
-int schro_frame_to_hip (SchroHipFrame * dest, const SchroHipFrame * src);
-int schro_hipframe_to_cpu (SchroHipFrame * dest, const SchroHipFrame * src);
+int schro_frame_to_hip (SchroHipFrame * dest, SchroHipFrame * src);
+int schro_hipframe_to_cpu (SchroHipFrame * dest, SchroHipFrame * src);
 
-/* The SchroParams fields read at this boundary (schroparams.h:31-74) */
-typedef struct {
-  int wavelet_filter_index;
-  int transform_depth;
-  int iwt_luma_width, iwt_luma_height;
-  int iwt_chroma_width, iwt_chroma_height;
-  int num_refs;
-  int xblen_luma, yblen_luma, xbsep_luma, ybsep_luma;
-  int mv_precision;
-  int picture_weight_bits, picture_weight_1, picture_weight_2;
-  int x_num_blocks, y_num_blocks;
-  int have_global_motion;
-} SchroHipParams;
-
-/* schro_frame_inverse_iwt_transform_cuda (schrocuda.h:13-14) replacement:
- * upload transform_frame (host) or use it in place (device), run the
- * multi-level inverse transform into `frame` (device, iwt-padded size). */
+/* schro_frame_inverse_iwt_transform_cuda (schrocuda.h:13-14) replacement, same arguments:
+ * upload transform_frame (host) or use it where it is (device), run the multi-level inverse
+ * transform into `frame` (device, iwt-padded size). */
 int schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
-    const SchroHipFrame * transform_frame, const SchroHipParams * params);
+    SchroHipFrame * transform_frame, SchroHipParams * params);
 
 /* schro_decoder_decode_lowdelay_transform_data (picture), schrolowdelay.c:746-762, with
  * picture->transform_frame on the device: `slices` is picture->lowdelay_buffer->data (host),
@@ -427,29 +603,20 @@ int schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame,
 
 /* schro_upsampled_gpuframe_upsample (schrogpuframe.h:27) replacement:
  * dest (device, is_upsampled) <- half-pel images of src (device u8). */
-int schro_upsampled_hipframe_upsample (SchroHipFrame * dest,
-    const SchroHipFrame * src);
+int schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src);
 
-/* SchroMotion (schromotion.h:53-86) as read by schro_motion_render */
-typedef struct {
-  const SchroHipFrame *src1;    /* device; plain u8 if mv_precision==0 else upsampled */
-  const SchroHipFrame *src2;    /* may be NULL */
-  const void *motion_vectors;   /* HOST SchroMotionVector array */
-  const SchroHipParams *params;
-} SchroHipMotion;
+/* schro_motion_render (motion, dest, addframe, add, output_frame) (schromotion.h:100, as
+ * x_render_motion calls it, schrodecoder.c:1905-1935) replacement, same arguments: add must
+ * be TRUE, `dest` (the CPU path's s16 scratch frame) is not used and may be NULL.  addframe:
+ * device s16/s32 residual (picture->frame), output_frame: device u8.  Global motion is not
+ * supported (the reference routes it to a different renderer, schromotion.c:113-118)
+ * -> SCHRO_HIP_EUNSUPPORTED. */
+int schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest,
+    SchroHipFrame * addframe, int add, SchroHipFrame * output_frame);
 
-/* schro_motion_render (motion, dest, addframe, add=TRUE, output_frame)
- * (schromotion.h:100) replacement.  addframe: device s16/s32 residual
- * (picture->frame), output_frame: device u8.  Global motion is not
- * supported (the reference routes it to a different renderer,
- * schromotion.c:113-118) -> SCHRO_HIP_EUNSUPPORTED. */
-int schro_motion_render_hip (const SchroHipMotion * motion,
-    const SchroHipFrame * addframe, SchroHipFrame * output_frame);
-
-/* schro_gpuframe_convert (schrogpuframe.h:20) replacement for the two
- * conversions the decode path performs: s16/s32 -> u8 (+128, clamp, crop)
- * and u8 -> u8 copy. */
-int schro_hipframe_convert (SchroHipFrame * dest, const SchroHipFrame * src);
+/* schro_gpuframe_convert (schrogpuframe.h:20) replacement for the conversions the decode path
+ * performs: s16/s32 -> u8 (+128, clamp, crop), u8 -> u8 copy, u8 -> packed. */
+int schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,8 @@ EXPORTED_SYMBOLS = [
     "schro_hip_domain_alloc", "schro_hip_domain_free", "schro_hip_domain_bytes",
     "schro_hip_upload_2d", "schro_hip_download_2d", "schro_hip_memset",
     "schro_hip_synchronize", "schro_hip_stream",
+    "schro_memory_domain_new_hip", "schro_memory_domain_free_hip", "schro_hip_domain_context",
+    "schro_hip_context_domain",
     "schro_hip_context_select_queue", "schro_hip_context_queue", "schro_hip_queue_wait",
     "schro_hip_queue_mark", "schro_hip_queue_wait_mark",
     "schro_hip_timer_begin", "schro_hip_timer_end",
@@ -102,26 +104,50 @@ class FrameData(C.Structure):
 
 
 class Frame(C.Structure):
-    _fields_ = [("refcount", C.c_int), ("domain", C.c_void_p),
-                ("regions", C.c_void_p * 3),
-                ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
-                ("components", FrameData * 3),
-                ("extension", C.c_int), ("is_upsampled", C.c_int),
-                ("upsample_done", C.c_int), ("priv", C.c_void_p)]
+    """SchroHipFrame == SchroFrame (schroframe.h:69-94), member for member."""
+
+
+Frame._fields_ = [("refcount", C.c_int), ("free", C.c_void_p), ("domain", C.c_void_p),
+                  ("regions", C.c_void_p * 3), ("priv", C.c_void_p),
+                  ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                  ("components", FrameData * 3),
+                  ("is_virtual", C.c_int), ("cached_lines", (C.c_int * 32) * 3),
+                  ("virt_frame1", C.POINTER(Frame)), ("virt_frame2", C.POINTER(Frame)),
+                  ("render_line", C.c_void_p), ("virt_priv", C.c_void_p), ("virt_priv2", C.c_void_p),
+                  ("extension", C.c_int), ("cache_offset", C.c_int * 3),
+                  ("is_upsampled", C.c_int), ("upsample_done", C.c_int)]
+
+
+class GlobalMotion(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("b0", "b1", "a_exp", "a00", "a01", "a10", "a11", "c_exp", "c0", "c1")]
 
 
 class Params(C.Structure):
-    _fields_ = [(n, C.c_int) for n in (
-        "wavelet_filter_index", "transform_depth",
-        "iwt_luma_width", "iwt_luma_height", "iwt_chroma_width", "iwt_chroma_height",
-        "num_refs", "xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma",
-        "mv_precision", "picture_weight_bits", "picture_weight_1", "picture_weight_2",
-        "x_num_blocks", "y_num_blocks", "have_global_motion")]
+    """SchroHipParams == SchroParams (schroparams.h:31-74)."""
+    _fields_ = ([("video_format", C.c_void_p), ("is_noarith", C.c_int), ("wavelet_filter_index", C.c_int),
+                 ("transform_depth", C.c_int), ("horiz_codeblocks", C.c_int * 7), ("vert_codeblocks", C.c_int * 7)]
+                + [(n, C.c_int) for n in ("codeblock_mode_index", "num_refs", "have_global_motion", "xblen_luma",
+                                          "yblen_luma", "xbsep_luma", "ybsep_luma", "mv_precision")]
+                + [("global_motion", GlobalMotion * 2)]
+                + [(n, C.c_int) for n in ("picture_pred_mode", "picture_weight_bits", "picture_weight_1",
+                                          "picture_weight_2", "is_lowdelay", "n_horiz_slices", "n_vert_slices",
+                                          "slice_bytes_num", "slice_bytes_denom")]
+                + [("quant_matrix", C.c_int * 19)]
+                + [(n, C.c_int) for n in ("iwt_chroma_width", "iwt_chroma_height", "iwt_luma_width",
+                                          "iwt_luma_height", "x_num_blocks", "y_num_blocks", "x_offset", "y_offset")])
 
 
 class Motion(C.Structure):
-    _fields_ = [("src1", C.POINTER(Frame)), ("src2", C.POINTER(Frame)),
-                ("motion_vectors", C.c_void_p), ("params", C.POINTER(Params))]
+    """SchroHipMotion == SchroMotion (schromotion.h:53-86)."""
+    _fields_ = ([("src1", C.POINTER(Frame)), ("src2", C.POINTER(Frame)),
+                 ("motion_vectors", C.c_void_p), ("params", C.POINTER(Params))]
+                + [(n, C.c_int) for n in ("ref_weight_precision", "ref1_weight", "ref2_weight", "mv_precision",
+                                          "xoffset", "yoffset", "xbsep", "ybsep", "xblen", "yblen")]
+                + [("block", FrameData), ("alloc_block", FrameData), ("obmc_weight", FrameData),
+                   ("alloc_block_ref", FrameData * 2), ("block_ref", FrameData * 2),
+                   ("weight_x", C.c_int * 64), ("weight_y", C.c_int * 64)]
+                + [(n, C.c_int) for n in ("width", "height", "max_fast_x", "max_fast_y", "simple_weight",
+                                          "oneref_noscale")])
 
 
 _lib = None
@@ -162,6 +188,14 @@ def load():
     L.schro_hip_synchronize.restype = i
     L.schro_hip_stream.argtypes = [vp]
     L.schro_hip_stream.restype = vp
+    L.schro_memory_domain_new_hip.argtypes = [i]
+    L.schro_memory_domain_new_hip.restype = vp
+    L.schro_memory_domain_free_hip.argtypes = [vp]
+    L.schro_memory_domain_free_hip.restype = None
+    L.schro_hip_domain_context.argtypes = [vp]
+    L.schro_hip_domain_context.restype = vp
+    L.schro_hip_context_domain.argtypes = [vp]
+    L.schro_hip_context_domain.restype = vp
     L.schro_hip_context_select_queue.argtypes = [vp, i]
     L.schro_hip_context_select_queue.restype = i
     L.schro_hip_context_queue.argtypes = [vp]
@@ -221,7 +255,8 @@ def load():
     L.schro_frame_inverse_iwt_transform_hip.restype = i
     L.schro_upsampled_hipframe_upsample.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
     L.schro_upsampled_hipframe_upsample.restype = i
-    L.schro_motion_render_hip.argtypes = [C.POINTER(Motion), C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_motion_render_hip.argtypes = [C.POINTER(Motion), C.POINTER(Frame), C.POINTER(Frame), i,
+                                          C.POINTER(Frame)]
     L.schro_motion_render_hip.restype = i
     L.schro_hipframe_convert.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
     L.schro_hipframe_convert.restype = i

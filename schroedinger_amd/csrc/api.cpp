@@ -168,6 +168,66 @@ schro_hip_set_abort_on_error (int enable)
   g_abort_on_error = enable;
 }
 
+// ---- the SchroMemoryDomain-shaped handle -------------------------------------------------------
+// alloc / free of the reference's table carry no domain argument (schrodomain.h:18-22), so they
+// resolve the domain from the calling thread's current device, as the reference's CUDA table
+// resolves its device from the CUDA runtime's current-device state.
+static constexpr int kMaxDevices = 64;
+static SchroHipMemoryDomain *g_domain_of_device[kMaxDevices];
+
+static SchroHipContext *
+current_device_context ()
+{
+  int dev = 0;
+  if (hipGetDevice (&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_domain_of_device[dev])
+    return nullptr;
+  return g_domain_of_device[dev]->ctx;
+}
+
+static void *
+domain_vt_alloc (int size)
+{
+  SchroHipContext *ctx = current_device_context ();
+  if (!ctx || size <= 0) {
+    set_error (SCHRO_HIP_EINVAL, "domain alloc (%d): no HIP domain on the current device", size);
+    return nullptr;
+  }
+  // plain allocation: the caller (schro_memory_domain_alloc, schrodomain.c:58-109) keeps its own
+  // slot cache on top of this table
+  void *p = nullptr;
+  if (hipMalloc (&p, (size_t) size) != hipSuccess) {
+    set_error (SCHRO_HIP_ENOMEM, "domain alloc: hipMalloc (%d) failed", size);
+    return nullptr;
+  }
+  return p;
+}
+
+static void *
+domain_vt_alloc_2d (int depth, int width, int height)
+{
+  // the reference's CUDA table returns a cudaArray for texture fetches here; this path has no
+  // textures (coordinate clamp in the kernels), so a 2-D block is a linear one
+  if (depth <= 0 || width <= 0 || height <= 0)
+    return nullptr;
+  return domain_vt_alloc (((depth + 7) / 8) * width * height);
+}
+
+static void
+domain_vt_free (void *ptr, int size)
+{
+  (void) size;
+  if (ptr)
+    (void) hipFree (ptr);
+}
+
+static SchroHipContext *
+frame_ctx (const SchroHipFrame * f)
+{
+  if (!f || !f->domain || !(f->domain->flags & SCHRO_MEMORY_DOMAIN_HIP))
+    return nullptr;
+  return f->domain->ctx;
+}
+
 SchroHipContext *
 schro_hip_context_new (int device)
 {
@@ -177,6 +237,12 @@ schro_hip_context_new (int device)
   }
   SchroHipContext *ctx = new SchroHipContext ();
   ctx->device = device;
+  ctx->domain = (SchroHipMemoryDomain *) calloc (1, sizeof (SchroHipMemoryDomain));
+  ctx->domain->flags = SCHRO_MEMORY_DOMAIN_HIP;
+  ctx->domain->alloc = domain_vt_alloc;
+  ctx->domain->alloc_2d = domain_vt_alloc_2d;
+  ctx->domain->free = domain_vt_free;
+  ctx->domain->ctx = ctx;
   ctx->domain_bytes = 0;
   for (int q = 0; q < SchroHipContext::kQueues; q++) {
     ctx->scratch_q[q] = nullptr;
@@ -208,10 +274,39 @@ schro_hip_context_new (int device)
   if (!ok) {
     set_error (SCHRO_HIP_EDEVICE, "context creation failed on device %d: %s", device,
         hipGetErrorString (hipGetLastError ()));
+    free (ctx->domain);
     delete ctx;
     return nullptr;
   }
+  if (device >= 0 && device < kMaxDevices && !g_domain_of_device[device])
+    g_domain_of_device[device] = ctx->domain;   // the table's alloc / free on this device
   return ctx;
+}
+
+SchroHipMemoryDomain *
+schro_memory_domain_new_hip (int device)
+{
+  SchroHipContext *ctx = schro_hip_context_new (device);
+  return ctx ? ctx->domain : nullptr;
+}
+
+void
+schro_memory_domain_free_hip (SchroHipMemoryDomain * domain)
+{
+  if (domain && (domain->flags & SCHRO_MEMORY_DOMAIN_HIP))
+    schro_hip_context_free (domain->ctx);
+}
+
+SchroHipContext *
+schro_hip_domain_context (SchroHipMemoryDomain * domain)
+{
+  return domain && (domain->flags & SCHRO_MEMORY_DOMAIN_HIP) ? domain->ctx : nullptr;
+}
+
+SchroHipMemoryDomain *
+schro_hip_context_domain (SchroHipContext * ctx)
+{
+  return ctx ? ctx->domain : nullptr;
 }
 
 void
@@ -249,6 +344,9 @@ schro_hip_context_free (SchroHipContext * ctx)
   }
   (void) hipEventDestroy (ctx->ev_begin);
   (void) hipEventDestroy (ctx->ev_end);
+  if (ctx->device >= 0 && ctx->device < kMaxDevices && g_domain_of_device[ctx->device] == ctx->domain)
+    g_domain_of_device[ctx->device] = nullptr;
+  free (ctx->domain);
   for (int m = 0; m < SchroHipContext::kMarks; m++)
     if (ctx->marks[m])
       (void) hipEventDestroy (ctx->marks[m]);
@@ -1285,7 +1383,7 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     // packed output frame: one component (schroframe.c:81-99)
     SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
     f->refcount = 1;
-    f->domain = ctx;
+    f->domain = ctx->domain;
     f->format = format;
     f->width = width;
     f->height = height;
@@ -1310,7 +1408,7 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
   }
   SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
   f->refcount = 1;
-  f->domain = ctx;
+  f->domain = ctx->domain;
   f->format = format;
   f->width = width;
   f->height = height;
@@ -1361,8 +1459,8 @@ schro_hip_frame_unref (SchroHipFrame * frame)
     return;
   if (--frame->refcount > 0)
     return;
-  if (frame->domain && frame->regions[0])
-    schro_hip_domain_free (frame->domain, frame->regions[0]);
+  if (frame_ctx (frame) && frame->regions[0])
+    schro_hip_domain_free (frame_ctx (frame), frame->regions[0]);
   free (frame);
 }
 
@@ -1399,28 +1497,28 @@ copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * s
 }
 
 int
-schro_frame_to_hip (SchroHipFrame * dest, const SchroHipFrame * src)
+schro_frame_to_hip (SchroHipFrame * dest, SchroHipFrame * src)
 {
-  SCHRO_HIP_REQUIRE (dest && src && dest->domain && !src->domain,
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && !frame_ctx (src),
       "frame_to_hip: dest must be a device frame and src a host frame");
-  return copy_frame (dest->domain, dest, src, hipMemcpyHostToDevice);
+  return copy_frame (frame_ctx (dest), dest, src, hipMemcpyHostToDevice);
 }
 
 int
-schro_hipframe_to_cpu (SchroHipFrame * dest, const SchroHipFrame * src)
+schro_hipframe_to_cpu (SchroHipFrame * dest, SchroHipFrame * src)
 {
-  SCHRO_HIP_REQUIRE (dest && src && src->domain && !dest->domain,
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (src) && !frame_ctx (dest),
       "hipframe_to_cpu: src must be a device frame and dest a host frame");
-  return copy_frame (src->domain, dest, src, hipMemcpyDeviceToHost);
+  return copy_frame (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
 }
 
 int
 schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
-    const SchroHipFrame * transform_frame, const SchroHipParams * params)
+    SchroHipFrame * transform_frame, SchroHipParams * params)
 {
-  SCHRO_HIP_REQUIRE (frame && transform_frame && params && frame->domain,
+  SCHRO_HIP_REQUIRE (frame && transform_frame && params && frame_ctx (frame),
       "inverse_iwt_transform: bad arguments");
-  SchroHipContext *ctx = frame->domain;
+  SchroHipContext *ctx = frame_ctx (frame);
   int bpp = format_bpp (frame->format);
   SCHRO_HIP_REQUIRE ((bpp == 2 || bpp == 4) && format_bpp (transform_frame->format) == bpp,
       "inverse_iwt_transform: frames must both be s16 or both s32");
@@ -1428,8 +1526,8 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
   // host coefficients are staged on the device first (the H2D step of
   // schro_frame_inverse_iwt_transform_cuda, schrogpuframe.c:584-599)
   SchroHipFrame *staged = nullptr;
-  const SchroHipFrame *src = transform_frame;
-  if (!transform_frame->domain) {
+  SchroHipFrame *src = transform_frame;
+  if (!frame_ctx (transform_frame)) {
     staged = schro_hip_frame_new_and_alloc (ctx, transform_frame->format, transform_frame->width,
         transform_frame->height, 0);
     if (!staged)
@@ -1469,9 +1567,9 @@ int
 schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const void *slices,
     size_t slices_bytes, const SchroHipLowDelayParams * params)
 {
-  SCHRO_HIP_REQUIRE (transform_frame && transform_frame->domain && slices && params,
+  SCHRO_HIP_REQUIRE (transform_frame && frame_ctx (transform_frame) && slices && params,
       "decode_lowdelay_transform_data: bad arguments");
-  SchroHipContext *ctx = transform_frame->domain;
+  SchroHipContext *ctx = frame_ctx (transform_frame);
   const int bpp = format_bpp (transform_frame->format);
   SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "decode_lowdelay_transform_data: the frame must be s16 or s32");
   for (int k = 0; k < 3; k++)
@@ -1501,9 +1599,9 @@ schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const
 }
 
 int
-schro_upsampled_hipframe_upsample (SchroHipFrame * dest, const SchroHipFrame * src)
+schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
 {
-  SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && src->domain == dest->domain
       && dest->is_upsampled && !src->is_upsampled && format_bpp (src->format) == 1,
       "upsampled_hipframe_upsample: bad arguments");
   if (dest->upsample_done)      // schroframe.c:2006-2009
@@ -1520,25 +1618,27 @@ schro_upsampled_hipframe_upsample (SchroHipFrame * dest, const SchroHipFrame * s
     planes[k].width = src->components[k].width;
     planes[k].height = src->components[k].height;
   }
-  int r = schro_hip_upsample_batch (dest->domain, planes, 3);
+  int r = schro_hip_upsample_batch (frame_ctx (dest), planes, 3);
   if (!r)
-    r = schro_hip_synchronize (dest->domain);
+    r = schro_hip_synchronize (frame_ctx (dest));
   if (!r)
     dest->upsample_done = 1;
   return r;
 }
 
 int
-schro_motion_render_hip (const SchroHipMotion * motion, const SchroHipFrame * addframe,
+schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHipFrame * addframe, int add,
     SchroHipFrame * output_frame)
 {
+  (void) dest;                  // the CPU path's s16 scratch frame: the accumulator lives in LDS here
   SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors && addframe
-      && output_frame && output_frame->domain && addframe->domain == output_frame->domain,
+      && output_frame && frame_ctx (output_frame) && addframe->domain == output_frame->domain,
       "motion_render: bad arguments");
+  SCHRO_HIP_REQUIRE (add, "motion_render: only the fused form (add = TRUE, output_frame) is exact on this domain");
   const SchroHipParams *p = motion->params;
   if (p->have_global_motion)    // schromotion.c:113-118 routes this to another renderer
     return set_error (SCHRO_HIP_EUNSUPPORTED, "motion_render: global motion is not supported");
-  SchroHipContext *ctx = output_frame->domain;
+  SchroHipContext *ctx = frame_ctx (output_frame);
   const int upsampled = p->mv_precision > 0;
   SCHRO_HIP_REQUIRE (motion->src1->is_upsampled == upsampled
       && (!motion->src2 || motion->src2->is_upsampled == upsampled),
@@ -1600,11 +1700,11 @@ schro_motion_render_hip (const SchroHipMotion * motion, const SchroHipFrame * ad
 }
 
 int
-schro_hipframe_convert (SchroHipFrame * dest, const SchroHipFrame * src)
+schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
 {
-  SCHRO_HIP_REQUIRE (dest && src && dest->domain && src->domain == dest->domain,
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && src->domain == dest->domain,
       "hipframe_convert: both frames must live in the same device domain");
-  SchroHipContext *ctx = dest->domain;
+  SchroHipContext *ctx = frame_ctx (dest);
   if (dest->format & 0x100) {
     // copy-out into a packed frame (schroframe.c:878-899, 943-955): u8 planar sources only
     SCHRO_HIP_REQUIRE (!(src->format & 0x100) && format_bpp (src->format) == 1,

@@ -279,6 +279,7 @@ void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y
 
 struct SchroHipContext {
   int device;
+  SchroHipMemoryDomain *domain; // the SchroMemoryDomain-shaped handle of this context
   // Two in-order queues (HIP streams) per context: the pixel path of one batch of pictures is
   // HBM-bound in the inverse wavelet and issue-bound in OBMC, so a decoder that runs batch k's
   // OBMC on one queue and batch k+1's wavelet + upsample on the other keeps both busy.  Calls

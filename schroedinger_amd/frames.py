@@ -1,7 +1,7 @@
 """SchroFrame-shaped views for the stage-level C ABI (include/schro_hip.h, frame layer).
 
-HostFrame wraps three numpy planes as a SchroHipFrame with domain == NULL (what a
-patched schrodecoder.c would fill from its SchroFrame); DeviceFrame owns a frame
+SchroHipFrame IS SchroFrame (same layout, tests/test_ref_layout.py): HostFrame wraps three numpy
+planes as a frame with domain == NULL (a decoder's host SchroFrame); DeviceFrame owns a frame
 allocated by schro_hip_frame_new_and_alloc in the context's memory domain."""
 import ctypes as C
 

@@ -1,0 +1,65 @@
+"""A compiled C program (tests/c/stage_replay.c) calls the frame layer the way a patched
+schrodecoder.c would -- SchroMemoryDomain-shaped HIP domain, SchroFrame / SchroParams /
+SchroMotion-shaped structs, stages in the decoder's order -- and its decoded picture must equal
+the oracle's.  (the boundary needs a C caller, not only ctypes.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "c", "_build", "stage_replay")
+
+
+def build_harness():
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "c")])
+    return EXE
+
+
+@pytest.mark.parametrize("w,h,chroma,prec,blk,filt,depth", [
+    (176, 144, (1, 1), 2, (12, 8), 0, 3),       # CIF-ish 4:2:0, quarter-pel, DD(9,7)
+    (320, 240, (1, 0), 0, (12, 8), 1, 4),       # the test stream's shape: 4:2:2, full-pel, LeGall depth 4
+    (200, 120, (0, 0), 3, (16, 12), 3, 2),      # 4:4:4, eighth-pel, Haar
+])
+def test_c_caller_decodes_an_inter_picture(tmp_path, w, h, chroma, prec, blk, filt, depth):
+    exe = build_harness()
+    hs, vs = chroma
+    P = synth.motion_params(w, h, blk[0], blk[1], prec, (1, 1, 1), chroma)
+    cw, ch = -(-w >> hs), -(-h >> vs)
+    up = lambda v: -(-v // (1 << depth)) * (1 << depth)
+    iw = [(up(h), up(w)), (up(ch), up(cw)), (up(ch), up(cw))]
+    pd = [(h, w), (ch, cw), (ch, cw)]
+    resid = [synth.image_s(ih, iwd, np.int16, seed=3 + k) for k, (ih, iwd) in enumerate(iw)]
+    coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+    refs = [[synth.picture_u8(ph, pw, seed=11 + 10 * r + k) for k, (ph, pw) in enumerate(pd)] for r in range(2)]
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 20 << prec, seed=5)
+    d = tmp_path
+    (d / "params.txt").write_text(" ".join(str(v) for v in [
+        w, h, hs, vs, iw[0][1], iw[0][0], iw[1][1], iw[1][0], depth, filt, prec, blk[0], blk[0], blk[1], blk[1],
+        P["x_num_blocks"], P["y_num_blocks"]]))
+    np.concatenate([c.ravel() for c in coeffs]).tofile(d / "coeffs.bin")
+    for r in range(2):
+        np.concatenate([p.ravel() for p in refs[r]]).tofile(d / ("ref%d.bin" % r))
+    mv.tofile(d / "mvs.bin")
+    p = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = np.fromfile(d / "out.bin", np.uint8)
+    res = np.fromfile(d / "residual.bin", np.int16)
+    o = r0 = 0
+    for k, ((ph, pw), (ih, iwd)) in enumerate(zip(pd, iw)):
+        want_res = O.inverse_iwt(coeffs[k], depth, filt)
+        got_res = res[r0:r0 + ih * iwd].reshape(ih, iwd)
+        r0 += ih * iwd
+        assert np.array_equal(got_res, want_res), "component %d residual" % k
+        want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs[0][k], upsample=prec > 0),
+                               O.UpComp(refs[1][k], upsample=prec > 0), want_res, pw, ph)
+        got = out[o:o + ph * pw].reshape(ph, pw)
+        o += ph * pw
+        assert np.array_equal(got, want), "component %d picture" % k

@@ -70,7 +70,7 @@ def test_inter_picture_through_stage_calls(ctx, hs, vs, prec, filt, depth):
     # x_render_motion: schro_motion_render (motion, mc_tmp, frame, add=TRUE, ref_output_frame)
     out = frames.DeviceFrame(ctx, fmt8, w, h)
     motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
-    sa.check(lib.schro_motion_render_hip(C.byref(motion), frame.ptr(), out.ptr()))
+    sa.check(lib.schro_motion_render_hip(C.byref(motion), None, frame.ptr(), 1, out.ptr()))
     got = out.download()
     for k, (ph, pw) in enumerate(pd):
         want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
@@ -120,9 +120,9 @@ def test_error_behaviour(ctx):
     res = frames.DeviceFrame(ctx, sa.FORMAT_S16_420, 64, 48)
     out = frames.DeviceFrame(ctx, sa.FORMAT_U8_420, 64, 48)
     motion = _lib.Motion(ref.ptr(), None, mv.ctypes.data, C.pointer(params))
-    assert lib.schro_motion_render_hip(C.byref(motion), res.ptr(), out.ptr()) == -4   # global motion
+    assert lib.schro_motion_render_hip(C.byref(motion), None, res.ptr(), 1, out.ptr()) == -4   # global motion
     params.have_global_motion = 0
-    assert lib.schro_motion_render_hip(C.byref(motion), res.ptr(), out.ptr()) == -1   # plain ref at qpel
+    assert lib.schro_motion_render_hip(C.byref(motion), None, res.ptr(), 1, out.ptr()) == -1   # plain ref at qpel
     assert b"upsampled" in lib.schro_hip_last_error()
     assert lib.schro_hipframe_convert(res.ptr(), out.ptr()) == -4                       # u8 -> s16 not on path
     frames.DeviceFrame(ctx, sa.FORMAT_U8_420, 64, 48).unref()
