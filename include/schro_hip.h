@@ -131,7 +131,8 @@ float schro_hip_timer_end (SchroHipContext * ctx);
 #define SCHRO_HIP_KERNEL_CONVERT 4
 #define SCHRO_HIP_KERNEL_SLICES 5
 #define SCHRO_HIP_KERNEL_DC_PREDICT 6
-#define SCHRO_HIP_KERNEL_CLASSES 7
+#define SCHRO_HIP_KERNEL_DEQUANT 7
+#define SCHRO_HIP_KERNEL_CLASSES 8
 int schro_hip_profile_enable (SchroHipContext * ctx, int enable);
 int schro_hip_profile_reset (SchroHipContext * ctx);
 int schro_hip_profile_read (SchroHipContext * ctx, int kernel_class,
@@ -354,6 +355,44 @@ typedef struct {
 
 int schro_hip_obmc_batch (SchroHipContext * ctx,
     const SchroHipObmcPlane * planes, int nplanes);
+
+/* ---- core-syntax coefficients: dequantisation on the device ----------------
+ *
+ * schro_decoder_decode_subband (schrodecoder.c:3525-3640) does two things per codeblock: the
+ * serial entropy decode (binary arithmetic coder or VLC), and the data-parallel rest -- zero
+ * fill of zero codeblocks (:3311-3322) and dequantisation (:3072-3079, :3400-3451,
+ * orc_dequantise_s16_* / _s32_ip_2d schroorc.orc:1098-1219).  The arithmetic decoder's
+ * contexts look only at whether neighbouring / parent coefficients are zero and at a
+ * neighbour's sign, which quantised values answer as well as dequantised ones (a non-zero value
+ * stays non-zero: quant_factor >= 4), so a host decoder can keep the QUANTISED values, hand
+ * them over for the non-zero codeblocks only -- 1, 2 or 4 bytes each -- and leave the dense
+ * coefficient frame to the device: schro_hip_dequant_batch, then schro_hip_dc_predict_batch on
+ * the LL bands of intra pictures (schrodecoder.c:3629-3636), then schro_hip_iiwt_batch. */
+typedef struct {
+  int dst_offset;               /* bytes from the plane's base to the codeblock's first sample */
+  int dst_stride;               /* bytes between its rows: the frame stride << the sub-band's level shift
+                                 * (schro_subband_get_frame_data, schroparams.c:319-368) */
+  int width, height;            /* samples: xmax - xmin, ymax - ymin */
+  int src_offset;               /* bytes from `values` to its quantised values, row-major and
+                                 * tight; < 0: zero codeblock (nothing stored) */
+  unsigned char src_bytes;      /* 1, 2 or 4 bytes per stored value (signed) */
+  unsigned char quant_index;    /* ctx->quant_index of the codeblock, 0 .. 60 */
+  unsigned char pad[2];
+} SchroHipCodeblock;
+
+typedef struct {
+  void *dst;                    /* the component's coefficient plane (device, s16 or s32) */
+  const void *values;           /* packed quantised values of its non-zero codeblocks (device) */
+  const SchroHipCodeblock *codeblocks;  /* HOST array: every codeblock of every sub-band */
+  int ncodeblocks;
+  int is_intra;                 /* params->num_refs == 0: schro_table_offset_1_2, else _3_8 */
+} SchroHipDequantPlane;
+
+/* arith 0: C int arithmetic (arithmetic-coded codeblocks; s32 frames); 1: the 16-bit Orc
+ * arithmetic of the VLC (is_noarith) path on s16 frames.  The two differ only where 16-bit
+ * products wrap, which no legal stream reaches. */
+int schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * planes, int nplanes,
+    int bytes_per_sample, int arith);
 
 /* ---- frame layer: the reference's stage boundary ------------------------- */
 

@@ -390,27 +390,34 @@ class Decoder:
         return mv
 
     # ---- coefficients ------------------------------------------------------------------------
-    def decode_coefficients(self, pic):
-        """Three int16 planes of the iwt size in the interleaved sub-band layout."""
+    def decode_coefficients(self, pic, quantised=False):
+        """Three int16 planes of the iwt size in the interleaved sub-band layout.
+        quantised: stop BEFORE dequantisation and intra DC prediction (what a host decoder hands
+        to schro_hip_dequant_batch): int32 planes of quantised values, and self.codeblocks[comp]
+        = [(sub-band index, xmin, ymin, xmax, ymax, zero codeblock?, quantiser index)]."""
         intra = pic.num_refs == 0
         planes = []
+        self.codeblocks = [[], [], []]
         for comp in range(3):
             h, w = pic.iwt[1 if comp else 0]
             plane = np.zeros((h, w), np.int32)
             for index in range(1 + 3 * pic.depth):
                 q0, buf = pic.subbands[comp][index]
+                band = subband_view(plane, pic.depth, index)
                 if not buf:
+                    # schro_decoder_decode_subband: subband_length == 0 -> zero_block over the sub-band
+                    self.codeblocks[comp].append((index, 0, 0, band.shape[1], band.shape[0], True, q0))
                     continue
                 position = SUBBAND_POSITION[index]
-                band = subband_view(plane, pic.depth, index)
                 parent = subband_view(plane, pic.depth, index - 3) if position >= 4 else None
-                self.decode_subband(pic, band, parent, position, index, q0, buf, intra)
-                if position == 0 and intra:
+                self.decode_subband(pic, band, parent, position, index, q0, buf, intra, quantised, self.codeblocks[comp])
+                if position == 0 and intra and not quantised:
                     dc_predict_s16(band)
-            planes.append(plane.astype(np.int16))
+            planes.append(plane.astype(np.int32 if quantised else np.int16))
         return planes
 
-    def decode_subband(self, pic, band, parent, position, index, quant_index, buf, intra):
+    def decode_subband(self, pic, band, parent, position, index, quant_index, buf, intra, quantised=False,
+                       records=None):
         ar = Arith(buf, self.lut)
         bh, bw = band.shape
         level = 0 if position == 0 else (position >> 2) + 1
@@ -451,9 +458,13 @@ class Decoder:
                     xmin += 1
                 x1 = xmin
                 if zero_flags and bit(CTX_ZERO_CODEBLOCK):
+                    if records is not None:
+                        records.append((index, x0, ymin, x1, ymax, True, quant_index))
                     continue                                  # the plane starts as zeros
                 if quant_delta:
                     quant_index = min(max(quant_index + ar.sint(CTX_Q_CONT, CTX_Q_VALUE, CTX_Q_SIGN), 0), 60)
+                if records is not None:
+                    records.append((index, x0, ymin, x1, ymax, False, quant_index))
                 factor, offset = self.qf[quant_index], qoff[quant_index]
                 for j in range(ymin, ymax):
                     line = rows[j]
@@ -484,7 +495,11 @@ class Decoder:
                             elif vert:
                                 pv = prev[i] if prev is not None else 0
                             sign = CTX_SIGN_NEG if pv < 0 else (CTX_SIGN_POS if pv > 0 else CTX_SIGN_ZERO)
-                            v = (offset + factor * v + 2) >> 2
+                            # quantised: keep the decoded value itself.  The contexts only look at
+                            # whether neighbours / parent are zero and at a neighbour's sign, which
+                            # dequantisation preserves (factor >= 4: a non-zero value stays non-zero)
+                            if not quantised:
+                                v = (offset + factor * v + 2) >> 2
                             if bit(sign):
                                 v = -v
                             line[i] = ((v + 32768) & 0xffff) - 32768      # stored as int16_t

@@ -214,4 +214,9 @@ int16_t oracle_dequantise_var_s16 (int16_t q, int quant_factor, int quant_offset
 #ifdef __cplusplus
 }
 #endif
+/* ---- oracle_dequant.c: core-syntax coefficient reconstruction after entropy decoding ---- */
+int oracle_quant_offset_3_8 (int q);
+void oracle_dequant_codeblock (void *dst, int dst_stride, int bpp, const void *src, int src_bytes,
+    int width, int height, int quant_index, int is_intra, int arith);
+
 #endif

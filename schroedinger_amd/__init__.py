@@ -93,6 +93,17 @@ class HpPlane(DevicePlane):
         return out
 
 
+class SubPlane:
+    """A strided view into a DevicePlane (e.g. the LL band of a coefficient frame in the
+    in-place sub-band layout: rows 2^depth apart, stride << depth); owns nothing."""
+
+    def __init__(self, plane, y0, x0, height, width, stride=None):
+        self.ctx, self.dtype = plane.ctx, plane.dtype
+        self.ptr = plane.ptr + y0 * plane.stride + x0 * plane.dtype.itemsize
+        self.height, self.width = int(height), int(width)
+        self.stride = int(stride) if stride else plane.stride
+
+
 class Context:
     """One exec-domain context: device, stream, memory domain."""
 
@@ -149,7 +160,8 @@ class Context:
             raise SchroHipError(self.lib.schro_hip_last_error().decode())
         return ms
 
-    KERNEL_CLASSES = ("iiwt_finest", "iiwt_coarse", "upsample", "obmc", "convert", "slices", "dc_predict")
+    KERNEL_CLASSES = ("iiwt_finest", "iiwt_coarse", "upsample", "obmc", "convert", "slices", "dc_predict",
+                      "dequant")
 
     def profile_enable(self, on=True):
         check(self.lib.schro_hip_profile_enable(self.h, 1 if on else 0))
@@ -256,6 +268,22 @@ class Context:
                 assert planes[k].dtype.itemsize == bpp
                 a.comp[k], a.stride[k] = planes[k].ptr, planes[k].stride
         check(self.lib.schro_hip_lowdelay_batch(self.h, arr, n, C.byref(self.lowdelay_params(P)), bpp))
+
+    def dequant_batch(self, jobs, arith=0):
+        """jobs: (dst DevicePlane (s16 / s32), values device blob (DevicePlane of bytes) or None,
+        codeblocks list of (dst_offset, dst_stride, width, height, src_offset, src_bytes,
+        quant_index), is_intra) per component."""
+        n = len(jobs)
+        arr = (_lib.DequantPlane * n)()
+        keep = []
+        for a, (dst, values, cbs, intra) in zip(arr, jobs):
+            tab = (_lib.Codeblock * len(cbs))()
+            for t, cb in zip(tab, cbs):
+                (t.dst_offset, t.dst_stride, t.width, t.height, t.src_offset, t.src_bytes, t.quant_index) = cb
+            keep.append(tab)
+            a.dst, a.values = dst.ptr, values.ptr if values is not None else None
+            a.codeblocks, a.ncodeblocks, a.is_intra = tab, len(cbs), 1 if intra else 0
+        check(self.lib.schro_hip_dequant_batch(self.h, arr, n, jobs[0][0].dtype.itemsize, arith))
 
     def dc_predict_batch(self, planes):
         """In-place DC prediction of LL bands given as DevicePlanes (s16 / s32)."""

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
     "schro_hip_pack_v210_batch",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
+    "schro_hip_dequant_batch",
     "schro_hip_decode_lowdelay_transform_data",
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
@@ -67,6 +68,17 @@ class LowDelayParams(C.Structure):
 class LowDelayPicture(C.Structure):
     _fields_ = [("slices", C.c_void_p), ("slices_bytes", C.c_size_t),
                 ("comp", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class Codeblock(C.Structure):
+    _fields_ = [("dst_offset", C.c_int), ("dst_stride", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("src_offset", C.c_int), ("src_bytes", C.c_ubyte), ("quant_index", C.c_ubyte),
+                ("pad", C.c_ubyte * 2)]
+
+
+class DequantPlane(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("values", C.c_void_p), ("codeblocks", C.POINTER(Codeblock)),
+                ("ncodeblocks", C.c_int), ("is_intra", C.c_int)]
 
 
 class DcPlane(C.Structure):
@@ -234,6 +246,8 @@ def load():
     L.schro_hip_decode_lowdelay_transform_data.restype = i
     L.schro_hip_dc_predict_batch.argtypes = [vp, C.POINTER(DcPlane), i, i]
     L.schro_hip_dc_predict_batch.restype = i
+    L.schro_hip_dequant_batch.argtypes = [vp, C.POINTER(DequantPlane), i, i, i]
+    L.schro_hip_dequant_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]
     L.schro_hip_upsampled_bytes.restype = C.c_size_t
     L.schro_hip_upsampled_download.argtypes = [vp, vp, i, vp, i, i, i]

@@ -971,6 +971,75 @@ schro_hip_dc_predict_batch (SchroHipContext * ctx, const SchroHipDcPlane * plane
 }
 
 int
+schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * planes, int nplanes, int bytes_per_sample,
+    int arith)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0, "dequant_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (bytes_per_sample == 2 || bytes_per_sample == 4, "dequant_batch: bytes_per_sample must be 2 or 4");
+  SCHRO_HIP_REQUIRE (arith == 0 || (arith == 1 && bytes_per_sample == 2),
+      "dequant_batch: the 16-bit arithmetic belongs to s16 frames");
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  dequant_tile_geometry (&tw, &th);
+  // job tables travel through the table slots: as many codeblocks per launch as fit one
+  constexpr size_t kPerLaunch = std::min < size_t > (4096, SchroHipContext::kArgSlotBytes / sizeof (DequantJob));
+  std::vector < DequantJob > jobs;
+  jobs.reserve (kPerLaunch);
+  int tile_base = 0;
+  auto flush = [&] () -> int {
+    if (jobs.empty ())
+      return 0;
+    void *d_jobs;
+    int r = push_args (ctx, jobs.data (), sizeof (DequantJob) * jobs.size (), &d_jobs);
+    if (r)
+      return r;
+    {
+      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DEQUANT);
+      r = launch_dequant (ctx->stream, (const DequantJob *) d_jobs, (int) jobs.size (), tile_base, bytes_per_sample, arith);
+    }
+    jobs.clear ();
+    tile_base = 0;
+    return r;
+  };
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipDequantPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.dst && pl.codeblocks && pl.ncodeblocks > 0 && (uintptr_t) pl.dst % bytes_per_sample == 0,
+        "dequant_batch: plane %d invalid", p);
+    for (int c = 0; c < pl.ncodeblocks; c++) {
+      const SchroHipCodeblock & cb = pl.codeblocks[c];
+      if (cb.width == 0 || cb.height == 0)
+        continue;                 // (a sub-band narrower than its codeblock count: schrodecoder.c:3572-3588)
+      SCHRO_HIP_REQUIRE (cb.width > 0 && cb.height > 0 && cb.dst_offset >= 0 && cb.dst_offset % bytes_per_sample == 0
+          && cb.dst_stride % bytes_per_sample == 0 && cb.dst_stride >= cb.width * bytes_per_sample,
+          "dequant_batch: plane %d codeblock %d: bad geometry", p, c);
+      SCHRO_HIP_REQUIRE (cb.src_offset < 0 || (pl.values && (cb.src_bytes == 1 || cb.src_bytes == 2 || cb.src_bytes == 4)
+              && cb.src_offset % cb.src_bytes == 0),
+          "dequant_batch: plane %d codeblock %d: values must be 1, 2 or 4 bytes each and aligned", p, c);
+      SCHRO_HIP_REQUIRE (cb.quant_index <= 60, "dequant_batch: plane %d codeblock %d: quant_index %d", p, c, cb.quant_index);
+      DequantJob j;
+      memset (&j, 0, sizeof (j));
+      j.dst = (char *) pl.dst + cb.dst_offset;
+      j.src = cb.src_offset < 0 ? nullptr : (const char *) pl.values + cb.src_offset;
+      j.dst_stride = cb.dst_stride;
+      j.w = cb.width;
+      j.h = cb.height;
+      j.src_bytes = cb.src_bytes;
+      dequant_tables (cb.quant_index, pl.is_intra, &j.factor, &j.offset);
+      j.tiles_x = div_up (cb.width, tw);
+      j.tile_base = tile_base;
+      tile_base += j.tiles_x * div_up (cb.height, th);
+      jobs.push_back (j);
+      if (jobs.size () == kPerLaunch) {
+        int r = flush ();
+        if (r)
+          return r;
+      }
+    }
+  }
+  return flush ();
+}
+
+int
 schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture * pictures, int npictures,
     const SchroHipLowDelayParams * params, int bytes_per_sample)
 {

@@ -125,6 +125,18 @@ struct DcJob {
   int pad;
 };
 
+// One codeblock of the core-syntax dequantisation (dequant.hip).
+struct DequantJob {
+  void *dst;                    // first sample of the codeblock in the coefficient frame
+  const void *src;              // its quantised values (row-major, tight); NULL: zero codeblock
+  int dst_stride;
+  int w, h;
+  int src_bytes;
+  uint32_t factor, offset;
+  int tiles_x;
+  int tile_base;
+};
+
 constexpr int kMaxJobs = 256;
 
 // XCD-aware workgroup order.  The dispatcher deals workgroups round-robin over
@@ -263,6 +275,10 @@ void upsample_tile_geometry (int *tw, int *th);
 int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P,
     int bpp, int arith);
 int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
+int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
+void dequant_tile_geometry (int *tw, int *th);
+// schro_table_quant[i] and schro_table_offset_1_2[i] (intra) / _3_8[i] (inter)
+void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t * offset);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order);
 // staged kernel (obmc_stage.hip): prediction dwords per block row, 0 = geometry not supported

@@ -64,6 +64,10 @@ def lib():
         L.oracle_quant_factor.restype = C.c_uint32
         L.oracle_quant_offset_1_2.argtypes = [i]
         L.oracle_quant_offset_1_2.restype = C.c_uint32
+        L.oracle_quant_offset_3_8.argtypes = [i]
+        L.oracle_quant_offset_3_8.restype = i
+        L.oracle_dequant_codeblock.argtypes = [vp, i, i, vp, i, i, i, i, i, i]
+        L.oracle_dequant_codeblock.restype = None
         L.oracle_dequantise_var_s16.argtypes = [C.c_int16, i, i]
         L.oracle_dequantise_var_s16.restype = C.c_int16
         _LIB = L
@@ -325,3 +329,21 @@ def dc_predict(a):
 def quant_tables():
     L = lib()
     return ([L.oracle_quant_factor(q) for q in range(61)], [L.oracle_quant_offset_1_2(q) for q in range(61)])
+
+
+def quant_offset_3_8():
+    return [lib().oracle_quant_offset_3_8(q) for q in range(61)]
+
+
+def dequant_codeblock(dst, q, quant_index, is_intra, arith):
+    """dst: 2-D view (a codeblock of a sub-band, any strides) of int16 / int32, written in place.
+    q: the codeblock's quantised values (2-D, int8 / int16 / int32) or None for a zero codeblock."""
+    h, w = dst.shape
+    assert dst.strides[1] == dst.itemsize
+    src = None
+    if q is not None:
+        src = np.ascontiguousarray(q)
+        assert src.shape == (h, w)
+    lib().oracle_dequant_codeblock(dst.ctypes.data_as(C.c_void_p), dst.strides[0], dst.itemsize,
+                                   _ptr(src) if src is not None else None, src.itemsize if src is not None else 0,
+                                   w, h, quant_index, 1 if is_intra else 0, arith)

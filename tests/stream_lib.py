@@ -26,8 +26,12 @@ def load_stream():
     return open(os.path.join(GOLDEN, "test_stream.drc"), "rb").read()
 
 
-def decode_stream(data, tables, limit=None):
-    """Yields per picture (coded order) a dict with everything decoded."""
+def decode_stream(data, tables, limit=None, quantised=False):
+    """Yields per picture (coded order) a dict with everything decoded.  quantised: also
+    "quant" (int32 planes of quantised values) and "codeblocks" (per component, see
+    dirac_stream.Decoder.decode_coefficients): the hand-over point of device-side
+    dequantisation.  The compatibility heuristic of old streams carries state from sub-band to
+    sub-band, so the two decodes of a picture run on copies of the decoder."""
     qf, qo12 = O.quant_tables()
     dec = D.Decoder(tables["arith_lut"], qf, qo12, tables["schro_table_offset_3_8"])
     refs, n = {}, 0
@@ -42,10 +46,18 @@ def decode_stream(data, tables, limit=None):
                 res = None
                 coeffs = None
             else:
+                quant = cbs = None
+                if quantised:
+                    import copy
+                    dq = copy.copy(dec)
+                    quant = dq.decode_coefficients(pic, quantised=True)
+                    cbs = dq.codeblocks
                 coeffs = dec.decode_coefficients(pic)
                 res = [O.inverse_iwt(c, pic.depth, pic.wavelet) for c in coeffs]
             rec = dict(number=pic.number, num_refs=pic.num_refs, refs=list(pic.refs), is_ref=pic.is_ref,
                        coeffs=coeffs, zero_residual=pic.zero_residual)
+            if quantised and not pic.zero_residual:
+                rec.update(quant=quant, codeblocks=cbs)
             if pic.num_refs == 0:
                 out = [O.convert_u8(res[k], dims[k][1], dims[k][0]) for k in range(3)]
             else:

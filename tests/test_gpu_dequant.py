@@ -1,0 +1,163 @@
+"""GPU parity: core-syntax dequantisation on the device (schro_hip_dequant_batch)
+against oracle/oracle_dequant.c -- which is pinned on the reference's compiled
+orc_dequantise_* kernels -- and, end to end, the reference's own stream decoded from its
+QUANTISED values: dequantise + intra DC prediction + inverse wavelet + OBMC / convert on the
+device, every one of the 100 pictures equal to the oracle's and carrying its digest."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import stream_lib as S
+
+sys.path.insert(0, os.path.join(S.ROOT, "oracle"))
+import dirac_stream as D  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_codeblocks(plane_shape, itemsize, stride, depth, quant, records):
+    """(quantised plane, front-end records) -> (values blob, SchroHipCodeblock tuples): what a
+    host decoder hands over.  Values of non-zero codeblocks only, 1 / 2 / 4 bytes each."""
+    probe = np.zeros(plane_shape, np.int8)
+    blob, cbs = bytearray(), []
+    for (index, x0, y0, x1, y1, zero, qi) in records:
+        band = D.subband_view(probe, depth, index)
+        # byte offset / stride of the sub-band inside the device plane (same geometry, device stride)
+        off_elems = (band.__array_interface__["data"][0] - probe.__array_interface__["data"][0])
+        row0, col0 = divmod(off_elems, probe.strides[0])
+        lvl_stride = band.strides[0] // probe.strides[0]
+        dst_off = (row0 + y0 * lvl_stride) * stride + (col0 + x0) * itemsize
+        dst_stride = lvl_stride * stride
+        if zero:
+            cbs.append((dst_off, dst_stride, x1 - x0, y1 - y0, -1, 0, qi))
+            continue
+        q = D.subband_view(quant, depth, index)[y0:y1, x0:x1]
+        m = int(np.abs(q).max()) if q.size else 0
+        dt = np.int8 if m < 128 else (np.int16 if m < 32768 else np.int32)
+        while len(blob) % np.dtype(dt).itemsize:
+            blob.append(0)
+        cbs.append((dst_off, dst_stride, x1 - x0, y1 - y0, len(blob), np.dtype(dt).itemsize, qi))
+        blob += np.ascontiguousarray(q, dtype=dt).tobytes()
+    return np.frombuffer(bytes(blob) or b"\0", np.uint8), cbs
+
+
+def synthetic_records(h, w, depth, rng, zero_share=0.4):
+    """A codeblock partition of every sub-band (schrodecoder.c:3572-3596 geometry) with random
+    zero flags and quantiser indices."""
+    records = []
+    probe = np.zeros((h, w), np.int8)
+    for index in range(1 + 3 * depth):
+        band = D.subband_view(probe, depth, index)
+        bh, bw = band.shape
+        ncx, ncy = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        cbw = bw // ncx
+        inc = bw - ncx * cbw
+        for cy in range(ncy):
+            y0, y1 = (bh * cy) // ncy, (bh * (cy + 1)) // ncy
+            xmin = acc = 0
+            for cx in range(ncx):
+                x0 = xmin
+                xmin += cbw
+                acc += inc
+                if acc >= ncx:
+                    acc -= ncx
+                    xmin += 1
+                records.append((index, x0, y0, xmin, y1, bool(rng.random() < zero_share), int(rng.integers(0, 61))))
+    return records
+
+
+@pytest.mark.parametrize("dtype,arith", [(np.int16, 0), (np.int16, 1), (np.int32, 0)])
+def test_synthetic_codeblocks(ctx, dtype, arith):
+    rng = np.random.default_rng(11)
+    jobs, want, outs = [], [], []
+    for (h, w, depth, span, intra) in [(64, 96, 2, 100, 1), (144, 176, 3, 3000, 0), (48, 40, 1, 40000, 0),
+                                       (270 * 4, 480 * 4, 4, 90, 1)]:
+        quant = rng.integers(-span, span + 1, (h, w)).astype(np.int32)
+        quant[rng.random((h, w)) < 0.5] = 0
+        records = synthetic_records(h, w, depth, rng)
+        dst = ctx.plane(h, w, dtype).fill(0x5a)
+        blob, cbs = pack_codeblocks((h, w), np.dtype(dtype).itemsize, dst.stride, depth, quant, records)
+        jobs.append((dst, ctx.upload_bytes(blob), cbs, intra))
+        ref = np.full((h, w), 0x5a5a5a5a & (0xffff if dtype == np.int16 else 0xffffffff), np.uint32).astype(dtype)
+        for (index, x0, y0, x1, y1, zero, qi) in records:
+            band, qb = D.subband_view(ref, depth, index), D.subband_view(quant, depth, index)
+            if x1 > x0 and y1 > y0:
+                O.dequant_codeblock(band[y0:y1, x0:x1], None if zero else qb[y0:y1, x0:x1], qi, intra, arith)
+        want.append(ref)
+        outs.append(dst)
+    ctx.dequant_batch(jobs, arith)
+    for n, (dst, ref) in enumerate(zip(outs, want)):
+        assert np.array_equal(dst.download(), ref), n
+
+
+def test_bad_arguments_are_refused(ctx):
+    dst = ctx.plane(16, 16, np.int16)
+    blob = ctx.upload_bytes(np.zeros(512, np.uint8))
+    with pytest.raises(sa.SchroHipError):       # 3-byte values
+        ctx.dequant_batch([(dst, blob, [(0, dst.stride, 4, 4, 0, 3, 10)], 0)])
+    with pytest.raises(sa.SchroHipError):       # quantiser index beyond the tables
+        ctx.dequant_batch([(dst, blob, [(0, dst.stride, 4, 4, 0, 1, 61)], 0)])
+    with pytest.raises(sa.SchroHipError):       # the 16-bit arithmetic on an s32 frame
+        ctx.dequant_batch([(ctx.plane(16, 16, np.int32), blob, [(0, 64, 4, 4, 0, 1, 10)], 0)], arith=1)
+
+
+def test_whole_stream_from_quantised_values(ctx):
+    md5 = json.load(open(os.path.join(S.GOLDEN, "stream_md5.json")))["oracle"]
+    decoded, count, sent, dense = {}, 0, 0, 0
+    for rec in S.decode_stream(S.load_stream(), S.load_tables(), quantised=True):
+        number, refs, want = rec["number"], rec["refs"], rec["out"]
+        intra = rec["num_refs"] == 0
+        out = [ctx.plane(w.shape[0], w.shape[1], np.uint8).fill(0x11) for w in want]
+        tmp = []
+        if rec["zero_residual"]:
+            res = [ctx.upload(np.zeros(w.shape, np.int16)) for w in want]
+        else:
+            depth = rec["depth"]
+            co, jobs = [], []
+            for k in range(3):
+                q = rec["quant"][k]
+                d = ctx.plane(q.shape[0], q.shape[1], np.int16).fill(0x5a)
+                blob, cbs = pack_codeblocks(q.shape, 2, d.stride, depth, q, rec["codeblocks"][k])
+                sent += blob.size + 24 * len(cbs)
+                dense += q.size * 2
+                vals = ctx.upload_bytes(blob)
+                jobs.append((d, vals, cbs, intra))
+                co.append(d)
+                tmp.append(vals)
+            ctx.dequant_batch(jobs, 0)
+            if intra:       # schrodecoder.c:3629-3636: the LL band of an intra picture
+                ctx.dc_predict_batch([sa.SubPlane(c, 0, 0, c.height >> depth, c.width >> depth, c.stride << depth)
+                                      for c in co])
+            for k in range(3):
+                assert np.array_equal(co[k].download(), rec["coeffs"][k]), "picture %d coefficients %d" % (number, k)
+            res = [ctx.plane(c.height, c.width, np.int16) for c in co]
+            ctx.iiwt_batch(list(zip(co, res)), depth, rec["wavelet"])
+            tmp += co
+        if intra:
+            ctx.convert_u8_batch(list(zip(res, out)))
+        else:
+            d_mv = ctx.upload_bytes(rec["mv"])
+            ctx.obmc_batch([sa.obmc_plane(d_mv, rec["params"], k, decoded[refs[0]][k],
+                                          decoded[refs[1] if len(refs) > 1 else refs[0]][k], res[k], out[k])
+                            for k in range(3)])
+        got = [o.download() for o in out]
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), "picture %d component %d" % (number, k)
+        assert D.frame_md5(got) == md5[number]
+        for p in tmp + res:
+            p.free()
+        if rec["is_ref"]:
+            decoded[number] = out
+        else:
+            for p in out:
+                p.free()
+        count += 1
+    assert count == 100
+    # what crossed the host boundary instead of dense s16 coefficient frames
+    print("quantised hand-over: %.1f %% of the dense coefficient bytes" % (100.0 * sent / dense))
+    assert sent < dense / 2
