@@ -191,7 +191,10 @@ int schro_hip_convert_u8_batch (SchroHipContext * ctx,
 #define SCHRO_HIP_FORMAT_YUYV 0x100     /* SCHRO_FRAME_FORMAT_YUYV, schroframe.h:36-38 */
 #define SCHRO_HIP_FORMAT_UYVY 0x101
 #define SCHRO_HIP_FORMAT_AYUV 0x102
+#define SCHRO_HIP_FORMAT_ARGB 0x103     /* from s16 4:4:4 YCoCg-R planes */
+#define SCHRO_HIP_FORMAT_v216 0x105     /* from s16 4:2:2 */
 #define SCHRO_HIP_FORMAT_v210 0x106     /* 10 bit 4:2:2, six pixels in four words */
+#define SCHRO_HIP_FORMAT_AY64 0x107     /* 16-bit A, Y, U, V from s32 4:4:4 */
 
 typedef struct {
   const uint8_t *src[3];        /* Y, U, V planes (device) */
@@ -221,6 +224,24 @@ int schro_hip_pack_u8_batch (SchroHipContext * ctx,
  * bytes of the sample type. */
 int schro_hip_pack_v210_batch (SchroHipContext * ctx,
     const SchroHipPackPlane * planes, int nplanes, int src_bpp);
+
+/* The remaining packed destinations of schro_frame_convert (schroframe.c:886-895, 957-968),
+ * chosen by `format` of each plane:
+ *   SCHRO_HIP_FORMAT_v216  from a 4:2:2 source brought to s16; pack_v216
+ *                          (schrovirtframe.c:1007-1028) reads the s16 lines through byte
+ *                          pointers and this does exactly the same: 8 bytes per pixel pair,
+ *                          rows of width / 2 pairs;
+ *   SCHRO_HIP_FORMAT_ARGB  from a 4:4:4 source brought to s16, YCoCg-R -> A,R,G,B bytes
+ *                          (pack_argb :1265-1287), 4 bytes per pixel;
+ *   SCHRO_HIP_FORMAT_AY64  from a 4:4:4 source brought to s32, 16-bit A,Y,U,V words
+ *                          clamp (x + 0x8000, 0, 0xffff) (pack_ayuv64 :1302-1322), 8 bytes per pixel.
+ * src_bpp 1 / 2 / 4 with the reference's depth conversions (u8: x - 128; s32 -> s16:
+ * truncation; s16 -> s32: sign extension, schrovirtframe.c:1742-1817); the source's chroma
+ * format must already be the destination's (the reference resamples u8 frames only). */
+int schro_hip_pack_wide_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes,
+    int src_bpp);
+
+
 
 /* ---- VC-2 low-delay transform data -----------------------------
  * Replaces schro_decoder_decode_lowdelay_transform_data (schrolowdelay.c:746-762):
@@ -280,6 +301,13 @@ typedef struct {
 } SchroHipDcPlane;
 int schro_hip_dc_predict_batch (SchroHipContext * ctx,
     const SchroHipDcPlane * planes, int nplanes, int bytes_per_sample);
+
+/* schro_frame_shift_right (schroframe.c:1265-1293) on planes, in place:
+ * x = (x + ((1 << shift) >> 1)) >> shift.  The decoder applies it to an intra picture's frame
+ * when the stream's bit depth exceeds the output picture's (schrodecoder.c:2013-2019). */
+int schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * planes, int nplanes,
+    int bytes_per_sample, int shift);
+
 
 /* Half-pel upsampling of one u8 component; replaces
  * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /
@@ -654,8 +682,11 @@ int schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest,
     SchroHipFrame * addframe, int add, SchroHipFrame * output_frame);
 
 /* schro_gpuframe_convert (schrogpuframe.h:20) replacement for the conversions the decode path
- * performs: s16/s32 -> u8 (+128, clamp, crop), u8 -> u8 copy, u8 -> packed. */
+ * performs: s16/s32 -> u8 (+128, clamp, crop), u8 -> u8 copy, planar -> packed (YUYV, UYVY,
+ * AYUV from u8; v210, v216, ARGB, AY64 from u8 / s16 / s32). */
 int schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src);
+/* schro_frame_shift_right (schroframe.c:1265-1293) on a device s16 / s32 frame */
+int schro_hipframe_shift_right (SchroHipFrame * frame, int shift);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,16 @@ int oracle_pack_u8 (uint8_t * dst, int dst_stride, int format, int width, int he
 int oracle_pack_v210 (uint8_t * dst, int dst_stride, int width, int height,
     const OraclePackSrc * src, int src_bpp);
 
+/* v216 (0x105: s16 4:2:2), ARGB (0x103: s16 4:4:4, YCoCg-R) and AY64 (0x107: s32 4:4:4)
+ * destinations; src_bpp 1, 2 or 4 as for v210, chroma format already the target's. */
+#define ORACLE_FORMAT_ARGB 0x103
+#define ORACLE_FORMAT_v216 0x105
+#define ORACLE_FORMAT_AY64 0x107
+int oracle_pack_wide (uint8_t * dst, int dst_stride, int format, int width, int height,
+    const OraclePackSrc * src, int src_bpp);
+/* schro_frame_shift_right on one component, in place (bpp 2 or 4) */
+int oracle_shift_right (void *data, int stride, int width, int height, int bpp, int shift);
+
 /* ---- VC-2 low-delay transform data (oracle_lowdelay.c) ------------------- */
 
 /* the SchroParams members the slice decode reads (schrolowdelay.c:559-762) */

@@ -19,6 +19,7 @@ FORMAT_U8_444, FORMAT_U8_422, FORMAT_U8_420 = 0x00, 0x01, 0x03
 FORMAT_S16_444, FORMAT_S16_422, FORMAT_S16_420 = 0x04, 0x05, 0x07
 FORMAT_S32_444, FORMAT_S32_422, FORMAT_S32_420 = 0x08, 0x09, 0x0b
 FORMAT_YUYV, FORMAT_UYVY, FORMAT_AYUV = 0x100, 0x101, 0x102       # packed, schroframe.h:36-38
+FORMAT_ARGB, FORMAT_V216, FORMAT_AY64 = 0x103, 0x105, 0x107
 FORMAT_V210 = 0x106
 
 # SchroMotionVector, schroedinger/schromotion.h:20-37 (20 bytes)
@@ -237,6 +238,31 @@ class Context:
             a.dst, a.dst_stride = dst.ptr, dst.stride
             a.width, a.height, a.format = w, h, FORMAT_V210
         check(self.lib.schro_hip_pack_v210_batch(self.h, arr, n, bpp))
+
+    def pack_wide_batch(self, jobs):
+        """jobs: (planes [Y, U, V] DevicePlanes of one dtype, h_shift, v_shift, dst DevicePlane of
+        bytes, width, height, format (FORMAT_V216 / FORMAT_ARGB / FORMAT_AY64)) per picture."""
+        n = len(jobs)
+        arr = (_lib.PackPlane * n)()
+        bpp = jobs[0][0][0].dtype.itemsize
+        for a, (planes, hs, vs, dst, w, h, fmt) in zip(arr, jobs):
+            assert planes[0].dtype.itemsize == bpp
+            for k in range(3):
+                a.src[k] = planes[k].ptr
+                a.src_stride[k] = planes[k].stride
+            a.src_width, a.src_height = planes[0].width, planes[0].height
+            a.src_h_shift, a.src_v_shift = hs, vs
+            a.dst, a.dst_stride = dst.ptr, dst.stride
+            a.width, a.height, a.format = w, h, fmt
+        check(self.lib.schro_hip_pack_wide_batch(self.h, arr, n, bpp))
+
+    def shift_right_batch(self, planes, shift):
+        """schro_frame_shift_right on DevicePlanes (s16 / s32), in place."""
+        n = len(planes)
+        arr = (_lib.DcPlane * n)()
+        for a, p in zip(arr, planes):
+            a.data, a.stride, a.width, a.height = p.ptr, p.stride, p.width, p.height
+        check(self.lib.schro_hip_shift_right_batch(self.h, arr, n, planes[0].dtype.itemsize, shift))
 
     @staticmethod
     def lowdelay_params(P):

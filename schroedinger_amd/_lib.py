@@ -24,7 +24,8 @@ EXPORTED_SYMBOLS = [
     "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
-    "schro_hip_pack_v210_batch",
+    "schro_hip_pack_v210_batch", "schro_hip_pack_wide_batch", "schro_hip_shift_right_batch",
+    "schro_hipframe_shift_right",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
     "schro_hip_decode_lowdelay_transform_data",
@@ -246,6 +247,12 @@ def load():
     L.schro_hip_decode_lowdelay_transform_data.restype = i
     L.schro_hip_dc_predict_batch.argtypes = [vp, C.POINTER(DcPlane), i, i]
     L.schro_hip_dc_predict_batch.restype = i
+    L.schro_hip_shift_right_batch.argtypes = [vp, C.POINTER(DcPlane), i, i, i]
+    L.schro_hip_shift_right_batch.restype = i
+    L.schro_hip_pack_wide_batch.argtypes = [vp, C.POINTER(PackPlane), i, i]
+    L.schro_hip_pack_wide_batch.restype = i
+    L.schro_hipframe_shift_right.argtypes = [C.POINTER(Frame), i]
+    L.schro_hipframe_shift_right.restype = i
     L.schro_hip_dequant_batch.argtypes = [vp, C.POINTER(DequantPlane), i, i, i]
     L.schro_hip_dequant_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]

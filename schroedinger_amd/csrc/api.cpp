@@ -821,8 +821,16 @@ schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * 
   return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
 }
 
+static bool
+is_wide_format (int f)
+{
+  return f == SCHRO_HIP_FORMAT_v216 || f == SCHRO_HIP_FORMAT_ARGB || f == SCHRO_HIP_FORMAT_AY64;
+}
+
+// v210_bpp > 0: every plane goes to v210 from that depth; wide_bpp > 0: v216 / ARGB / AY64 by
+// the plane's format from that depth; both 0: YUYV / UYVY / AYUV from u8
 static int
-pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes, int v210_bpp)
+pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes, int v210_bpp, int wide_bpp = 0)
 {
   SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs, "pack_batch: bad arguments");
   (void) hipSetDevice (ctx->device);
@@ -834,9 +842,16 @@ pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes
     const SchroHipPackPlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.src[0] && pl.src[1] && pl.src[2] && pl.dst && pl.width > 0 && pl.height > 0
         && pl.src_width > 0 && pl.src_height > 0, "pack_batch: plane %d invalid", p);
-    SCHRO_HIP_REQUIRE (v210_bpp || pl.format == SCHRO_HIP_FORMAT_YUYV || pl.format == SCHRO_HIP_FORMAT_UYVY
+    SCHRO_HIP_REQUIRE (v210_bpp || wide_bpp || pl.format == SCHRO_HIP_FORMAT_YUYV || pl.format == SCHRO_HIP_FORMAT_UYVY
         || pl.format == SCHRO_HIP_FORMAT_AYUV, "pack_batch: plane %d: format 0x%x is not YUYV / UYVY / AYUV",
         p, pl.format);
+    if (wide_bpp) {
+      SCHRO_HIP_REQUIRE (is_wide_format (pl.format), "pack_wide_batch: plane %d: format 0x%x is not v216 / ARGB / AY64",
+          p, pl.format);
+      // no chroma resampling after the depth conversion (schrovirtframe.c:1545-1575 knows u8 only)
+      SCHRO_HIP_REQUIRE (pl.src_v_shift == 0 && pl.src_h_shift == (pl.format == SCHRO_HIP_FORMAT_v216 ? 1 : 0),
+          "pack_wide_batch: plane %d: the source must be %s", p, pl.format == SCHRO_HIP_FORMAT_v216 ? "4:2:2" : "4:4:4");
+    }
     // the reference resamples chroma of u8 frames only (schrovirtframe.c:1545-1575)
     SCHRO_HIP_REQUIRE (v210_bpp <= 1 || (pl.src_h_shift == 1 && pl.src_v_shift == 0),
         "pack_v210_batch: plane %d: s16 / s32 sources must be 4:2:2", p);
@@ -848,6 +863,8 @@ pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes
         "pack_batch: plane %d: %dx%d from %dx%d mixes crop and extension", p, pl.width, pl.height,
         pl.src_width, pl.src_height);
     const int row_bytes = v210_bpp ? 16 * div_up (pl.width, 6)
+        : wide_bpp ? (pl.format == SCHRO_HIP_FORMAT_v216 ? 8 * (pl.width / 2) : pl.format == SCHRO_HIP_FORMAT_ARGB
+            ? 4 * pl.width : 8 * pl.width)
         : pl.format == SCHRO_HIP_FORMAT_AYUV ? 4 * pl.width : 4 * (pl.width / 2);
     SCHRO_HIP_REQUIRE (pl.dst_stride >= row_bytes, "pack_batch: plane %d stride too small", p);
     PackJob & j = jobs[p];
@@ -864,7 +881,7 @@ pack_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes
     j.w = pl.width;
     j.h = pl.height;
     j.format = v210_bpp ? SCHRO_HIP_FORMAT_v210 : pl.format;
-    j.src_bpp = v210_bpp ? v210_bpp : 1;
+    j.src_bpp = v210_bpp ? v210_bpp : (wide_bpp ? wide_bpp : 1);
     j.tiles_x = div_up (div_up (row_bytes, 16), gx);
     if (j.tiles_x == 0)
       j.tiles_x = 1;
@@ -891,6 +908,50 @@ schro_hip_pack_v210_batch (SchroHipContext * ctx, const SchroHipPackPlane * plan
 {
   SCHRO_HIP_REQUIRE (src_bpp == 1 || src_bpp == 2 || src_bpp == 4, "pack_v210_batch: src_bpp must be 1, 2 or 4");
   return pack_batch (ctx, planes, nplanes, src_bpp);
+}
+
+int
+schro_hip_pack_wide_batch (SchroHipContext * ctx, const SchroHipPackPlane * planes, int nplanes, int src_bpp)
+{
+  SCHRO_HIP_REQUIRE (src_bpp == 1 || src_bpp == 2 || src_bpp == 4, "pack_wide_batch: src_bpp must be 1, 2 or 4");
+  return pack_batch (ctx, planes, nplanes, 0, src_bpp);
+}
+
+int
+schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * planes, int nplanes, int bytes_per_sample,
+    int shift)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs, "shift_right_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (bytes_per_sample == 2 || bytes_per_sample == 4, "shift_right_batch: bytes_per_sample must be 2 or 4");
+  SCHRO_HIP_REQUIRE (shift >= 0 && shift < 8 * bytes_per_sample, "shift_right_batch: shift %d", shift);
+  if (shift == 0)
+    return 0;
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  convert_tile_geometry (&tw, &th);
+  std::vector < ConvertJob > jobs (nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipDcPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.data && pl.width > 0 && pl.height > 0 && pl.stride >= pl.width * bytes_per_sample
+        && pl.stride % bytes_per_sample == 0 && (uintptr_t) pl.data % bytes_per_sample == 0,
+        "shift_right_batch: plane %d invalid", p);
+    ConvertJob & j = jobs[p];
+    j.src = pl.data;
+    j.dst = (uint8_t *) pl.data;
+    j.src_stride = j.dst_stride = pl.stride;
+    j.w = pl.width;
+    j.h = pl.height;
+    j.tiles_x = div_up (pl.width, tw);
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (pl.height, th);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (ConvertJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
+  return launch_shift_right (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bytes_per_sample, shift);
 }
 
 size_t
@@ -1448,7 +1509,8 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     int upsampled)
 {
   if (ctx && width > 0 && height > 0 && !upsampled && (format == SCHRO_HIP_FORMAT_YUYV
-          || format == SCHRO_HIP_FORMAT_UYVY || format == SCHRO_HIP_FORMAT_AYUV)) {
+          || format == SCHRO_HIP_FORMAT_UYVY || format == SCHRO_HIP_FORMAT_AYUV || format == SCHRO_HIP_FORMAT_v210
+          || is_wide_format (format))) {
     // packed output frame: one component (schroframe.c:81-99)
     SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
     f->refcount = 1;
@@ -1460,7 +1522,11 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     c->format = format;
     c->width = width;
     c->height = height;
-    c->stride = (int) round_up ((size_t) (format == SCHRO_HIP_FORMAT_AYUV ? width * 4 : ((width + 1) & ~1) * 2), 64);
+    const size_t row = format == SCHRO_HIP_FORMAT_AYUV || format == SCHRO_HIP_FORMAT_ARGB ? (size_t) width * 4
+        : format == SCHRO_HIP_FORMAT_AY64 ? (size_t) width * 8
+        : format == SCHRO_HIP_FORMAT_v216 ? (size_t) ((width + 1) & ~1) * 4
+        : format == SCHRO_HIP_FORMAT_v210 ? (size_t) 16 * div_up (width, 6) : (size_t) ((width + 1) & ~1) * 2;
+    c->stride = (int) round_up (row, 64);
     c->length = c->stride * height;
     c->data = schro_hip_domain_alloc (ctx, round_up ((size_t) c->length, 256));
     if (!c->data) {
@@ -1543,7 +1609,10 @@ copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * s
     const SchroHipFrameData *s = &src->components[0];
     SchroHipFrameData *d = &dest->components[0];
     int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
-    size_t row = src->format == SCHRO_HIP_FORMAT_AYUV ? (size_t) w * 4 : (size_t) (w / 2) * 4;
+    const int f = src->format;
+    size_t row = f == SCHRO_HIP_FORMAT_AYUV || f == SCHRO_HIP_FORMAT_ARGB ? (size_t) w * 4
+        : f == SCHRO_HIP_FORMAT_AY64 ? (size_t) w * 8 : f == SCHRO_HIP_FORMAT_v216 ? (size_t) (w / 2) * 8
+        : f == SCHRO_HIP_FORMAT_v210 ? (size_t) 16 * div_up (w, 6) : (size_t) (w / 2) * 4;
     if (row && h > 0)
       SCHRO_HIP_CHECK (hipMemcpy2DAsync (d->data, d->stride, s->data, s->stride, row, h, kind, ctx->stream));
     SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
@@ -1775,9 +1844,11 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
       "hipframe_convert: both frames must live in the same device domain");
   SchroHipContext *ctx = frame_ctx (dest);
   if (dest->format & 0x100) {
-    // copy-out into a packed frame (schroframe.c:878-899, 943-955): u8 planar sources only
-    SCHRO_HIP_REQUIRE (!(src->format & 0x100) && format_bpp (src->format) == 1,
-        "hipframe_convert: packed destinations take a planar u8 source (convert to u8 first)");
+    // copy-out into a packed frame (schroframe.c:878-899, 943-968)
+    const bool wide = is_wide_format (dest->format), v210 = dest->format == SCHRO_HIP_FORMAT_v210;
+    SCHRO_HIP_REQUIRE (!(src->format & 0x100) && format_bpp (src->format)
+        && (wide || v210 || format_bpp (src->format) == 1),
+        "hipframe_convert: YUYV / UYVY / AYUV take a planar u8 source (convert to u8 first)");
     SchroHipPackPlane pl;
     for (int k = 0; k < 3; k++) {
       pl.src[k] = (const uint8_t *) src->components[k].data;
@@ -1792,7 +1863,8 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
     pl.width = dest->width;
     pl.height = dest->height;
     pl.format = dest->format;
-    int r = schro_hip_pack_u8_batch (ctx, &pl, 1);
+    int r = wide ? schro_hip_pack_wide_batch (ctx, &pl, 1, format_bpp (src->format))
+        : v210 ? schro_hip_pack_v210_batch (ctx, &pl, 1, format_bpp (src->format)) : schro_hip_pack_u8_batch (ctx, &pl, 1);
     return r ? r : schro_hip_synchronize (ctx);
   }
   int sb = format_bpp (src->format), db = format_bpp (dest->format);
@@ -1822,6 +1894,22 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
   }
   return set_error (SCHRO_HIP_EUNSUPPORTED, "hipframe_convert: depth %d -> %d is not on the decode path",
       sb, db);
+}
+
+int
+schro_hipframe_shift_right (SchroHipFrame * frame, int shift)
+{
+  SCHRO_HIP_REQUIRE (frame && frame_ctx (frame) && !(frame->format & 0x100) && format_bpp (frame->format) > 1,
+      "hipframe_shift_right: needs a device s16 / s32 frame");
+  SchroHipDcPlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    planes[k].data = frame->components[k].data;
+    planes[k].stride = frame->components[k].stride;
+    planes[k].width = frame->components[k].width;
+    planes[k].height = frame->components[k].height;
+  }
+  int r = schro_hip_shift_right_batch (frame_ctx (frame), planes, 3, format_bpp (frame->format), shift);
+  return r ? r : schro_hip_synchronize (frame_ctx (frame));
 }
 
 }                               // extern "C"

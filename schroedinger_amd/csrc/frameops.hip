@@ -16,6 +16,7 @@
 // kernel's bilinear taps are neighbours in memory.
 
 #include "schro_hip_internal.h"
+#include <type_traits>
 
 namespace schro {
 namespace {
@@ -299,6 +300,33 @@ v210_sample (const PackJob & job, int comp, int X, int Y)
   return (uint32_t) clampi (v + 512, 0, 1023);
 }
 
+// one sample of the frame just before pack_v216 / pack_argb / pack_ayuv64: depth conversion to the
+// packed format's planar depth (convert_s16_u8 / _s32_u8: x - 128; convert_s16_s32: truncation;
+// convert_s32_s16: sign extension, schrovirtframe.c:1742-1817), crop / edge-extend clamp
+__device__ __forceinline__ int
+wide_sample (const PackJob & job, int target_bpp, int t_hs, int comp, int X, int Y)
+{
+  const int cw = comp ? (job.sw + (1 << t_hs) - 1) >> t_hs : job.sw;
+  const int x = min (X, cw - 1), y = min (Y, job.sh - 1);
+  const uint8_t *row = job.src[comp] + (size_t) y * job.src_stride[comp];
+  int v;
+  if (job.src_bpp == 1)
+    v = (int) gload < uint8_t > (row + x) - 128;
+  else if (job.src_bpp == 2)
+    v = gload < int16_t > ((const int16_t *) row + x);
+  else
+    v = gload < int32_t > ((const int32_t *) row + x);
+  return target_bpp == 2 ? (int) (int16_t) v : v;
+}
+
+// byte b of an S16 line as pack_v216 reads it (schrovirtframe.c:1007-1028: uint8_t pointers
+// over int16_t lines, little endian)
+__device__ __forceinline__ uint32_t
+v216_line_byte (const PackJob & job, int comp, int b, int Y)
+{
+  return ((uint32_t) (uint16_t) wide_sample (job, 2, 1, comp, b >> 1, Y) >> (8 * (b & 1))) & 0xffu;
+}
+
 __global__ __launch_bounds__ (kThreads)
 void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
 {
@@ -336,6 +364,62 @@ void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
     } else {
       for (int k = 0; k < 4; k++)
         gstore < u32_u > (d + 4 * k, o[k]);
+    }
+    return;
+  }
+  if (job.format == SCHRO_HIP_FORMAT_v216 || job.format == SCHRO_HIP_FORMAT_ARGB || job.format == SCHRO_HIP_FORMAT_AY64) {
+    int nbytes = 16;
+    if (job.format == SCHRO_HIP_FORMAT_v216) {
+      // 8 bytes per pixel pair, two pairs per lane
+      const int pairs = job.w >> 1, j0 = 2 * g;
+      if (j0 >= pairs)
+        return;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int j = j0 + k;
+        const uint32_t u = v216_line_byte (job, 1, j, y), v = v216_line_byte (job, 2, j, y);
+        const uint32_t y0 = v216_line_byte (job, 0, 2 * j, y), y1 = v216_line_byte (job, 0, 2 * j + 1, y);
+        o[2 * k] = u * 0x0101u | (y0 * 0x0101u << 16);
+        o[2 * k + 1] = v * 0x0101u | (y1 * 0x0101u << 16);
+      }
+      nbytes = 8 * min (2, pairs - j0);
+    } else if (job.format == SCHRO_HIP_FORMAT_ARGB) {
+      const int x0 = 4 * g;
+      if (x0 >= job.w)
+        return;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = x0 + k;
+        const int yv = wide_sample (job, 2, 0, 0, x, y), co = wide_sample (job, 2, 0, 1, x, y);
+        const int cg = wide_sample (job, 2, 0, 2, x, y);
+        const int t = yv + (cg >> 1), b = t - (co >> 1);        // YCoCg-R, schrovirtframe.c:1281-1286
+        o[k] = 0xffu | ((uint32_t) ((b + co) & 0xff) << 8) | ((uint32_t) ((t + cg) & 0xff) << 16)
+            | ((uint32_t) (b & 0xff) << 24);
+      }
+      nbytes = 4 * min (4, job.w - x0);
+    } else {
+      const int x0 = 2 * g;
+      if (x0 >= job.w)
+        return;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int x = x0 + k;
+        uint32_t w[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const long long v = (long long) wide_sample (job, 4, 0, c, x, y) + 0x8000;
+          w[c] = (uint32_t) (v < 0 ? 0 : (v > 0xffff ? 0xffff : v));
+        }
+        o[2 * k] = 0xffffu | (w[0] << 16);
+        o[2 * k + 1] = w[1] | (w[2] << 16);
+      }
+      nbytes = 8 * min (2, job.w - x0);
+    }
+    if (nbytes == 16 && (((uintptr_t) d) & 15) == 0) {
+      gstore < u32x4 > (d, (u32x4) { o[0], o[1], o[2], o[3] });
+    } else {
+      for (int b = 0; b < nbytes; b++)
+        gstore < uint8_t > (d + b, (uint8_t) (o[b >> 2] >> (8 * (b & 3))));
     }
     return;
   }
@@ -405,7 +489,46 @@ void pack_kernel (const PackJob * __restrict__ jobs, int njobs)
   }
 }
 
+// schro_frame_shift_right (schroframe.c:1265-1293), in place: orc_add_const_rshift_s16 / _s32
+// (schroorc.orc:146-163): x = (x + ((1 << shift) >> 1)) >> shift, wrapping add, arithmetic shift.
+// Reuses ConvertJob: src == dst plane.
+template < typename T >
+__global__ __launch_bounds__ (kThreads)
+void shift_right_kernel (const ConvertJob * __restrict__ jobs, int njobs, int shift)
+{
+  const int bid = blockIdx.x;
+  const ConvertJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int ty = fdiv (t, job.tiles_x), tx = t - ty * job.tiles_x;
+  const int x = tx * kCvtTW + (threadIdx.x % 64) * 8;
+  const int y = ty * kCvtTH + threadIdx.x / 64;
+  if (y >= job.h || x >= job.w)
+    return;
+  typedef typename std::make_unsigned < T >::type U;
+  const U rnd = (U) ((1u << shift) >> 1);
+  T *row = (T *) ((char *) job.dst + (size_t) y * job.dst_stride);
+  for (int e = 0; e < 8 && x + e < job.w; e++) {
+    const T v = gload < T > (row + x + e);
+    gstore < T > (row + x + e, (T) ((T) ((U) v + rnd) >> shift));
+  }
+}
+
 }                               // namespace
+
+int
+launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp, int shift)
+{
+  if (bpp == 2)
+    hipLaunchKernelGGL ((shift_right_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
+        njobs, shift);
+  else
+    hipLaunchKernelGGL ((shift_right_kernel < int32_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
+        njobs, shift);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "shift_right launch: %s", hipGetErrorString (e));
+  return 0;
+}
 
 void
 pack_tile_geometry (int *groups_x, int *rows)

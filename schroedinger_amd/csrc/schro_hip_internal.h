@@ -268,6 +268,7 @@ int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,
     int total_tiles, int bpp);
 void convert_tile_geometry (int *tw, int *th);
 int launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int total_tiles);
+int launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp, int shift);
 void pack_tile_geometry (int *groups_x, int *rows);
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);

@@ -38,12 +38,17 @@ class HostFrame:
         return C.byref(self.c)
 
 
+def packed_row_bytes(fmt, width):
+    """Bytes of the pixels of one row of a packed frame (schroframe.c:233-330 layouts)."""
+    return {0x100: 4 * (width // 2), 0x101: 4 * (width // 2), 0x102: 4 * width, 0x103: 4 * width,
+            0x105: 8 * (width // 2), 0x106: 16 * (-(-width // 6)), 0x107: 8 * width}[fmt]
+
+
 class PackedHostFrame:
-    """A packed (YUYV / UYVY / AYUV) host frame: one component of 4-byte groups."""
+    """A packed (YUYV / UYVY / AYUV / ARGB / v216 / v210 / AY64) host frame: one component."""
 
     def __init__(self, fmt, width, height):
-        groups = width if fmt == 0x102 else (width + 1) // 2
-        self.rows = np.zeros((height, 4 * groups), np.uint8)
+        self.rows = np.zeros((height, max(packed_row_bytes(fmt, width), 4)), np.uint8)
         self.c = _lib.Frame()
         f = self.c
         f.refcount, f.domain, f.format, f.width, f.height = 1, None, fmt, width, height
@@ -78,8 +83,7 @@ class DeviceFrame:
         if f.format & 0x100:            # packed: rows of 4-byte groups
             host = PackedHostFrame(f.format, f.width, f.height)
             check(self.ctx.lib.schro_hipframe_to_cpu(host.ptr(), self.p))
-            groups = f.width if f.format == 0x102 else f.width // 2
-            return host.rows[:, :4 * groups]
+            return host.rows[:, :packed_row_bytes(f.format, f.width)]
         dt = _DTYPE[f.format & 0xc]
         mul = 2 if f.is_upsampled else 1
         planes = [np.zeros((f.components[k].height * mul, f.components[k].width * mul), dt)

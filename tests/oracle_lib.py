@@ -51,6 +51,10 @@ def lib():
         L.oracle_pack_u8.restype = i
         L.oracle_pack_v210.argtypes = [vp, i, i, i, vp, i]
         L.oracle_pack_v210.restype = i
+        L.oracle_pack_wide.argtypes = [vp, i, i, i, i, vp, i]
+        L.oracle_pack_wide.restype = i
+        L.oracle_shift_right.argtypes = [vp, i, i, i, i, i]
+        L.oracle_shift_right.restype = i
         L.oracle_lowdelay_arith.argtypes = [C.POINTER(LowDelayParams), i]
         L.oracle_lowdelay_arith.restype = i
         L.oracle_lowdelay_decode.argtypes = [vp, C.c_int64, C.c_void_p * 3, C.c_int * 3, C.POINTER(LowDelayParams), i]
@@ -237,6 +241,32 @@ def pack_v210(planes, h_shift, v_shift, width, height):
     r = lib().oracle_pack_v210(_ptr(out), out.strides[0], width, height, C.byref(src), dt.itemsize)
     assert r == 0, "oracle_pack_v210 refused the arguments"
     return out
+
+
+WIDE_ROW_BYTES = {0x105: lambda w: 8 * (w // 2), 0x103: lambda w: 4 * w, 0x107: lambda w: 8 * w}
+
+
+def pack_wide(planes, h_shift, v_shift, width, height, fmt):
+    """schro_frame_convert (v216 0x105 / ARGB 0x103 / AY64 0x107 dest, planar u8 / s16 / s32 src)."""
+    dt = np.asarray(planes[0]).dtype
+    planes = [np.ascontiguousarray(p, dt) for p in planes]
+    src = PackSrc()
+    for k in range(3):
+        src.data[k] = planes[k].ctypes.data
+        src.stride[k] = planes[k].strides[0]
+    src.height, src.width = planes[0].shape
+    src.h_shift, src.v_shift = h_shift, v_shift
+    out = np.zeros((height, WIDE_ROW_BYTES[fmt](width)), np.uint8)
+    r = lib().oracle_pack_wide(_ptr(out), out.strides[0], fmt, width, height, C.byref(src), dt.itemsize)
+    assert r == 0, "oracle_pack_wide refused the arguments"
+    return out
+
+
+def shift_right(a, shift):
+    a = np.ascontiguousarray(a).copy()
+    r = lib().oracle_shift_right(_ptr(a), a.strides[0], a.shape[1], a.shape[0], a.dtype.itemsize, shift)
+    assert r == 0
+    return a
 
 
 MV_DTYPE = np.dtype([("flags", "<u4"), ("metric", "<u4"), ("chroma_metric", "<u4"),

@@ -116,3 +116,62 @@ def test_pack_v210_refuses_non_422_signed_sources(ctx):
     dst = ctx.plane(4, 48, np.uint8)
     with pytest.raises(sa.SchroHipError):
         ctx.pack_v210_batch([(dev, 0, 0, dst, 16, 4)])
+
+
+# ---- v216 / ARGB / AY64 and the > 8-bit output shift --------------------------
+WIDE = [(sa.FORMAT_V216, 1, 0, lambda w: 8 * (w // 2)), (sa.FORMAT_ARGB, 0, 0, lambda w: 4 * w),
+        (sa.FORMAT_AY64, 0, 0, lambda w: 8 * w)]
+
+
+def wide_planes(w, h, hs, dtype, seed):
+    cw = -(-w >> hs)
+    if dtype == np.uint8:
+        mk = lambda hh, ww, sd: (synth.lcg(hh * ww, sd) & 0xff).reshape(hh, ww).astype(np.uint8)
+    else:
+        span = 40000 if dtype == np.int32 else 32768        # AY64 clamps; s32 -> s16 truncates
+        mk = lambda hh, ww, sd: ((synth.lcg(hh * ww, sd).astype(np.int64) * 7919 % (2 * span)) - span).reshape(hh, ww).astype(dtype)
+    return [mk(h, w, seed), mk(h, cw, seed + 1), mk(h, cw, seed + 2)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32])
+@pytest.mark.parametrize("fmt,hs,vs,row_bytes", WIDE)
+def test_pack_wide_formats(ctx, fmt, hs, vs, row_bytes, dtype):
+    cases = []
+    for (w, h) in [(12, 4), (13, 3), (2, 2), (1, 1), (50, 9), (96, 16), (1920, 8), (3842, 3)]:
+        pl = wide_planes(w, h, hs, dtype, w + h)
+        for (W, H) in [(w, h), (w + 7, h + 2), (max(w - 5, 1), max(h - 1, 1))]:
+            if row_bytes(W) > 0:
+                cases.append((pl, W, H))
+    jobs, outs = [], []
+    for (pl, W, H) in cases:
+        dev = [ctx.upload(p) for p in pl]
+        dst = ctx.plane(H, row_bytes(W), np.uint8).fill(0x5a)
+        jobs.append((dev, hs, vs, dst, W, H, fmt))
+        outs.append((dst, dev))
+    ctx.pack_wide_batch(jobs)
+    for (pl, W, H), (dst, dev) in zip(cases, outs):
+        assert np.array_equal(dst.download(), O.pack_wide(pl, hs, vs, W, H, fmt)), (hex(fmt), dtype, pl[0].shape, W, H)
+        dst.free()
+        for d in dev:
+            d.free()
+
+
+def test_pack_wide_refuses_other_chroma_formats(ctx):
+    pl = [ctx.upload(p) for p in wide_planes(16, 4, 1, np.int16, 1)]
+    dst = ctx.plane(4, 64, np.uint8)
+    with pytest.raises(sa.SchroHipError, match="4:4:4"):
+        ctx.pack_wide_batch([(pl, 1, 0, dst, 16, 4, sa.FORMAT_ARGB)])
+    with pytest.raises(sa.SchroHipError, match="4:2:2"):
+        ctx.pack_wide_batch([(pl, 0, 0, dst, 16, 4, sa.FORMAT_V216)])
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_shift_right(ctx, dtype):
+    # schro_frame_shift_right: the intra frame of a > 8-bit stream on its way to an 8-bit picture
+    planes = [synth.full_range(h, w, dtype, seed=3 + n) for n, (h, w) in enumerate([(1, 1), (7, 13), (64, 520), (270, 481)])]
+    for shift in (1, 2, 4):
+        dev = [ctx.upload(p) for p in planes]
+        ctx.shift_right_batch(dev, shift)
+        for d, p in zip(dev, planes):
+            assert np.array_equal(d.download(), O.shift_right(p, shift)), (dtype, shift, p.shape)
+            d.free()

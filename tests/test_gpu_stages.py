@@ -152,3 +152,29 @@ def test_copy_out_to_packed_frames(ctx):
                 assert np.array_equal(out.download(), O.pack_u8(pl, hs, vs, fmt, W, H)), (fmt8, fmt, W, H)
                 out.unref()
         dev.unref()
+
+
+def test_copy_out_of_deep_frames(ctx):
+    # the > 8-bit end of x_combine (schrodecoder.c:2005-2021): an intra picture's s16 / s32 frame,
+    # shifted down when the stream is deeper than the output picture, then schro_frame_convert
+    # into the packed frame the application supplied (v210, v216, ARGB, AY64)
+    lib = ctx.lib
+    for dtype, fmts in ((np.int16, [(sa.FORMAT_V216, 1), (0x106, 1), (sa.FORMAT_ARGB, 0)]),
+                        (np.int32, [(sa.FORMAT_AY64, 0), (sa.FORMAT_V216, 1)])):
+        for fmt, hs in fmts:
+            w, h = 98, 20
+            cw = -(-w >> hs)
+            pl = [synth.image_s(h, w, dtype, seed=5) * 3, synth.image_s(h, cw, dtype, seed=6) * 3,
+                  synth.image_s(h, cw, dtype, seed=7) * 3]
+            dev = frames.DeviceFrame(ctx, frames.frame_format(dtype, hs, 0), w, h).upload(frames.HostFrame(pl, hs, 0))
+            sa.check(lib.schro_hipframe_shift_right(dev.ptr(), 2))
+            shifted = [O.shift_right(p, 2) for p in pl]
+            for a, b in zip(dev.download(), shifted):
+                assert np.array_equal(a, b)
+            for (W, H) in [(w, h), (w + 6, h + 2), (w - 8, h - 4)]:
+                out = frames.DeviceFrame(ctx, fmt, W, H)
+                sa.check(lib.schro_hipframe_convert(out.ptr(), dev.ptr()))
+                want = O.pack_v210(shifted, hs, 0, W, H) if fmt == 0x106 else O.pack_wide(shifted, hs, 0, W, H, fmt)
+                assert np.array_equal(out.download(), want), (dtype, hex(fmt), W, H)
+                out.unref()
+            dev.unref()

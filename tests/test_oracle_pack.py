@@ -143,3 +143,82 @@ def test_v210_matches_the_chain(dtype):
             for (W, H) in [(w, h), (w + 7, h + 2), (max(w - 5, 1), max(h - 1, 1))]:
                 got = O.pack_v210(pl, hs, vs, W, H)
                 assert np.array_equal(got, v210_numpy(pl, hs, vs, W, H)), (dtype, w, h, hs, vs, W, H)
+
+
+# ---- v216 / ARGB / AY64 and the > 8-bit output shift --------------------------
+def test_shift_right_against_the_compiled_reference_kernels():
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import ctypes as C
+    ref = O.reforc()
+    v16 = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16).reshape(256, 256)
+    rng = np.random.default_rng(1)
+    v32 = rng.integers(-2 ** 31, 2 ** 31, (64, 200)).astype(np.int32)
+    for shift in (1, 2, 4, 6, 8):
+        a = v16.copy()
+        for row in a:
+            ref.orc_add_const_rshift_s16(row.ctypes.data_as(C.c_void_p), (1 << shift) >> 1, shift, row.size)
+        assert np.array_equal(O.shift_right(v16, shift), a), shift
+        b = v32.copy()
+        for row in b:
+            ref.orc_add_const_rshift_s32(row.ctypes.data_as(C.c_void_p), (1 << shift) >> 1, shift, row.size)
+        assert np.array_equal(O.shift_right(v32, shift), b), shift
+
+
+def test_depth_conversions_against_the_compiled_reference_kernels():
+    # what feeds pack_v216 / pack_argb / pack_ayuv64: x - 128 from u8, truncation from s32
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import ctypes as C
+    ref = O.reforc()
+    u8 = np.arange(256, dtype=np.uint8)
+    s16 = np.zeros(256, np.int16)
+    ref.orc_offsetconvert_s16_u8(s16.ctypes.data_as(C.c_void_p), u8.ctypes.data_as(C.c_void_p), 256)
+    assert np.array_equal(s16, u8.astype(np.int16) - 128)
+    s32 = np.array([0, 1, -1, 32767, 32768, -32768, -32769, 65536 + 5, -70000, 2 ** 31 - 1], np.int32)
+    t16 = np.zeros(s32.size, np.int16)
+    ref.orc_convert_s16_s32(t16.ctypes.data_as(C.c_void_p), s32.ctypes.data_as(C.c_void_p), s32.size)
+    assert np.array_equal(t16, s32.astype(np.int16))
+    # the oracle applies exactly these before packing: ARGB of (y, 0, 0) is (0xff, y, y, y) mod 256
+    y = (u8.astype(np.int16) - 128).reshape(1, 256)
+    z = np.zeros((1, 256), np.int16)
+    argb = O.pack_wide([y, z, z], 0, 0, 256, 1, 0x103).reshape(256, 4)
+    assert np.array_equal(argb[:, 0], np.full(256, 0xff, np.uint8))
+    for c in (1, 2, 3):
+        assert np.array_equal(argb[:, c], (u8.astype(np.int16) - 128).astype(np.uint8))
+    argb8 = O.pack_wide([u8.reshape(1, 256), np.full((1, 256), 128, np.uint8), np.full((1, 256), 128, np.uint8)],
+                        0, 0, 256, 1, 0x103)
+    assert np.array_equal(argb8, argb.reshape(1, -1))
+
+
+def test_wide_packs_against_a_numpy_model():
+    rng = np.random.default_rng(7)
+    h, w = 9, 22
+    # AY64 from s32 4:4:4
+    pl = [rng.integers(-70000, 70000, (h, w)).astype(np.int32) for _ in range(3)]
+    got = O.pack_wide(pl, 0, 0, w, h, 0x107).view("<u2").reshape(h, w, 4)
+    assert np.all(got[:, :, 0] == 0xffff)
+    for k in range(3):
+        assert np.array_equal(got[:, :, 1 + k], np.clip(pl[k].astype(np.int64) + 0x8000, 0, 0xffff))
+    # ARGB from s16 4:4:4: the YCoCg-R inverse
+    pl = [rng.integers(-300, 300, (h, w)).astype(np.int16) for _ in range(3)]
+    y, co, cg = [p.astype(np.int64) for p in pl]
+    t = y + (cg >> 1)
+    b = t - (co >> 1)
+    got = O.pack_wide(pl, 0, 0, w, h, 0x103).reshape(h, w, 4)
+    assert np.array_equal(got[:, :, 1], (b + co).astype(np.uint8)) and np.array_equal(got[:, :, 2], (t + cg).astype(np.uint8))
+    assert np.array_equal(got[:, :, 3], b.astype(np.uint8))
+    # v216 from s16 4:2:2: bytes of the little-endian s16 lines, each doubled
+    yp = rng.integers(-512, 512, (h, w)).astype(np.int16)
+    up, vp = [rng.integers(-512, 512, (h, w // 2)).astype(np.int16) for _ in range(2)]
+    got = O.pack_wide([yp, up, vp], 1, 0, w, h, 0x105).reshape(h, w // 2, 8)
+    yb, ub, vb = [p.view(np.uint8) for p in (yp, up, vp)]
+    j = np.arange(w // 2)
+    assert np.array_equal(got[:, :, 0], ub[:, j]) and np.array_equal(got[:, :, 1], ub[:, j])
+    assert np.array_equal(got[:, :, 2], yb[:, 2 * j]) and np.array_equal(got[:, :, 6], yb[:, 2 * j + 1])
+    assert np.array_equal(got[:, :, 4], vb[:, j])
+    # crop and edge extension
+    big = O.pack_wide(pl, 0, 0, w + 5, h + 3, 0x103).reshape(h + 3, w + 5, 4)
+    assert np.array_equal(big[:h, :w], O.pack_wide(pl, 0, 0, w, h, 0x103).reshape(h, w, 4))
+    assert np.array_equal(big[h:, :w], np.repeat(big[h - 1:h, :w], 3, axis=0))
+    assert np.array_equal(big[:, w:], np.repeat(big[:, w - 1:w], 5, axis=1))
