@@ -1259,7 +1259,7 @@ schro_hip_obmc_stamps_dump (void)
   (void) hipDeviceSynchronize ();
   std::vector < unsigned long long >h (16384 * 16);
   (void) hipMemcpy (h.data (), g_stamps, h.size () * 8, hipMemcpyDeviceToHost);
-  for (int n = 1; n <= 9; n++) {
+  for (int n = 1; n <= 11; n++) {
     std::vector < unsigned long long >v;
     for (int b = 0; b < 16384; b++)
       if (h[b * 16 + 9])
@@ -1383,8 +1383,11 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   // vs 0.275 ms): 77 KB of LDS per tile leave two workgroups per CU to hide a chain of seven
   // barrier phases with two global round trips in it.
   static const bool use_staged = getenv ("SCHRO_HIP_OBMC_KERNEL") && strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "staged") == 0;
+  // default for half- / quarter-pel references and blocks up to 16 wide: the row kernel
+  // (obmc_row.hip); SCHRO_HIP_OBMC_KERNEL=item keeps obmc.hip's item kernel for A/B runs
+  static const bool use_row = !getenv ("SCHRO_HIP_OBMC_KERNEL") || strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
   std::vector < ObmcJob > all (nplanes);
-  std::vector < int >key (nplanes);
+  std::vector < int >key (nplanes), row_nd (nplanes);
   for (int p = 0; p < nplanes; p++) {
     const SchroHipObmcPlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
@@ -1443,8 +1446,11 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     j.w = pl.width;
     j.h = pl.height;
     const int variant = variant_of (pl);
-    const int nd = (variant == 1 && use_staged) ? obmc_stage_nd (j) : 0;
-    key[p] = pl.mv_precision | (variant << 4) | (nd << 8);
+    const int nd_staged = (variant == 1 && use_staged) ? obmc_stage_nd (j) : 0;
+    const int nd_row = (variant == 1 && use_row && !nd_staged) ? obmc_row_nd (j) : 0;
+    // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
+    key[p] = pl.mv_precision | (variant << 4) | ((nd_staged ? nd_staged : nd_row) << 8) | (nd_row ? 1 << 16 : 0);
+    row_nd[p] = nd_row;
   }
   // one launch per (precision class, kernel) group, keeping plane order
   std::vector < char >done (nplanes, 0);
@@ -1452,8 +1458,13 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     if (done[first])
       continue;
     const int prec = planes[first].mv_precision;
-    const int nd = key[first] >> 8;
-    const int variant = nd ? 2 : ((key[first] >> 4) & 15);
+    int nd = (key[first] >> 8) & 0xff;
+    const bool row = (key[first] >> 16) & 1;
+    if (row)
+      for (int p = first; p < nplanes; p++)
+        if (!done[p] && key[p] == key[first])
+          nd = std::max (nd, row_nd[p]);
+    const int variant = nd ? (row ? 3 : 2) : ((key[first] >> 4) & 15);
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
     for (int p = first; p < nplanes; p++) {
@@ -1479,7 +1490,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       return r;
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = nd ? launch_obmc_stage (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
+      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
+          : nd ? launch_obmc_stage (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
           : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
     }
     if (r)

@@ -947,6 +947,8 @@ obmc_item_geometry (ObmcJob * j)
   j->m_ybsep = div_magic (j->ybsep);
   j->m_nseg = div_magic (nseg);
   j->m_lpi = div_magic (lpi);
+  j->m_xramp = div_magic (2 * j->xoff - 1);
+  j->m_yramp = div_magic (2 * j->yoff - 1);
 }
 
 // variant 0: per-pixel kernel (any weights), 64x4 tiles

@@ -1,0 +1,703 @@
+// obmc_row.hip -- OBMC + residual add + u8 clamp, default picture weights, half- and
+// quarter-pel references: the kernel bench.py's workload runs.
+//
+// Same arithmetic and the same outer structure as obmc.hip's item kernel (a 256-thread
+// workgroup owns a 128x32 output tile and a 16-bit accumulator tile in LDS; blocks are decoded
+// once per tile, sorted by class, expanded into (block, row) items; picture-rim blocks take the
+// exact per-sample path; finish = round, add the residual, clamp, store) -- what changes is the
+// hot loop, which r01's counters showed to be instruction issue (156 M VALU wave-instructions
+// per 8 x 2160p, ~100 lane-operations per output sample):
+//
+//   * a lane owns a whole block ROW (12 luma pixels), not a 4-pixel segment: one item decode,
+//     one address computation, one weight-table read per row instead of three;
+//   * the lane loads its own row's 16-byte tile rows (adjacent lanes = adjacent rows of a
+//     block = the same 128-byte line of the 16x8-tiled half-pel image: one TA cycle per
+//     4 lanes) straight into registers and aligns them there (a two-level select by the
+//     window's dword phase + v_alignbyte) -- no LDS staging buffer, which frees 11 KB of LDS;
+//   * prediction is byte-parallel: at half / quarter pel orc_combine4_nxm_u8
+//     (schroorc.orc:1635-1662) degenerates to copy / 2-sample / 4-sample rounding averages,
+//     v_lerp_u8 on four pixels per instruction (exact, see avg4); the horizontal phase is a
+//     v_bfi select (lerp (E, E) = E), the vertical phase a class of the item sort; both
+//     references of a block are blended with one more v_lerp_u8 (avgub);
+//   * weights are u16 pairs (v_pk_mul_lo_u16) and two pixels share an accumulator word, so a
+//     row is accumulated with xblen / 2 ds_add_u32 instead of xblen.
+// Eighth-pel (arbitrary bilinear weights) and plain references stay with obmc.hip.
+//
+// References: schromotion8.c:303-335 (get_block), :542-657 (block arithmetic), :673-693
+// (accumulate_slow), :700-929 (schro_motion_render_u8); schroframe.c:2288-2482
+// (schro_upsampled_frame_get_block_fast_precN); schroorc.orc:636-661 (orc_rrshift6_add_s16_2d).
+
+#include "schro_hip_internal.h"
+#include "obmc_common.h"
+#include <algorithm>
+
+namespace schro {
+namespace {
+
+constexpr int kRThreads = 256;
+constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1)
+constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
+constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
+constexpr int kRBlkCap = 192;           // decoded blocks per chunk (<= kRThreads)
+constexpr int kRItemCap = 1536;         // (block, row) items per chunk
+constexpr int kRWCap = 16 * 8;          // (row, pixel pair) weight words
+constexpr int kRCls = 7;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 rim
+constexpr int kRRim = kRCls - 1;
+
+typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
+typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+
+struct __attribute__ ((aligned (16))) RowBlk {
+  int y, x;                     // block origin relative to the tile
+  int mode_dc;                  // bits 0-1 mode, bits 8..: DC value; rim blocks: as obmc.hip
+  int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
+  int off[2];                   // offset of the window's first 16-byte chunk in its tile row (rim: fx, fy of ref 0)
+  uint32_t rxm[2];              // bits 1..: all ones when the window sits at a horizontal half position,
+                                // bit 0: at a vertical one (rim: fx, fy of ref 1)
+};
+
+// obmc_weight_1d (obmc_common.h; schromotion.c:40-69) with get_ramp's division by
+// 2 * offset - 1 done as a multiplication (m = ceil (2^32 / (2 * offset - 1)), from the host)
+__device__ __forceinline__ int
+weight_1d (int i, int blen, int offset, uint32_t m)
+{
+  if (offset == 0)
+    return 8;
+  int x = i;
+  if (i >= 2 * offset) {
+    if (blen - 1 - i >= 2 * offset)
+      return 8;
+    x = blen - 1 - i;
+  }
+  if (offset == 1)
+    return x == 0 ? 3 : 5;
+  return 1 + mdiv (6 * x + offset - 1, 2 * offset - 1, m);
+}
+
+__device__ __forceinline__ uint32_t
+lerp1 (uint32_t a, uint32_t b)
+{
+  return __builtin_amdgcn_lerp (a, b, 0x01010101u);     // per byte (a + b + 1) >> 1 = avgub
+}
+
+__device__ __forceinline__ void
+acc_add_exact (uint32_t * word, int high, uint32_t value)
+{
+  // 16-bit wrapping add inside one half of the word (a DC value outside 0..255: the
+  // reference's s16 sum wraps and must not carry into the neighbour pixel)
+  unsigned int old = __hip_atomic_load (word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), assumed;
+  do {
+    assumed = old;
+    const unsigned int upd = high ? (assumed & 0xffffu) | ((assumed + (value << 16)) & 0xffff0000u)
+        : (assumed & 0xffff0000u) | ((assumed + value) & 0xffffu);
+    old = atomicCAS (word, assumed, upd);
+  } while (old != assumed);
+}
+
+// the accumulator word and half of tile-relative pixel (x, y); `par` = 1 when block origins are odd
+__device__ __forceinline__ uint32_t *
+acc_word (uint32_t * acc, int par, int x, int y, int *half)
+{
+  const int idx = x + kRMargin + par;
+  *half = idx & 1;
+  return acc + y * kRAccW + (idx >> 1);
+}
+
+// ---- one reference's prediction of a block row: ND dwords of 4 pixels ---------------------
+// RY: the window sits at a vertical half position (two sample rows)
+// (RY with ry1 == 0: "the second row" is the first one again -- the same cache lines -- and the
+// vertical average of a row with itself is that row; this lets blocks with two references be
+// ONE class whatever their vertical phases)
+template < int ND, bool RY >
+__device__ __forceinline__ void
+predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uint32_t rxm, uint32_t ry1, uint32_t * out)
+{
+  constexpr int NCH = ND <= 2 ? 2 : 3;  // 16-byte tile rows that can hold the 2 * xblen + 15 bytes from the chunk's start
+  constexpr int NU = 2 * ND + 1;        // dwords from the window's first dword on
+  const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
+  const uint32_t s = phase >> 4;        // x & 15 of the first sample
+  const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
+  const uint8_t *base = job.ref[r] + off_r;
+  uint32_t c[RY ? 2 : 1][4 * NCH + 2];
+#pragma unroll
+  for (int v = 0; v < (RY ? 2 : 1); v++) {
+    const uint32_t y = (phase & 7u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
+    const uint8_t *p = base + (__umul24 (y >> 3, tile_row_bytes) + ((y & 7u) << 4));
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j < NCH - 1 || last) {
+        const u32x4 q = gload < u32x4 > (p + 128 * j);
+        c[v][4 * j + 0] = q.x;
+        c[v][4 * j + 1] = q.y;
+        c[v][4 * j + 2] = q.z;
+        c[v][4 * j + 3] = q.w;
+      }
+    }
+  }
+  // (masks and v_bfi, not ?: on array elements: the compiler turns such a select into a
+  // run-time index and moves the array to scratch memory)
+  const uint32_t m2 = (s & 8u) ? 0xffffffffu : 0u, m1 = (s & 4u) ? 0xffffffffu : 0u;
+  const uint32_t sh = s & 3u;
+  uint32_t h[RY ? 2 : 1][ND], x[RY ? 2 : 1][ND];
+#pragma unroll
+  for (int v = 0; v < (RY ? 2 : 1); v++) {
+    // the window's dwords u[0 .. NU): c[q .. q + NU), q = s >> 2 in 0..3, by a two-level select
+    uint32_t t[NU + 1], u[NU];
+#pragma unroll
+    for (int i = 0; i < NU + 1; i++)
+      t[i] = (c[v][i + 2] & m2) | (c[v][i] & ~m2);
+#pragma unroll
+    for (int i = 0; i < NU; i++)
+      u[i] = (t[i + 1] & m1) | (t[i] & ~m1);
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const uint32_t lo = __builtin_amdgcn_alignbyte (u[2 * k + 1], u[2 * k], sh);
+      const uint32_t hi = __builtin_amdgcn_alignbyte (u[2 * k + 2], u[2 * k + 1], sh);
+      const uint32_t e = __builtin_amdgcn_perm (hi, lo, 0x06040200u);       // half-pel columns hx + 2k
+      const uint32_t o = __builtin_amdgcn_perm (hi, lo, 0x07050301u);       // hx + 1 + 2k
+      const uint32_t o2 = (o & rxm) | (e & ~rxm);       // integer horizontal position: average e with itself
+      h[v][k] = lerp1 (e, o2);
+      x[v][k] = e ^ o2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    if constexpr (RY) {
+      // per byte (a + b + c + d + 2) >> 2 exactly: with c1 = (a+b+1)>>1, c2 = (c+d+1)>>1 and l = the
+      // bit an average rounded up by, (c1 + c2 + 1 - (l1 | l2)) >> 1; for a + a + c + c: (a + c + 1) >> 1
+      out[k] = __builtin_amdgcn_lerp (h[0][k], h[1][k], ~(x[0][k] | x[1][k]));
+    } else {
+      out[k] = h[0][k];
+    }
+  }
+}
+
+// one pass: every lane predicts one (block, row) item and adds it into the accumulator tile
+// CLS 0-3 both references, 4-5 the first, 6-7 the second, 8 DC
+template < int ND, int CLS, bool EXACT >
+__device__ __forceinline__ void
+row_pass (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, const uint32_t * s_wp,
+    uint32_t * acc, int par, int npair, int it, int hi)
+{
+  const bool st = CLS == 0 && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
+  const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
+  const int e = s_item[min (it, hi - 1)];
+  const RowBlk & hb = s_hot[e & 0xff];
+  const int row = e >> 8;
+  uint32_t p[ND];
+  auto rx_mask = [] (uint32_t f) { return (uint32_t) ((int32_t) f >> 1); };       // bits 1.. smeared over the word
+  if constexpr (CLS == 5) {
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      p[k] = (uint32_t) (hb.mode_dc >> 8) * 0x01010101u;
+  } else if constexpr (CLS == 0) {
+    uint32_t p1[ND];
+    const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
+    predict_row < ND, true > (job, 0, hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
+    __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight
+    predict_row < ND, true > (job, 1, hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
+  } else {
+    constexpr int r = CLS >= 3 ? 1 : 0;
+    constexpr bool RY = CLS == 2 || CLS == 4;
+    const uint32_t ph = ((uint32_t) hb.rows >> (16 + 8 * r)) & 0xffu;
+    predict_row < ND, RY > (job, r, hb.off[r], ph, row, rx_mask (hb.rxm[r]), 1u, p);
+  }
+  if (st) {
+    asm volatile ("" :: "v" (p[0]));
+    job.stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime () - t0;
+  }
+  if (it >= hi)
+    return;
+  int half;
+  uint32_t *aw = acc_word (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
+  const uint32_t *w = s_wp + __umul24 (row, npair);
+#pragma unroll
+  for (int k = 0; k < 2 * ND; k++) {
+    if (k < npair) {
+      const uint32_t px = __builtin_amdgcn_perm (0u, p[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+      const uint32_t v = __builtin_bit_cast (uint32_t, (u16x2) (__builtin_bit_cast (u16x2, px) * __builtin_bit_cast (u16x2, w[k])));
+      if constexpr (EXACT) {
+        acc_add_exact (aw + k, 0, v & 0xffffu);
+        acc_add_exact (aw + k, 1, v >> 16);
+      } else {
+        atomicAdd (aw + k, v);  // sums of pred * weight <= 255 * 64: no carry between the halves
+      }
+    }
+  }
+  if (st) {
+    __builtin_amdgcn_s_waitcnt (0);
+    job.stamps[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime () - t0;
+  }
+}
+
+// the passes of one class; *turn counts the passes of the classes before it, so that the four
+// waves take the tile's passes in turn whatever the class sizes (with nine classes most have one
+// or two passes: "wave w takes the w-th pass of every class" left wave 0 with nine passes and
+// wave 3 with none)
+template < int ND, int CLS >
+__device__ __forceinline__ void
+row_class (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, const uint32_t * s_wp,
+    uint32_t * acc, int par, int npair, int lo, int hi, bool exact, int *turn)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int npass = (hi - lo + 63) >> 6;
+  constexpr int kWaves = kRThreads / 64;
+  const int k0 = (wave - *turn) & (kWaves - 1);
+  *turn = (*turn + npass) & (kWaves - 1);
+  if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
+    for (int k = k0; k < npass; k += kWaves)
+      row_pass < ND, CLS, true > (job, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+  } else {
+    for (int k = k0; k < npass; k += kWaves)
+      row_pass < ND, CLS, false > (job, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+  }
+}
+
+// picture-rim block rows: per-sample clamp and weight folding (accumulate_slow), 4 pixels
+template < int PC >
+__device__ __forceinline__ void
+row_slow (const ObmcJob & job, int bx, int by, int md, const int *fx, const int *fy, int row, int seg, int x_lo,
+    int y_lo, int xfold_hi, int yfold_hi, const int *s_wx, const int *s_wy, uint32_t * acc, int par, bool exact)
+{
+  const int prec = job.prec;
+  const int y = by + row, xs = bx + 4 * seg;
+  const int mode = md & 3;
+  int pred[4];
+  if (mode == 0) {
+    pred[0] = pred[1] = pred[2] = pred[3] = md >> 8;
+  } else {
+    int val[2][4] = { {0, 0, 0, 0}, {0, 0, 0, 0} };
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      if (mode & (r + 1)) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          val[r][e] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h,
+              fx[r] + (4 * seg + e) * (1 << prec), fy[r] + row * (1 << prec), prec);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      pred[e] = mode == 3 ? (val[0][e] + val[1][e] + 1) >> 1 : (mode == 1 ? val[0][e] : val[1][e]);
+  }
+  int wy = s_wy[row];
+  if (y < job.yoff)
+    wy += s_wy[2 * job.yoff - row - 1];
+  if (y >= yfold_hi)
+    wy += s_wy[2 * (job.yblen - job.yoff) - row - 1];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int x = xs + e, idx = 4 * seg + e;
+    if (idx >= job.xblen)
+      continue;
+    int wx = s_wx[idx];
+    if (x < job.xoff)
+      wx += s_wx[2 * job.xoff - idx - 1];
+    if (x >= xfold_hi)
+      wx += s_wx[2 * (job.xblen - job.xoff) - idx - 1];
+    int half;
+    uint32_t *aw = acc_word (acc, par, x - x_lo, y - y_lo, &half);
+    const uint32_t v = (uint32_t) (pred[e] * wx * wy);
+    if (exact)
+      acc_add_exact (aw, half, v & 0xffffu);
+    else
+      atomicAdd (aw, (v & 0xffffu) << (16 * half));
+  }
+}
+
+// out = sat_u8 (residual + ((acc + 32) >> 6)) for one tile
+__device__ __forceinline__ bool
+row_finish_is_fast (const ObmcJob & job, int x_lo, int x_hi)
+{
+  return job.res_bpp == 2 && x_hi - x_lo == kRTW
+      && ((((uintptr_t) job.residual) | (uintptr_t) job.residual_stride) & 15) == 0
+      && ((((uintptr_t) job.out) | (uintptr_t) job.out_stride) & 7) == 0;
+}
+
+// the fast finish's residual: 8 pixels of two rows per lane, fetched before the tile's last barrier
+__device__ __forceinline__ void
+row_finish_prefetch (const ObmcJob & job, int tid, int x_lo, int y_lo, int y_hi, u32x4 * res)
+{
+#pragma unroll
+  for (int n = 0; n < kRTH * (kRTW / 8) / kRThreads; n++) {
+    const int it = tid + n * kRThreads, g = it & (kRTW / 8 - 1), y = y_lo + (it >> 4);
+    if (y < y_hi)
+      res[n] = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * (x_lo + 8 * g));
+  }
+}
+
+__device__ __forceinline__ void
+row_finish (const ObmcJob & job, const uint32_t * acc, int par, int tid, int x_lo, int y_lo, int x_hi, int y_hi,
+    bool fast, const u32x4 * res)
+{
+  if (fast) {
+    // one lane: 8 pixels of one row, packed 16-bit arithmetic (the reference's adds wrap at 16 bits)
+#pragma unroll
+    for (int n = 0; n < kRTH * (kRTW / 8) / kRThreads; n++) {
+      const int it = tid + n * kRThreads;
+      const int g = it & (kRTW / 8 - 1), yy = it >> 4;
+      static_assert (kRTW / 8 == 16 && (kRTH * (kRTW / 8)) % kRThreads == 0, "8-pixel groups per tile row");
+      const int y = y_lo + yy;
+      if (y >= y_hi)
+        continue;
+      const uint32_t *ap = acc + yy * kRAccW + (kRMargin / 2 + 4 * g);
+      uint32_t av[4];
+      if (par) {
+        // pixel 8 g sits in the high half of word 4 g + 8: shift the five words down by one pixel
+        const uint32_t w0 = ap[0], w1 = ap[1], w2 = ap[2], w3 = ap[3], w4 = ap[4];
+        av[0] = __builtin_amdgcn_alignbit (w1, w0, 16);
+        av[1] = __builtin_amdgcn_alignbit (w2, w1, 16);
+        av[2] = __builtin_amdgcn_alignbit (w3, w2, 16);
+        av[3] = __builtin_amdgcn_alignbit (w4, w3, 16);
+      } else {
+        const u32x4 a = *reinterpret_cast < const u32x4 * >(ap);
+        av[0] = a.x;
+        av[1] = a.y;
+        av[2] = a.z;
+        av[3] = a.w;
+      }
+      const int x = x_lo + 8 * g;
+      const u32x4 r = res[n];
+      const uint32_t rv[4] = { r.x, r.y, r.z, r.w };
+      uint32_t t[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s16x2 v = (__builtin_bit_cast (s16x2, av[k]) + (short) 32) >> 6;
+        v = v + __builtin_bit_cast (s16x2, rv[k]);
+        v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+        t[k] = __builtin_bit_cast (uint32_t, v);
+      }
+      u32x2 o;
+      o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
+      o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
+      gstore < u32x2 > (job.out + (size_t) y * job.out_stride + x, o);
+    }
+    return;
+  }
+  // orc_rrshift6_add_s16_2d / _s32_2d on one pixel per lane and step
+  for (int it = tid; it < kRTH * kRTW; it += kRThreads) {
+    const int xx = it & (kRTW - 1), yy = it >> 7;
+    static_assert (kRTW == 128, "tile row = 128 pixels");
+    const int x = x_lo + xx, y = y_lo + yy;
+    if (y >= y_hi || x >= x_hi)
+      continue;
+    int half;
+    const uint32_t *aw = acc_word (const_cast < uint32_t * >(acc), par, xx, yy, &half);
+    const int16_t a = (int16_t) (*aw >> (16 * half));
+    const char *rrow = (const char *) job.residual + (size_t) y * job.residual_stride;
+    const int16_t res = job.res_bpp == 2 ? gload < int16_t > ((const int16_t *) rrow + x)
+        : (int16_t) gload < int32_t > ((const int32_t *) rrow + x);   // convlw
+    int16_t t1 = (int16_t) (a + 32);
+    t1 = (int16_t) (t1 >> 6);
+    t1 = (int16_t) (res + t1);
+    gstore < uint8_t > (job.out + (size_t) y * job.out_stride + x, (uint8_t) clampi (t1, 0, 255));
+  }
+}
+
+template < int ND >
+__device__ __forceinline__ void
+obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  __shared__ __attribute__ ((aligned (16))) uint32_t acc[kRTH * kRAccW];
+  __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
+  __shared__ RowBlk s_hot[kRBlkCap];
+  __shared__ uint16_t s_item[kRItemCap];
+  __shared__ uint32_t s_wp[kRWCap];
+  __shared__ int s_cnt[kRCls], s_icnt[kRCls];   // blocks / items of each class
+  __shared__ int s_wide;
+
+  const uint64_t t_start = __builtin_amdgcn_s_memtime ();
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const uint32_t entry = order ? __builtin_amdgcn_readfirstlane (gload < uint32_t > (order + bid)) : 0u;
+  const ObmcJob job = jobs[order ? (int) (entry >> 16) : find_job (jobs, njobs, bid)];
+  // scratch runs (SCHRO_HIP_OBMC_STAMPS): cycles since the workgroup started, per phase
+#define RSTAMP(n) do { if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) \
+    job.stamps[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime () - t_start; } while (0)
+  const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
+  const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
+  const int tid = threadIdx.x;
+  const int x_lo = tx * kRTW, y_lo = ty * kRTH;
+  const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + kRTH, job.h);
+
+  static_assert ((kRTH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
+  for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
+    reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
+  if (tid < job.xblen)
+    s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
+  if (tid >= 64 && tid - 64 < job.yblen)
+    s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
+
+  const int xblen = job.xblen, yblen = job.yblen, xbsep = job.xbsep, ybsep = job.ybsep;
+  const int xoff = job.xoff, yoff = job.yoff, prec = job.prec;
+  const int par = xoff & 1;             // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
+  const int npair = xblen >> 1;
+  const int i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
+  const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
+  const int j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
+  const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
+  const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
+  const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
+  const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+  const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
+  const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;     // last valid half-pel sample column / row
+  const int chunk_cap = min (kRBlkCap, kRItemCap / min (yblen, kRTH));
+  const uint32_t m_npair = div_magic (npair);
+  // the first chunk's motion vectors start their way from memory now, beside the set-up below
+  uint32_t mv_pre[3] = { 0u, 0u, 0u };
+  if (tid < min (chunk_cap, nblk)) {
+    const int bj = nbi == 1 ? tid : (int) (((uint32_t) tid * m16_nbi) >> 16);
+    const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) (j_lo + bj) * job.nbx + (i_lo + (tid - bj * nbi)));
+    mv_pre[0] = gload < uint32_t > (mvp);
+    mv_pre[1] = gload < uint32_t > (mvp + 12);
+    mv_pre[2] = gload < uint32_t > (mvp + 16);
+  }
+  __syncthreads ();             // ramps visible
+  // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each)
+  for (int i = tid; i < yblen * npair && i < kRWCap; i += kRThreads) {
+    const int r = mdiv (i, npair, m_npair), pr = i - r * npair;
+    s_wp[i] = (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16);
+  }
+
+  RSTAMP (1);
+  bool exact = false;
+  for (int chunk0 = 0; chunk0 < nblk; chunk0 += chunk_cap) {
+    const int nb = min (chunk_cap, nblk - chunk0);
+    if (tid < kRCls) {
+      s_cnt[tid] = 0;
+      s_icnt[tid] = 0;
+    }
+    if (tid == 32)
+      s_wide = 0;
+    __syncthreads ();           // accumulator / weights ready; the previous chunk's tables consumed
+    // ---- decode one block per thread ----------------------------------------------------
+    RowBlk info;
+    int key = 0, rank = 0, istart = 0, my_rows = 0, my_ra = 0;
+    const bool have = tid < nb;
+    if (have) {
+      const int blk = chunk0 + tid;
+      const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
+      const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
+      uint32_t flags = mv_pre[0], v01 = mv_pre[1], v23 = mv_pre[2];
+      if (chunk0 > 0) {
+        const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
+        flags = gload < uint32_t > (mvp);
+        v01 = gload < uint32_t > (mvp + 12);
+        v23 = gload < uint32_t > (mvp + 16);
+      }
+      const int bx = xbsep * i - xoff, by = ybsep * jj - yoff;
+      info.x = bx - x_lo;
+      info.y = by - y_lo;
+      const int mode = flags & 3;
+      const bool interior = i >= 1 && i < job.max_x_blocks && jj >= 1 && jj < job.max_y_blocks;
+      const int dc = job.comp == 0 ? (int16_t) (v01 & 0xffff)
+          : job.comp == 1 ? (int16_t) (v01 >> 16) : (int16_t) (v23 & 0xffff);
+      // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
+      const int pdc = interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
+      int md = mode | (pdc << 8);
+      int phases = 0, ry[2] = { 0, 0 };
+      bool clamped = false;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        int fx, fy;
+        mv_origin (job, bx, by, v01, v23, r, &fx, &fy);
+        int gx0 = fx, gy0 = fy, rx = 0;
+        if (prec >= 2) {
+          const int x8 = prec == 2 ? fx * 2 : fx, y8 = prec == 2 ? fy * 2 : fy;
+          rx = x8 & 3;
+          ry[r] = y8 & 3;
+          gx0 = x8 >> 2;
+          gy0 = y8 >> 2;
+        }
+        // both bilinear taps of every sample of the block (conservative for integer positions)
+        const int gx1 = gx0 + 2 * xblen - 1, gy1 = gy0 + 2 * (yblen - 1) + 1;
+        bool inside = gx0 >= 0 && gy0 >= 0 && gx1 <= gw && gy1 <= gh;
+        // every 16-byte tile row a lane may fetch lies inside the row pitch
+        if (inside && (gx0 & ~15) + 16 * (((gx0 & 15) + 2 * xblen + 15) >> 4) > job.ref_stride[r])
+          inside = false;
+        if (!inside && (mode & (r + 1)))
+          clamped = true;
+        info.off[r] = inside ? (gy0 >> 3) * (8 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
+        phases |= inside ? ((gy0 & 7) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+        info.rxm[r] = (rx ? 0xfffffffeu : 0u) | (ry[r] ? 1u : 0u);
+      }
+      info.mode_dc = md;
+      const int ra = max (0, -info.y), rb = min (yblen, y_hi - by);
+      info.rows = ra | ((rb - ra) << 8) | (phases << 16);
+      const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + xblen > xfold_hi;
+      const bool wide_dc = mode == 0 && (unsigned) pdc > 255u;
+      if (wide_dc)
+        s_wide = 1;
+      if (clamped || fold || wide_dc || yblen * npair > kRWCap) {
+        key = kRRim;
+        // the rim path works from the clamped fetch origins
+        int fx, fy;
+        mv_origin (job, bx, by, v01, v23, 0, &fx, &fy);
+        info.off[0] = fx;
+        info.off[1] = fy;
+        mv_origin (job, bx, by, v01, v23, 1, &fx, &fy);
+        info.rxm[0] = (uint32_t) fx;
+        info.rxm[1] = (uint32_t) fy;
+      } else if (mode == 3) {
+        key = 0;
+      } else if (mode == 0) {
+        key = 5;
+      } else {
+        key = mode == 1 ? 1 + (ry[0] ? 1 : 0) : 3 + (ry[1] ? 1 : 0);
+      }
+      rank = atomicAdd (&s_cnt[key], 1);
+      // the block's rows take the next free items of its class (any order within a class will do)
+      my_rows = key == kRRim ? 0 : rb - ra;
+      my_ra = ra;
+      istart = my_rows ? atomicAdd (&s_icnt[key], my_rows) : 0;
+    }
+    __syncthreads ();
+    RSTAMP (2);
+    if (s_wide && !exact) {
+      exact = true;
+      if (chunk0 > 0) {         // adds already made may have carried: start the tile over
+        __syncthreads ();
+        for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
+          reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
+        chunk0 = -chunk_cap;
+        continue;
+      }
+    }
+    int cbase[kRCls + 1], ibase[kRCls];       // first sorted block / first item of each class
+    cbase[0] = 0;
+    ibase[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kRCls; k++)
+      cbase[k + 1] = cbase[k] + s_cnt[k];
+#pragma unroll
+    for (int k = 0; k + 1 < kRCls; k++)
+      ibase[k + 1] = ibase[k] + s_icnt[k];
+    if (have) {
+      int base = 0, ib = 0;
+#pragma unroll
+      for (int k = 0; k < kRCls; k++) {
+        base = key == k ? cbase[k] : base;
+        ib = key == k ? ibase[k] : ib;
+      }
+      const int slot = base + rank;
+      s_hot[slot] = info;
+      for (int r = 0; r < my_rows; r++)
+        s_item[ib + istart + r] = (uint16_t) (slot | ((my_ra + r) << 8));
+    }
+    __syncthreads ();
+    RSTAMP (3);
+    // ---- accumulate: a wave's pass is 64 items of one class -------------------------------
+    int turn = 0;
+#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, s_item, s_hot, s_wp, acc, par, npair, \
+    ibase[C], ibase[C + 1], exact, &turn)
+    SCHRO_ROW_CLASS (0);
+    SCHRO_ROW_CLASS (1);
+    SCHRO_ROW_CLASS (2);
+    SCHRO_ROW_CLASS (3);
+    SCHRO_ROW_CLASS (4);
+    SCHRO_ROW_CLASS (5);
+#undef SCHRO_ROW_CLASS
+
+    RSTAMP (4);
+    // ---- picture-rim blocks: exact clamp / fold path -----------------------------------------
+    if (cbase[kRRim + 1] > cbase[kRRim]) {
+      const int nseg = (xblen + 3) >> 2, per_block = yblen * nseg;
+      const uint32_t m_per_block = div_magic (per_block), m_nseg = div_magic (nseg);
+      const int nslow = cbase[kRRim + 1] - cbase[kRRim];
+      for (int item = tid; item < nslow * per_block; item += kRThreads) {
+        const int b = mdiv (item, per_block, m_per_block);
+        const int rem = item - b * per_block;
+        const int r2 = mdiv (rem, nseg, m_nseg), s2 = rem - r2 * nseg;
+        const RowBlk & hb = s_hot[cbase[kRRim] + b];
+        const int bx = hb.x + x_lo, by = hb.y + y_lo;
+        const int y = by + r2, xs = bx + 4 * s2;
+        if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
+          continue;
+        const int fx[2] = { hb.off[0], (int) hb.rxm[0] }, fy[2] = { hb.off[1], (int) hb.rxm[1] };
+        if (prec == 1)
+          row_slow < 1 > (job, bx, by, hb.mode_dc, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+        else
+          row_slow < 2 > (job, bx, by, hb.mode_dc, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+      }
+    }
+  }
+  RSTAMP (5);
+  const bool fast = row_finish_is_fast (job, x_lo, x_hi);
+  u32x4 res[kRTH * (kRTW / 8) / kRThreads];
+  if (fast)
+    row_finish_prefetch (job, tid, x_lo, y_lo, y_hi, res);
+  __syncthreads ();
+  RSTAMP (6);
+  row_finish (job, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+  RSTAMP (9);
+#undef RSTAMP
+}
+
+// Waves per SIMD by row length: the kernel is latency-bound between its barriers, so as many
+// workgroups per CU as the registers of the row in flight allow (measured, 8 x 2160p: 6-pixel
+// chroma rows 0.158 ms at 5 waves, 0.148 at 6; 12-pixel luma rows 0.236 at 5, 0.272 at 6 -- spills)
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
+void obmc_row_kernel_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  obmc_row_body < 2 > (jobs, njobs, order);
+}
+
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+void obmc_row_kernel_3 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  obmc_row_body < 3 > (jobs, njobs, order);
+}
+
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+void obmc_row_kernel_4 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  obmc_row_body < 4 > (jobs, njobs, order);
+}
+
+template < int ND >
+int
+launch_row_nd (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, const uint32_t * d_order)
+{
+  if constexpr (ND == 2)
+    hipLaunchKernelGGL (obmc_row_kernel_2, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
+  else if constexpr (ND == 3)
+    hipLaunchKernelGGL (obmc_row_kernel_3, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
+  else
+    hipLaunchKernelGGL (obmc_row_kernel_4, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "obmc (row) launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+}                               // namespace
+
+// Prediction dwords per block row the row kernel runs this plane with; 0: not its case (plain or
+// eighth-pel references, blocks wider than 16, unaligned half-pel images) -> obmc.hip
+int
+obmc_row_nd (const ObmcJob & j)
+{
+  if (j.prec < 1 || j.prec > 2 || j.xblen > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
+    return 0;
+  if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1]) | (uintptr_t) j.ref_stride[0] | (uintptr_t) j.ref_stride[1]) & 15)
+    return 0;
+  if (j.yblen * (j.xblen >> 1) > kRWCap)
+    return 0;
+  const int need = (j.xblen + 3) / 4;
+  return need <= 2 ? 2 : need;  // 2, 3 or 4
+}
+
+int
+launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, const uint32_t * d_order)
+{
+  switch (nd) {
+    case 2: return launch_row_nd < 2 > (stream, d_jobs, njobs, total_tiles, d_order);
+    case 3: return launch_row_nd < 3 > (stream, d_jobs, njobs, total_tiles, d_order);
+    case 4: return launch_row_nd < 4 > (stream, d_jobs, njobs, total_tiles, d_order);
+  }
+  return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row unsupported", nd);
+}
+
+}                               // namespace schro

@@ -96,6 +96,7 @@ struct ObmcJob {
   // ceil (2^32 / d) for mdiv ()
   int nseg, nch, lpi, item_bytes, ipw, chunk_cap;
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
+  uint32_t m_xramp, m_yramp;    // ceil (2^32 / (2 * offset - 1)): get_ramp's division (schromotion.c:40-49)
   unsigned long long *stamps;   // scratch runs only (SCHRO_HIP_OBMC_STAMPS): per-workgroup phase stamps
 };
 
@@ -285,6 +286,10 @@ int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
 // staged kernel (obmc_stage.hip): prediction dwords per block row, 0 = geometry not supported
 int obmc_stage_nd (const ObmcJob & job);
 int launch_obmc_stage (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
+    const uint32_t * d_order);
+// row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
+int obmc_row_nd (const ObmcJob & job);
+int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
     const uint32_t * d_order);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
