@@ -411,7 +411,8 @@ def main():
         pictures = args.frames * world * args.steps
         value = pictures * W * H / dt / 1e6
         # dominant kernel = the class with the largest summed event time
-        dom = max(prof, key=lambda k: prof[k][0])
+        dom = max((k for k in prof if k in ("iiwt_finest", "iiwt_coarse", "obmc", "upsample", "convert")),
+                  key=lambda k: prof[k][0])
         samples = args.frames * (W * H * 3 // 2)            # 4:2:0 samples per launch
         # references used per block, from the actual motion field (mode 1/2: one, mode 3: two)
         modes = np.concatenate([m["flags"] & 3 for m in wl.mv_np])
@@ -426,14 +427,23 @@ def main():
             "upsample": 2 * (W * H * 3 // 2) * 5,           # 1 B read + 4 B written, two refs
             "convert": 3 * samples,
         }
+        # launches of a class per step (the row-per-lane OBMC kernels run luma and chroma planes as
+        # two launches: different row lengths, different register budgets); alg_bytes are per STEP
+        # for "obmc" and per launch for the others, so every figure below is bytes of the launches
+        # of one step / their summed time
+        per_step = {k: (n / profiled_steps if profiled_steps else 1) for k, (ms, n) in prof.items()}
+        alg_step = dict(alg_bytes)
+        for k in ("iiwt_finest", "iiwt_coarse", "upsample", "convert"):
+            alg_step[k] = alg_bytes[k] * per_step.get(k, 1)
         kernels = {}
         for k, (ms, n) in prof.items():
-            if n:
-                avg = ms / n
-                kernels[k] = {"avg_ms": round(avg, 4), "launches": n,
-                              "alg_GBs": round(alg_bytes[k] / (avg * 1e-3) / 1e9, 1)}
+            if n and k in alg_step:
+                step_ms = ms / profiled_steps
+                kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n, "ms_per_step": round(step_ms, 4),
+                              "alg_GBs": round(alg_step[k] / (step_ms * 1e-3) / 1e9, 1)}
         d_avg = prof[dom][0] / max(prof[dom][1], 1)
-        achieved = alg_bytes[dom] / (d_avg * 1e-3) / 1e9
+        d_step = prof[dom][0] / profiled_steps
+        achieved = alg_step[dom] / (d_step * 1e-3) / 1e9
         # the whole 3-level transform (north_star's figure): 4 B per sample of the plane,
         # independent of depth, over the summed time of its launches in one step
         iiwt_ms = (prof["iiwt_finest"][0] + prof["iiwt_coarse"][0]) / profiled_steps
@@ -465,7 +475,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "avg_launch_ms": round(d_avg, 4)},
+                         "avg_launch_ms": round(d_avg, 4), "launches_per_step": round(per_step[dom], 2),
+                         "ms_per_step": round(d_step, 4),
+                         "note": "algorithmic bytes of one step's launches of this kernel class / their summed "
+                                 "HIP-event time (OBMC: a luma and a chroma launch per step)"},
             "kernels": kernels,
         }
         if world == 1:

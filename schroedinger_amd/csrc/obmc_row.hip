@@ -40,9 +40,13 @@ constexpr int kRMargin = 16;            // accumulator pixels in front of the ti
 constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
 constexpr int kRBlkCap = 192;           // decoded blocks per chunk (<= kRThreads)
 constexpr int kRItemCap = 1536;         // (block, row) items per chunk
-constexpr int kRWCap = 16 * 8;          // (row, pixel pair) weight words
+constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
 constexpr int kRCls = 7;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 rim
 constexpr int kRRim = kRCls - 1;
+#ifndef SCHRO_ROW_SERIAL
+#define SCHRO_ROW_SERIAL 0
+#endif
+constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
@@ -118,22 +122,6 @@ predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uin
   const uint32_t s = phase >> 4;        // x & 15 of the first sample
   const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
   const uint8_t *base = job.ref[r] + off_r;
-  uint32_t c[RY ? 2 : 1][4 * NCH + 2];
-#pragma unroll
-  for (int v = 0; v < (RY ? 2 : 1); v++) {
-    const uint32_t y = (phase & 7u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
-    const uint8_t *p = base + (__umul24 (y >> 3, tile_row_bytes) + ((y & 7u) << 4));
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-      if (j < NCH - 1 || last) {
-        const u32x4 q = gload < u32x4 > (p + 128 * j);
-        c[v][4 * j + 0] = q.x;
-        c[v][4 * j + 1] = q.y;
-        c[v][4 * j + 2] = q.z;
-        c[v][4 * j + 3] = q.w;
-      }
-    }
-  }
   // (masks and v_bfi, not ?: on array elements: the compiler turns such a select into a
   // run-time index and moves the array to scratch memory)
   const uint32_t m2 = (s & 8u) ? 0xffffffffu : 0u, m1 = (s & 4u) ? 0xffffffffu : 0u;
@@ -141,11 +129,24 @@ predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uin
   uint32_t h[RY ? 2 : 1][ND], x[RY ? 2 : 1][ND];
 #pragma unroll
   for (int v = 0; v < (RY ? 2 : 1); v++) {
+    uint32_t c[4 * NCH + 2];
+    const uint32_t y = (phase & 7u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
+    const uint8_t *p = base + (__umul24 (y >> 3, tile_row_bytes) + ((y & 7u) << 4));
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j < NCH - 1 || last) {
+        const u32x4 q = gload < u32x4 > (p + 128 * j);
+        c[4 * j + 0] = q.x;
+        c[4 * j + 1] = q.y;
+        c[4 * j + 2] = q.z;
+        c[4 * j + 3] = q.w;
+      }
+    }
     // the window's dwords u[0 .. NU): c[q .. q + NU), q = s >> 2 in 0..3, by a two-level select
     uint32_t t[NU + 1], u[NU];
 #pragma unroll
     for (int i = 0; i < NU + 1; i++)
-      t[i] = (c[v][i + 2] & m2) | (c[v][i] & ~m2);
+      t[i] = (c[i + 2] & m2) | (c[i] & ~m2);
 #pragma unroll
     for (int i = 0; i < NU; i++)
       u[i] = (t[i + 1] & m1) | (t[i] & ~m1);
@@ -159,6 +160,8 @@ predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uin
       h[v][k] = lerp1 (e, o2);
       x[v][k] = e ^ o2;
     }
+    if constexpr (kRowSerial)
+      __builtin_amdgcn_sched_barrier (0);       // a sample row at a time: fewer registers in flight, more waves
   }
 #pragma unroll
   for (int k = 0; k < ND; k++) {
@@ -213,18 +216,27 @@ row_pass (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, co
     return;
   int half;
   uint32_t *aw = acc_word (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
-  const uint32_t *w = s_wp + __umul24 (row, npair);
+  // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go
+  uint32_t w[2 * ND];
+  {
+    const u32x2 *wp = reinterpret_cast < const u32x2 * >(s_wp + 2 * ND * row);
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const u32x2 q = wp[k];
+      w[2 * k] = q.x;
+      w[2 * k + 1] = q.y;
+    }
+  }
+  (void) npair;
 #pragma unroll
   for (int k = 0; k < 2 * ND; k++) {
-    if (k < npair) {
-      const uint32_t px = __builtin_amdgcn_perm (0u, p[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
-      const uint32_t v = __builtin_bit_cast (uint32_t, (u16x2) (__builtin_bit_cast (u16x2, px) * __builtin_bit_cast (u16x2, w[k])));
-      if constexpr (EXACT) {
-        acc_add_exact (aw + k, 0, v & 0xffffu);
-        acc_add_exact (aw + k, 1, v >> 16);
-      } else {
-        atomicAdd (aw + k, v);  // sums of pred * weight <= 255 * 64: no carry between the halves
-      }
+    const uint32_t px = __builtin_amdgcn_perm (0u, p[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+    const uint32_t v = __builtin_bit_cast (uint32_t, (u16x2) (__builtin_bit_cast (u16x2, px) * __builtin_bit_cast (u16x2, w[k])));
+    if constexpr (EXACT) {
+      acc_add_exact (aw + k, 0, v & 0xffffu);
+      acc_add_exact (aw + k, 1, v >> 16);
+    } else {
+      atomicAdd (aw + k, v);    // sums of pred * weight <= 255 * 64: no carry between the halves
     }
   }
   if (st) {
@@ -405,7 +417,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
   __shared__ RowBlk s_hot[kRBlkCap];
   __shared__ uint16_t s_item[kRItemCap];
-  __shared__ uint32_t s_wp[kRWCap];
+  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap];
   __shared__ int s_cnt[kRCls], s_icnt[kRCls];   // blocks / items of each class
   __shared__ int s_wide;
 
@@ -444,7 +456,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
   const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;     // last valid half-pel sample column / row
   const int chunk_cap = min (kRBlkCap, kRItemCap / min (yblen, kRTH));
-  const uint32_t m_npair = div_magic (npair);
   // the first chunk's motion vectors start their way from memory now, beside the set-up below
   uint32_t mv_pre[3] = { 0u, 0u, 0u };
   if (tid < min (chunk_cap, nblk)) {
@@ -455,10 +466,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     mv_pre[2] = gload < uint32_t > (mvp + 16);
   }
   __syncthreads ();             // ramps visible
-  // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each)
-  for (int i = tid; i < yblen * npair && i < kRWCap; i += kRThreads) {
-    const int r = mdiv (i, npair, m_npair), pr = i - r * npair;
-    s_wp[i] = (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16);
+  // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
+  // 2 * ND words, zero beyond the block's width
+  for (int i = tid; i < yblen * 2 * ND && i < kRWCap; i += kRThreads) {
+    const int r = i / (2 * ND), pr = i - r * (2 * ND);
+    s_wp[i] = pr < npair ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
   }
 
   RSTAMP (1);
@@ -530,7 +542,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       const bool wide_dc = mode == 0 && (unsigned) pdc > 255u;
       if (wide_dc)
         s_wide = 1;
-      if (clamped || fold || wide_dc || yblen * npair > kRWCap) {
+      if (clamped || fold || wide_dc || yblen * 2 * ND > kRWCap) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
         int fx, fy;
@@ -682,8 +694,6 @@ obmc_row_nd (const ObmcJob & j)
   if (j.prec < 1 || j.prec > 2 || j.xblen > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
     return 0;
   if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1]) | (uintptr_t) j.ref_stride[0] | (uintptr_t) j.ref_stride[1]) & 15)
-    return 0;
-  if (j.yblen * (j.xblen >> 1) > kRWCap)
     return 0;
   const int need = (j.xblen + 3) / 4;
   return need <= 2 ? 2 : need;  // 2, 3 or 4
