@@ -688,6 +688,39 @@ int schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src);
 /* schro_frame_shift_right (schroframe.c:1265-1293) on a device s16 / s32 frame */
 int schro_hipframe_shift_right (SchroHipFrame * frame, int shift);
 
+/* ---- several devices behind one decode loop -----------------------------
+ *
+ * One exec-domain thread per device, each with its own context -- the reference's
+ * schro_async_add_exec_domain thread (schroasync-pthread.c:362-390), N times -- and the
+ * device-affinity rule the reference's scheduler lacks (schro_decoder_async_schedule,
+ * schrodecoder.c:1546-1682; schro_picture_new :332-400): a picture runs on the device that
+ * holds its first reference, so a reference chain (closed GOP) never leaves its device; a
+ * picture without references starts a chain on the least loaded device.  A device runs its
+ * pictures in submission (= coded) order, which puts references before their dependents.
+ * `func` is the picture's pixel path -- the stage calls of this header on `ctx` -- and runs on
+ * that device's thread; no collective, no peer traffic unless a picture predicts across two
+ * chains (then *foreign_ref names the reference that lives elsewhere, the picture waits for
+ * it, and moving that frame is the caller's: one u8 picture over xGMI). */
+typedef struct SchroHipScheduler SchroHipScheduler;
+typedef int (*SchroHipPictureFunc) (SchroHipContext * ctx, int device_index, void *priv);
+
+/* n_devices 0: every visible device.  _virtual: threads and affinity without devices (ctx is
+ * NULL in the callbacks): the host logic under test on a machine without GPUs. */
+SchroHipScheduler *schro_hip_scheduler_new (int n_devices);
+SchroHipScheduler *schro_hip_scheduler_new_virtual (int n_devices);
+/* waits for everything submitted, stops the threads, frees the contexts */
+void schro_hip_scheduler_free (SchroHipScheduler * sched);
+int schro_hip_scheduler_n_devices (SchroHipScheduler * sched);
+SchroHipContext *schro_hip_scheduler_context (SchroHipScheduler * sched, int device_index);
+/* returns the device index the picture was given (< 0: error).  refs: the picture numbers it
+ * predicts from (0 .. 2), each submitted earlier with is_ref != 0. */
+int schro_hip_scheduler_submit (SchroHipScheduler * sched, int picture_number, const int *refs, int n_refs,
+    int is_ref, SchroHipPictureFunc func, void *priv, int *foreign_ref);
+/* a reference picture leaves the reference queue (schro_decoder_reference_retire) */
+int schro_hip_scheduler_retire (SchroHipScheduler * sched, int picture_number);
+/* waits until every submitted picture has run; returns the first non-zero result of a func */
+int schro_hip_scheduler_wait (SchroHipScheduler * sched);
+
 #ifdef __cplusplus
 }
 #endif

@@ -360,3 +360,57 @@ def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
     p.out, p.out_stride = out.ptr, out.stride
     p.width, p.height = out.width, out.height
     return p
+
+
+class Scheduler:
+    """schro_hip_scheduler_*: one exec-domain thread and context per device; pictures follow
+    their references (include/schro_hip.h).  func(ctx, device_index) is the picture's pixel
+    path; ctx is a Context of that device (None on virtual devices)."""
+
+    def __init__(self, n_devices=0, virtual=False):
+        self.lib = _lib.load()
+        self.h = (self.lib.schro_hip_scheduler_new_virtual if virtual else self.lib.schro_hip_scheduler_new)(n_devices)
+        if not self.h:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        self.n_devices = self.lib.schro_hip_scheduler_n_devices(self.h)
+        self.contexts = []
+        for k in range(self.n_devices):
+            hctx = self.lib.schro_hip_scheduler_context(self.h, k)
+            c = None
+            if hctx:
+                c = Context.__new__(Context)
+                c.lib, c.h, c.device = self.lib, hctx, k
+            self.contexts.append(c)
+        self._keep = []
+
+    def submit(self, number, refs, is_ref, func):
+        """Returns (device index, foreign reference or -1)."""
+        def thunk(hctx, index, priv):
+            try:
+                return int(func(self.contexts[index], index) or 0)
+            except Exception:       # an exception must not unwind into the C thread
+                import traceback
+                traceback.print_exc()
+                return -99
+        cb = _lib.PICTURE_FUNC(thunk)
+        self._keep.append(cb)
+        arr = (C.c_int * max(len(refs), 1))(*refs)
+        foreign = C.c_int(-1)
+        dev = self.lib.schro_hip_scheduler_submit(self.h, number, arr, len(refs), 1 if is_ref else 0, cb, None,
+                                                  C.byref(foreign))
+        if dev < 0:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        return dev, foreign.value
+
+    def retire(self, number):
+        check(self.lib.schro_hip_scheduler_retire(self.h, number))
+
+    def wait(self):
+        r = self.lib.schro_hip_scheduler_wait(self.h)
+        self._keep = []
+        return r
+
+    def close(self):
+        if self.h:
+            self.lib.schro_hip_scheduler_free(self.h)
+            self.h = None

@@ -18,6 +18,9 @@ EXPORTED_SYMBOLS = [
     "schro_hip_synchronize", "schro_hip_stream",
     "schro_memory_domain_new_hip", "schro_memory_domain_free_hip", "schro_hip_domain_context",
     "schro_hip_context_domain",
+    "schro_hip_scheduler_new", "schro_hip_scheduler_new_virtual", "schro_hip_scheduler_free",
+    "schro_hip_scheduler_n_devices", "schro_hip_scheduler_context", "schro_hip_scheduler_submit",
+    "schro_hip_scheduler_retire", "schro_hip_scheduler_wait",
     "schro_hip_context_select_queue", "schro_hip_context_queue", "schro_hip_queue_wait",
     "schro_hip_queue_mark", "schro_hip_queue_wait_mark",
     "schro_hip_timer_begin", "schro_hip_timer_end",
@@ -163,6 +166,9 @@ class Motion(C.Structure):
                                           "oneref_noscale")])
 
 
+# int (*SchroHipPictureFunc) (SchroHipContext *ctx, int device_index, void *priv)
+PICTURE_FUNC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
 _lib = None
 
 
@@ -209,6 +215,22 @@ def load():
     L.schro_hip_domain_context.restype = vp
     L.schro_hip_context_domain.argtypes = [vp]
     L.schro_hip_context_domain.restype = vp
+    L.schro_hip_scheduler_new.argtypes = [i]
+    L.schro_hip_scheduler_new.restype = vp
+    L.schro_hip_scheduler_new_virtual.argtypes = [i]
+    L.schro_hip_scheduler_new_virtual.restype = vp
+    L.schro_hip_scheduler_free.argtypes = [vp]
+    L.schro_hip_scheduler_free.restype = None
+    L.schro_hip_scheduler_n_devices.argtypes = [vp]
+    L.schro_hip_scheduler_n_devices.restype = i
+    L.schro_hip_scheduler_context.argtypes = [vp, i]
+    L.schro_hip_scheduler_context.restype = vp
+    L.schro_hip_scheduler_submit.argtypes = [vp, i, C.POINTER(C.c_int), i, i, PICTURE_FUNC, vp, C.POINTER(C.c_int)]
+    L.schro_hip_scheduler_submit.restype = i
+    L.schro_hip_scheduler_retire.argtypes = [vp, i]
+    L.schro_hip_scheduler_retire.restype = i
+    L.schro_hip_scheduler_wait.argtypes = [vp]
+    L.schro_hip_scheduler_wait.restype = i
     L.schro_hip_context_select_queue.argtypes = [vp, i]
     L.schro_hip_context_select_queue.restype = i
     L.schro_hip_context_queue.argtypes = [vp]
