@@ -343,6 +343,9 @@ def main():
     ap.add_argument("--queues", type=int, default=2, choices=(1, 2),
                     help="picture batches in flight per GPU (2: OBMC of one beside the wavelet of the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed workload: no CPU baseline, no 1080p / PCIe-inclusive extras "
+                         "(profiler runs: every launch in the trace is a launch of the headline step)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
     ap.add_argument("--profile-every", type=int, default=10,
                     help="bracket the launches of every n-th timed step with HIP events; such a step "
@@ -481,7 +484,7 @@ def main():
                                  "HIP-event time (OBMC: a luma and a chroma launch per step)"},
             "kernels": kernels,
         }
-        if world == 1:
+        if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
             out["iiwt_1080p"] = iiwt_1080p(ctx)
             out["pcie_inclusive"] = pcie_inclusive(wl)
@@ -494,7 +497,7 @@ def main():
                 ts.append(ctx.timer_end())
             out["one_batch_in_flight"] = {"median_ms_per_step": round(float(np.median(ts)), 4),
                                           "Mpix_per_s": round(args.frames * W * H / float(np.median(ts)) / 1e3, 1)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share
             v, ok, single = cpu_baseline(wl, cores)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpix/s", "cores": cores,
@@ -504,7 +507,7 @@ def main():
                                    "time) of the same workload + the two reference upsamples, oracle/ C "
                                    "port, gcc -O3" % (10 * cores, cores)}
             out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
-        if world == 1:
+        if world == 1 and not args.headline_only:
             out["pcie_inclusive_quantised"] = pcie_inclusive_quantised(wl)
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):

@@ -5,4 +5,4 @@ set -e
 name=$1; shift
 repo=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $1 --output-format csv -d $repo/gpurun_out/pmc_$name -o run -- python3 $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $repo/gpurun_out/pmc_$name.log 2>&1
+rocprofv3 --pmc $1 --output-format csv -d $repo/gpurun_out/pmc_$name -o run -- python3 $repo/bench.py --steps 4 --warmup 2 --queues 1 --headline-only > $repo/gpurun_out/pmc_$name.log 2>&1
