@@ -1237,6 +1237,14 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
 // is never drained here.
 // scratch runs only: SCHRO_HIP_OBMC_STAMPS=1 gives the staged kernel a buffer for per-phase
 // cycle stamps; schro_hip_obmc_stamps_dump () prints their medians
+// SCHRO_HIP_OBMC_MERGE=0: every plane its own job in the row kernel (A/B runs)
+static bool
+obmc_row_merge_enabled ()
+{
+  static const bool on = !getenv ("SCHRO_HIP_OBMC_MERGE") || atoi (getenv ("SCHRO_HIP_OBMC_MERGE")) != 0;
+  return on;
+}
+
 static unsigned long long *g_stamps;
 static unsigned long long *
 obmc_stamp_buffer ()
@@ -1452,6 +1460,20 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     key[p] = pl.mv_precision | (variant << 4) | ((nd_staged ? nd_staged : nd_row) << 8) | (nd_row ? 1 << 16 : 0);
     row_nd[p] = nd_row;
   }
+  // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
+  // ONE job whose tile workgroups decode the blocks once; such pairs form their own launch
+  for (int p = 0; p + 1 < nplanes; p++) {
+    const ObmcJob & a = all[p], &b = all[p + 1];
+    if (row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && obmc_row_merge_enabled () && a.comp == 1 && b.comp == 2
+        && a.mvs == b.mvs && a.w == b.w && a.h == b.h && a.nbx == b.nbx && a.nby == b.nby && a.xblen == b.xblen
+        && a.yblen == b.yblen && a.xbsep == b.xbsep && a.ybsep == b.ybsep && a.mv_shift_x == b.mv_shift_x
+        && a.mv_shift_y == b.mv_shift_y && a.res_bpp == b.res_bpp && a.ref_stride[0] == b.ref_stride[0]
+        && a.ref_stride[1] == b.ref_stride[1]) {
+      key[p] |= 1 << 17;
+      key[p + 1] |= 1 << 17;
+      p++;
+    }
+  }
   // one launch per (precision class, kernel) group, keeping plane order
   std::vector < char >done (nplanes, 0);
   for (int first = 0; first < nplanes; first++) {
@@ -1465,6 +1487,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         if (!done[p] && key[p] == key[first])
           nd = std::max (nd, row_nd[p]);
     const int variant = nd ? (row ? 3 : 2) : ((key[first] >> 4) & 15);
+    const bool paired = (key[first] >> 17) & 1;
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
     for (int p = first; p < nplanes; p++) {
@@ -1475,9 +1498,23 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       int tiles_y;
       obmc_tiles (variant, j.w, j.h, j.xoff, &j.tiles_x, &tiles_y);
       j.tile_base = tile_base;
-      tile_base += j.tiles_x * tiles_y;
       obmc_item_geometry (&j);
       j.stamps = obmc_stamp_buffer ();
+      j.nplanes = 1;
+      if (paired && j.comp == 2) {
+        // the V plane joins the U plane in front of it (checked above)
+        ObmcJob & a = jobs.back ();
+        a.nplanes = 2;
+        a.comp_b = j.comp;
+        a.ref_b[0] = j.ref[0];
+        a.ref_b[1] = j.ref[1];
+        a.residual_b = j.residual;
+        a.out_b = j.out;
+        a.residual_stride_b = j.residual_stride;
+        a.out_stride_b = j.out_stride;
+        continue;
+      }
+      tile_base += j.tiles_x * tiles_y;
       jobs.push_back (j);
     }
     void *d_jobs;
@@ -1490,7 +1527,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       return r;
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
+      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, paired ? 2 : 1, d_order)
           : nd ? launch_obmc_stage (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
           : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
     }

@@ -38,8 +38,8 @@ constexpr int kRThreads = 256;
 constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1)
 constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
 constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
-constexpr int kRBlkCap = 192;           // decoded blocks per chunk (<= kRThreads)
-constexpr int kRItemCap = 1536;         // (block, row) items per chunk
+constexpr int kRBlkCap = 384;           // blocks whose footprint meets a tile
+constexpr int kRItemCap = 2048;         // their (block, row) items
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
 constexpr int kRCls = 7;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 rim
 constexpr int kRRim = kRCls - 1;
@@ -52,8 +52,9 @@ typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
 
 struct __attribute__ ((aligned (16))) RowBlk {
-  int y, x;                     // block origin relative to the tile
-  int mode_dc;                  // bits 0-1 mode, bits 8..: DC value; rim blocks: as obmc.hip
+  int16_t y, x;                 // block origin relative to the tile
+  int dc_b;                     // DC value of the job's second plane
+  int mode_dc;                  // bits 0-1 mode, bits 8..: DC value (first plane)
   int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
   int off[2];                   // offset of the window's first 16-byte chunk in its tile row (rim: fx, fy of ref 0)
   uint32_t rxm[2];              // bits 1..: all ones when the window sits at a horizontal half position,
@@ -62,6 +63,16 @@ struct __attribute__ ((aligned (16))) RowBlk {
 
 // obmc_weight_1d (obmc_common.h; schromotion.c:40-69) with get_ramp's division by
 // 2 * offset - 1 done as a multiplication (m = ceil (2^32 / (2 * offset - 1)), from the host)
+// what differs between the planes of a job; kept in LDS (one copy per workgroup) so that the
+// pointers of the plane not being worked on cost no scalar registers -- with both planes'
+// pointers live beside the block geometry the kernel spilled 119 SGPRs
+struct __attribute__ ((aligned (8))) PlaneIO {
+  const uint8_t *ref[2];
+  const void *residual;
+  uint8_t *out;
+  int residual_stride, out_stride;
+};
+
 __device__ __forceinline__ int
 weight_1d (int i, int blen, int offset, uint32_t m)
 {
@@ -114,14 +125,15 @@ acc_word (uint32_t * acc, int par, int x, int y, int *half)
 // ONE class whatever their vertical phases)
 template < int ND, bool RY >
 __device__ __forceinline__ void
-predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uint32_t rxm, uint32_t ry1, uint32_t * out)
+predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r, uint32_t phase, int row, uint32_t rxm,
+    uint32_t ry1, uint32_t * out)
 {
   constexpr int NCH = ND <= 2 ? 2 : 3;  // 16-byte tile rows that can hold the 2 * xblen + 15 bytes from the chunk's start
   constexpr int NU = 2 * ND + 1;        // dwords from the window's first dword on
-  const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
+  const uint32_t tile_row_bytes = 8u * (uint32_t) ref_stride;
   const uint32_t s = phase >> 4;        // x & 15 of the first sample
   const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
-  const uint8_t *base = job.ref[r] + off_r;
+  const uint8_t *base = ref + off_r;
   // (masks and v_bfi, not ?: on array elements: the compiler turns such a select into a
   // run-time index and moves the array to scratch memory)
   const uint32_t m2 = (s & 8u) ? 0xffffffffu : 0u, m1 = (s & 4u) ? 0xffffffffu : 0u;
@@ -179,26 +191,27 @@ predict_row (const ObmcJob & job, int r, int off_r, uint32_t phase, int row, uin
 // CLS 0-3 both references, 4-5 the first, 6-7 the second, 8 DC
 template < int ND, int CLS, bool EXACT >
 __device__ __forceinline__ void
-row_pass (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, const uint32_t * s_wp,
-    uint32_t * acc, int par, int npair, int it, int hi)
+row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
+    const uint32_t * s_wp, uint32_t * acc, int par, int npair, int it, int hi)
 {
+  const uint8_t *const ref0 = io.ref[0], *const ref1 = io.ref[1];
   const bool st = CLS == 0 && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
   const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
   const int e = s_item[min (it, hi - 1)];
-  const RowBlk & hb = s_hot[e & 0xff];
-  const int row = e >> 8;
+  const RowBlk & hb = s_hot[e & 0x1ff];
+  const int row = e >> 9;
   uint32_t p[ND];
   auto rx_mask = [] (uint32_t f) { return (uint32_t) ((int32_t) f >> 1); };       // bits 1.. smeared over the word
   if constexpr (CLS == 5) {
 #pragma unroll
     for (int k = 0; k < ND; k++)
-      p[k] = (uint32_t) (hb.mode_dc >> 8) * 0x01010101u;
+      p[k] = (uint32_t) (pl ? hb.dc_b : hb.mode_dc >> 8) * 0x01010101u;
   } else if constexpr (CLS == 0) {
     uint32_t p1[ND];
     const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-    predict_row < ND, true > (job, 0, hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
+    predict_row < ND, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight
-    predict_row < ND, true > (job, 1, hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
+    predict_row < ND, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
@@ -206,7 +219,7 @@ row_pass (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, co
     constexpr int r = CLS >= 3 ? 1 : 0;
     constexpr bool RY = CLS == 2 || CLS == 4;
     const uint32_t ph = ((uint32_t) hb.rows >> (16 + 8 * r)) & 0xffu;
-    predict_row < ND, RY > (job, r, hb.off[r], ph, row, rx_mask (hb.rxm[r]), 1u, p);
+    predict_row < ND, RY > (job, r ? ref1 : ref0, job.ref_stride[r], hb.off[r], ph, row, rx_mask (hb.rxm[r]), 1u, p);
   }
   if (st) {
     asm volatile ("" :: "v" (p[0]));
@@ -251,8 +264,8 @@ row_pass (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, co
 // wave 3 with none)
 template < int ND, int CLS >
 __device__ __forceinline__ void
-row_class (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, const uint32_t * s_wp,
-    uint32_t * acc, int par, int npair, int lo, int hi, bool exact, int *turn)
+row_class (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
+    const uint32_t * s_wp, uint32_t * acc, int par, int npair, int lo, int hi, bool exact, int *turn)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int npass = (hi - lo + 63) >> 6;
@@ -261,19 +274,20 @@ row_class (const ObmcJob & job, const uint16_t * s_item, const RowBlk * s_hot, c
   *turn = (*turn + npass) & (kWaves - 1);
   if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, true > (job, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+      row_pass < ND, CLS, true > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
   } else {
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, false > (job, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+      row_pass < ND, CLS, false > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
   }
 }
 
 // picture-rim block rows: per-sample clamp and weight folding (accumulate_slow), 4 pixels
 template < int PC >
 __device__ __forceinline__ void
-row_slow (const ObmcJob & job, int bx, int by, int md, const int *fx, const int *fy, int row, int seg, int x_lo,
-    int y_lo, int xfold_hi, int yfold_hi, const int *s_wx, const int *s_wy, uint32_t * acc, int par, bool exact)
+row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const int *fx, const int *fy, int row, int seg,
+    int x_lo, int y_lo, int xfold_hi, int yfold_hi, const int *s_wx, const int *s_wy, uint32_t * acc, int par, bool exact)
 {
+  const uint8_t *const refs[2] = { io.ref[0], io.ref[1] };
   const int prec = job.prec;
   const int y = by + row, xs = bx + 4 * seg;
   const int mode = md & 3;
@@ -287,7 +301,7 @@ row_slow (const ObmcJob & job, int bx, int by, int md, const int *fx, const int 
       if (mode & (r + 1)) {
 #pragma unroll
         for (int e = 0; e < 4; e++)
-          val[r][e] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h,
+          val[r][e] = fetch_ref < PC > (refs[r], job.ref_stride[r], job.w, job.h,
               fx[r] + (4 * seg + e) * (1 << prec), fy[r] + row * (1 << prec), prec);
       }
     }
@@ -322,28 +336,28 @@ row_slow (const ObmcJob & job, int bx, int by, int md, const int *fx, const int 
 
 // out = sat_u8 (residual + ((acc + 32) >> 6)) for one tile
 __device__ __forceinline__ bool
-row_finish_is_fast (const ObmcJob & job, int x_lo, int x_hi)
+row_finish_is_fast (const ObmcJob & job, const PlaneIO & io, int x_lo, int x_hi)
 {
   return job.res_bpp == 2 && x_hi - x_lo == kRTW
-      && ((((uintptr_t) job.residual) | (uintptr_t) job.residual_stride) & 15) == 0
-      && ((((uintptr_t) job.out) | (uintptr_t) job.out_stride) & 7) == 0;
+      && ((((uintptr_t) io.residual) | (uintptr_t) io.residual_stride) & 15) == 0
+      && ((((uintptr_t) io.out) | (uintptr_t) io.out_stride) & 7) == 0;
 }
 
 // the fast finish's residual: 8 pixels of two rows per lane, fetched before the tile's last barrier
 __device__ __forceinline__ void
-row_finish_prefetch (const ObmcJob & job, int tid, int x_lo, int y_lo, int y_hi, u32x4 * res)
+row_finish_prefetch (const PlaneIO & io, int tid, int x_lo, int y_lo, int y_hi, u32x4 * res)
 {
 #pragma unroll
   for (int n = 0; n < kRTH * (kRTW / 8) / kRThreads; n++) {
     const int it = tid + n * kRThreads, g = it & (kRTW / 8 - 1), y = y_lo + (it >> 4);
     if (y < y_hi)
-      res[n] = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * (x_lo + 8 * g));
+      res[n] = gload < u32x4 > ((const char *) io.residual + (size_t) y * io.residual_stride + 2 * (x_lo + 8 * g));
   }
 }
 
 __device__ __forceinline__ void
-row_finish (const ObmcJob & job, const uint32_t * acc, int par, int tid, int x_lo, int y_lo, int x_hi, int y_hi,
-    bool fast, const u32x4 * res)
+row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, int tid, int x_lo, int y_lo,
+    int x_hi, int y_hi, bool fast, const u32x4 * res)
 {
   if (fast) {
     // one lane: 8 pixels of one row, packed 16-bit arithmetic (the reference's adds wrap at 16 bits)
@@ -385,7 +399,7 @@ row_finish (const ObmcJob & job, const uint32_t * acc, int par, int tid, int x_l
       u32x2 o;
       o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
       o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
-      gstore < u32x2 > (job.out + (size_t) y * job.out_stride + x, o);
+      gstore < u32x2 > (io.out + (size_t) y * io.out_stride + x, o);
     }
     return;
   }
@@ -397,29 +411,31 @@ row_finish (const ObmcJob & job, const uint32_t * acc, int par, int tid, int x_l
     if (y >= y_hi || x >= x_hi)
       continue;
     int half;
-    const uint32_t *aw = acc_word (const_cast < uint32_t * >(acc), par, xx, yy, &half);
+    const uint32_t *aw = acc_word (acc, par, xx, yy, &half);
     const int16_t a = (int16_t) (*aw >> (16 * half));
-    const char *rrow = (const char *) job.residual + (size_t) y * job.residual_stride;
+    const char *rrow = (const char *) io.residual + (size_t) y * io.residual_stride;
     const int16_t res = job.res_bpp == 2 ? gload < int16_t > ((const int16_t *) rrow + x)
         : (int16_t) gload < int32_t > ((const int32_t *) rrow + x);   // convlw
     int16_t t1 = (int16_t) (a + 32);
     t1 = (int16_t) (t1 >> 6);
     t1 = (int16_t) (res + t1);
-    gstore < uint8_t > (job.out + (size_t) y * job.out_stride + x, (uint8_t) clampi (t1, 0, 255));
+    gstore < uint8_t > (io.out + (size_t) y * io.out_stride + x, (uint8_t) clampi (t1, 0, 255));
   }
 }
 
-template < int ND >
+template < int ND, int NP >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[kRTH * kRAccW];
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
-  __shared__ RowBlk s_hot[kRBlkCap];
+  __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
+  __shared__ uint16_t s_meta[kRBlkCap];         // class | first item within the class << 4
+  __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
   __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap];
-  __shared__ int s_cnt[kRCls], s_icnt[kRCls];   // blocks / items of each class
-  __shared__ int s_wide;
+  __shared__ int s_icnt[kRCls];                 // items of each class
+  __shared__ int s_nrim, s_wide;
 
   const uint64_t t_start = __builtin_amdgcn_s_memtime ();
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
@@ -433,6 +449,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int tid = threadIdx.x;
   const int x_lo = tx * kRTW, y_lo = ty * kRTH;
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + kRTH, job.h);
+  constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
   static_assert ((kRTH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
   for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
@@ -441,74 +458,70 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
   if (tid >= 64 && tid - 64 < job.yblen)
     s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
+  if (tid >= 128 && tid < 128 + kRCls)
+    s_icnt[tid - 128] = 0;
+  if (tid == 192) {
+    s_nrim = 0;
+    s_wide = 0;
+  }
 
-  const int xblen = job.xblen, yblen = job.yblen, xbsep = job.xbsep, ybsep = job.ybsep;
-  const int xoff = job.xoff, yoff = job.yoff, prec = job.prec;
-  const int par = xoff & 1;             // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
+  const int xblen = job.xblen, yblen = job.yblen;
+  const int par = job.xoff & 1;         // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
   const int npair = xblen >> 1;
-  const int i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
-  const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
-  const int j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
-  const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
-  const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
-  const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
-  const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
-  const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
-  const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;     // last valid half-pel sample column / row
-  const int chunk_cap = min (kRBlkCap, kRItemCap / min (yblen, kRTH));
-  // the first chunk's motion vectors start their way from memory now, beside the set-up below
-  uint32_t mv_pre[3] = { 0u, 0u, 0u };
-  if (tid < min (chunk_cap, nblk)) {
-    const int bj = nbi == 1 ? tid : (int) (((uint32_t) tid * m16_nbi) >> 16);
-    const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) (j_lo + bj) * job.nbx + (i_lo + (tid - bj * nbi)));
-    mv_pre[0] = gload < uint32_t > (mvp);
-    mv_pre[1] = gload < uint32_t > (mvp + 12);
-    mv_pre[2] = gload < uint32_t > (mvp + 16);
-  }
-  __syncthreads ();             // ramps visible
-  // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
-  // 2 * ND words, zero beyond the block's width
-  for (int i = tid; i < yblen * 2 * ND && i < kRWCap; i += kRThreads) {
-    const int r = i / (2 * ND), pr = i - r * (2 * ND);
-    s_wp[i] = pr < npair ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
-  }
-
-  RSTAMP (1);
-  bool exact = false;
-  for (int chunk0 = 0; chunk0 < nblk; chunk0 += chunk_cap) {
-    const int nb = min (chunk_cap, nblk - chunk0);
-    if (tid < kRCls) {
-      s_cnt[tid] = 0;
-      s_icnt[tid] = 0;
+  const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
+  int nblk;
+  {
+    // ---- decode: every block whose footprint meets the tile, one per thread and round -----
+    const int xbsep = job.xbsep, ybsep = job.ybsep, xoff = job.xoff, yoff = job.yoff, prec = job.prec;
+    const int i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
+    const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
+    const int j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
+    const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
+    const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
+    nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
+    const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+    const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;   // last valid half-pel sample column / row
+    // the motion vectors of the first round start their way from memory beside the set-up
+    uint32_t mv_pre[3] = { 0u, 0u, 0u };
+    if (tid < nblk) {
+      const int bj = nbi == 1 ? tid : (int) (((uint32_t) tid * m16_nbi) >> 16);
+      const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) (j_lo + bj) * job.nbx + (i_lo + (tid - bj * nbi)));
+      mv_pre[0] = gload < uint32_t > (mvp);
+      mv_pre[1] = gload < uint32_t > (mvp + 12);
+      mv_pre[2] = gload < uint32_t > (mvp + 16);
     }
-    if (tid == 32)
-      s_wide = 0;
-    __syncthreads ();           // accumulator / weights ready; the previous chunk's tables consumed
-    // ---- decode one block per thread ----------------------------------------------------
-    RowBlk info;
-    int key = 0, rank = 0, istart = 0, my_rows = 0, my_ra = 0;
-    const bool have = tid < nb;
-    if (have) {
-      const int blk = chunk0 + tid;
+    __syncthreads ();           // ramps, counters
+    // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
+    // 2 * ND words, zero beyond the block's width
+    for (int i = tid; i < yblen * 2 * ND && i < kRWCap; i += kRThreads) {
+      const int r = i / (2 * ND), pr = i - r * (2 * ND);
+      s_wp[i] = pr < npair ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
+    }
+    RSTAMP (1);
+    for (int blk = tid; blk < nblk; blk += kRThreads) {
       const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       uint32_t flags = mv_pre[0], v01 = mv_pre[1], v23 = mv_pre[2];
-      if (chunk0 > 0) {
+      if (blk >= kRThreads) {
         const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
         flags = gload < uint32_t > (mvp);
         v01 = gload < uint32_t > (mvp + 12);
         v23 = gload < uint32_t > (mvp + 16);
       }
       const int bx = xbsep * i - xoff, by = ybsep * jj - yoff;
-      info.x = bx - x_lo;
-      info.y = by - y_lo;
+      RowBlk info;
+      info.x = (int16_t) (bx - x_lo);
+      info.y = (int16_t) (by - y_lo);
       const int mode = flags & 3;
       const bool interior = i >= 1 && i < job.max_x_blocks && jj >= 1 && jj < job.max_y_blocks;
-      const int dc = job.comp == 0 ? (int16_t) (v01 & 0xffff)
-          : job.comp == 1 ? (int16_t) (v01 >> 16) : (int16_t) (v23 & 0xffff);
-      // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
-      const int pdc = interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
-      int md = mode | (pdc << 8);
+      auto dc_of = [&] (int comp) {
+        const int dc = comp == 0 ? (int16_t) (v01 & 0xffff) : comp == 1 ? (int16_t) (v01 >> 16) : (int16_t) (v23 & 0xffff);
+        // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
+        return interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
+      };
+      const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
+      info.dc_b = pdc_b;
+      info.mode_dc = mode | (pdc << 8);
       int phases = 0, ry[2] = { 0, 0 };
       bool clamped = false;
 #pragma unroll
@@ -535,13 +548,13 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         phases |= inside ? ((gy0 & 7) | ((gx0 & 15) << 4)) << (8 * r) : 0;
         info.rxm[r] = (rx ? 0xfffffffeu : 0u) | (ry[r] ? 1u : 0u);
       }
-      info.mode_dc = md;
-      const int ra = max (0, -info.y), rb = min (yblen, y_hi - by);
+      const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
       info.rows = ra | ((rb - ra) << 8) | (phases << 16);
       const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + xblen > xfold_hi;
-      const bool wide_dc = mode == 0 && (unsigned) pdc > 255u;
+      const bool wide_dc = mode == 0 && ((unsigned) pdc > 255u || (unsigned) pdc_b > 255u);
       if (wide_dc)
         s_wide = 1;
+      int key;
       if (clamped || fold || wide_dc || yblen * 2 * ND > kRWCap) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
@@ -552,6 +565,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         mv_origin (job, bx, by, v01, v23, 1, &fx, &fy);
         info.rxm[0] = (uint32_t) fx;
         info.rxm[1] = (uint32_t) fy;
+        s_rim[atomicAdd (&s_nrim, 1)] = (uint16_t) blk;
       } else if (mode == 3) {
         key = 0;
       } else if (mode == 0) {
@@ -559,50 +573,49 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       } else {
         key = mode == 1 ? 1 + (ry[0] ? 1 : 0) : 3 + (ry[1] ? 1 : 0);
       }
-      rank = atomicAdd (&s_cnt[key], 1);
+      s_hot[blk] = info;
       // the block's rows take the next free items of its class (any order within a class will do)
-      my_rows = key == kRRim ? 0 : rb - ra;
-      my_ra = ra;
-      istart = my_rows ? atomicAdd (&s_icnt[key], my_rows) : 0;
+      const int istart = key == kRRim ? 0 : atomicAdd (&s_icnt[key], rb - ra);
+      s_meta[blk] = (uint16_t) (key | (istart << 4));
     }
-    __syncthreads ();
-    RSTAMP (2);
-    if (s_wide && !exact) {
-      exact = true;
-      if (chunk0 > 0) {         // adds already made may have carried: start the tile over
-        __syncthreads ();
-        for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
-          reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
-        chunk0 = -chunk_cap;
-        continue;
-      }
-    }
-    int cbase[kRCls + 1], ibase[kRCls];       // first sorted block / first item of each class
-    cbase[0] = 0;
-    ibase[0] = 0;
+  }
+  __syncthreads ();
+  RSTAMP (2);
+  int ibase[kRCls];             // first item of each class
+  ibase[0] = 0;
+#pragma unroll
+  for (int k = 0; k + 1 < kRCls; k++)
+    ibase[k + 1] = ibase[k] + s_icnt[k];
+  for (int blk = tid; blk < nblk; blk += kRThreads) {
+    const int meta = s_meta[blk], key = meta & 15;
+    if (key == kRRim)
+      continue;
+    int ib = 0;
 #pragma unroll
     for (int k = 0; k < kRCls; k++)
-      cbase[k + 1] = cbase[k] + s_cnt[k];
+      ib = key == k ? ibase[k] : ib;
+    const int rows = s_hot[blk].rows, ra = rows & 0xff, n = (rows >> 8) & 0xff;
+    uint16_t *ip = s_item + ib + (meta >> 4);
+    for (int r = 0; r < n; r++)
+      ip[r] = (uint16_t) (blk | ((ra + r) << 9));
+  }
+  const bool exact = s_wide != 0;       // a DC value outside 0..255 in the tile: 16-bit sums may wrap
+  const int nrim = s_nrim;
+  __syncthreads ();
+  RSTAMP (3);
+
+  // ---- per plane of the job: accumulate, finish -----------------------------------------------
 #pragma unroll
-    for (int k = 0; k + 1 < kRCls; k++)
-      ibase[k + 1] = ibase[k] + s_icnt[k];
-    if (have) {
-      int base = 0, ib = 0;
-#pragma unroll
-      for (int k = 0; k < kRCls; k++) {
-        base = key == k ? cbase[k] : base;
-        ib = key == k ? ibase[k] : ib;
-      }
-      const int slot = base + rank;
-      s_hot[slot] = info;
-      for (int r = 0; r < my_rows; r++)
-        s_item[ib + istart + r] = (uint16_t) (slot | ((my_ra + r) << 8));
-    }
-    __syncthreads ();
-    RSTAMP (3);
-    // ---- accumulate: a wave's pass is 64 items of one class -------------------------------
+  for (int pl = 0; pl < nplanes; pl++) {
+    PlaneIO io;
+    io.ref[0] = pl ? job.ref_b[0] : job.ref[0];
+    io.ref[1] = pl ? job.ref_b[1] : job.ref[1];
+    io.residual = pl ? job.residual_b : job.residual;
+    io.out = pl ? job.out_b : job.out;
+    io.residual_stride = pl ? job.residual_stride_b : job.residual_stride;
+    io.out_stride = pl ? job.out_stride_b : job.out_stride;
     int turn = 0;
-#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, s_item, s_hot, s_wp, acc, par, npair, \
+#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, \
     ibase[C], ibase[C + 1], exact, &turn)
     SCHRO_ROW_CLASS (0);
     SCHRO_ROW_CLASS (1);
@@ -611,73 +624,103 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     SCHRO_ROW_CLASS (4);
     SCHRO_ROW_CLASS (5);
 #undef SCHRO_ROW_CLASS
-
     RSTAMP (4);
-    // ---- picture-rim blocks: exact clamp / fold path -----------------------------------------
-    if (cbase[kRRim + 1] > cbase[kRRim]) {
+    // picture-rim blocks: exact clamp / fold path
+    if (nrim > 0) {
       const int nseg = (xblen + 3) >> 2, per_block = yblen * nseg;
       const uint32_t m_per_block = div_magic (per_block), m_nseg = div_magic (nseg);
-      const int nslow = cbase[kRRim + 1] - cbase[kRRim];
-      for (int item = tid; item < nslow * per_block; item += kRThreads) {
+      for (int item = tid; item < nrim * per_block; item += kRThreads) {
         const int b = mdiv (item, per_block, m_per_block);
         const int rem = item - b * per_block;
         const int r2 = mdiv (rem, nseg, m_nseg), s2 = rem - r2 * nseg;
-        const RowBlk & hb = s_hot[cbase[kRRim] + b];
+        const RowBlk & hb = s_hot[s_rim[b]];
         const int bx = hb.x + x_lo, by = hb.y + y_lo;
         const int y = by + r2, xs = bx + 4 * s2;
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
         const int fx[2] = { hb.off[0], (int) hb.rxm[0] }, fy[2] = { hb.off[1], (int) hb.rxm[1] };
-        if (prec == 1)
-          row_slow < 1 > (job, bx, by, hb.mode_dc, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+        const int md = pl ? (hb.mode_dc & 3) | (hb.dc_b << 8) : hb.mode_dc;
+        if (job.prec == 1)
+          row_slow < 1 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
         else
-          row_slow < 2 > (job, bx, by, hb.mode_dc, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+          row_slow < 2 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
       }
     }
+    RSTAMP (5);
+    const bool fast = row_finish_is_fast (job, io, x_lo, x_hi);
+    u32x4 res[kRTH * (kRTW / 8) / kRThreads];
+    if (fast)
+      row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+    __syncthreads ();
+    RSTAMP (6);
+    row_finish (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+    if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
+      __syncthreads ();
+      for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
+        reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
+      __syncthreads ();
+    }
   }
-  RSTAMP (5);
-  const bool fast = row_finish_is_fast (job, x_lo, x_hi);
-  u32x4 res[kRTH * (kRTW / 8) / kRThreads];
-  if (fast)
-    row_finish_prefetch (job, tid, x_lo, y_lo, y_hi, res);
-  __syncthreads ();
-  RSTAMP (6);
-  row_finish (job, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
   RSTAMP (9);
 #undef RSTAMP
 }
 
-// Waves per SIMD by row length: the kernel is latency-bound between its barriers, so as many
-// workgroups per CU as the registers of the row in flight allow (measured, 8 x 2160p: 6-pixel
-// chroma rows 0.158 ms at 5 waves, 0.148 at 6; 12-pixel luma rows 0.236 at 5, 0.272 at 6 -- spills)
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
-void obmc_row_kernel_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+// Waves per SIMD: the kernel is latency-bound between its barriers, so as many workgroups per CU
+// as fit: 30 KB of LDS allow five, and so do the registers of a 12-pixel row in flight (measured,
+// 8 x 2160p luma: 0.236 ms at 5 waves per SIMD, 0.272 at 6 -- spills)
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  obmc_row_body < 2 > (jobs, njobs, order);
+  obmc_row_body < 2, 1 > (jobs, njobs, order);
 }
 
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
-void obmc_row_kernel_3 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  obmc_row_body < 3 > (jobs, njobs, order);
+  obmc_row_body < 2, 2 > (jobs, njobs, order);
+}
+
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+void obmc_row_kernel_3_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  obmc_row_body < 3, 1 > (jobs, njobs, order);
+}
+
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+void obmc_row_kernel_3_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+{
+  obmc_row_body < 3, 2 > (jobs, njobs, order);
 }
 
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
-void obmc_row_kernel_4 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+void obmc_row_kernel_4_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  obmc_row_body < 4 > (jobs, njobs, order);
+  obmc_row_body < 4, 1 > (jobs, njobs, order);
 }
 
-template < int ND >
-int
-launch_row_nd (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, const uint32_t * d_order)
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+void obmc_row_kernel_4_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  if constexpr (ND == 2)
-    hipLaunchKernelGGL (obmc_row_kernel_2, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
-  else if constexpr (ND == 3)
-    hipLaunchKernelGGL (obmc_row_kernel_3, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
-  else
-    hipLaunchKernelGGL (obmc_row_kernel_4, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
+  obmc_row_body < 4, 2 > (jobs, njobs, order);
+}
+
+typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *);
+
+int
+launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int np, const uint32_t * d_order)
+{
+  RowKernel k = nullptr;
+  switch (nd * 10 + np) {
+    case 21: k = obmc_row_kernel_2_1; break;
+    case 22: k = obmc_row_kernel_2_2; break;
+    case 31: k = obmc_row_kernel_3_1; break;
+    case 32: k = obmc_row_kernel_3_2; break;
+    case 41: k = obmc_row_kernel_4_1; break;
+    case 42: k = obmc_row_kernel_4_2; break;
+  }
+  if (!k)
+    return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row x %d planes unsupported", nd, np);
+  hipLaunchKernelGGL (k, dim3 (total_tiles), dim3 (kRThreads), 0, stream, d_jobs, njobs, d_order);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "obmc (row) launch: %s", hipGetErrorString (e));
@@ -693,6 +736,10 @@ obmc_row_nd (const ObmcJob & j)
 {
   if (j.prec < 1 || j.prec > 2 || j.xblen > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
     return 0;
+  // the blocks that can meet a 128x32 tile and their rows inside it fit the kernel's tables
+  const int nbi = (kRTW - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
+  if (nbi * nbj > kRBlkCap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > kRItemCap)
+    return 0;
   if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1]) | (uintptr_t) j.ref_stride[0] | (uintptr_t) j.ref_stride[1]) & 15)
     return 0;
   const int need = (j.xblen + 3) / 4;
@@ -700,14 +747,10 @@ obmc_row_nd (const ObmcJob & j)
 }
 
 int
-launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, const uint32_t * d_order)
+launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int planes_per_job,
+    const uint32_t * d_order)
 {
-  switch (nd) {
-    case 2: return launch_row_nd < 2 > (stream, d_jobs, njobs, total_tiles, d_order);
-    case 3: return launch_row_nd < 3 > (stream, d_jobs, njobs, total_tiles, d_order);
-    case 4: return launch_row_nd < 4 > (stream, d_jobs, njobs, total_tiles, d_order);
-  }
-  return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row unsupported", nd);
+  return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order);
 }
 
 }                               // namespace schro

@@ -98,6 +98,15 @@ struct ObmcJob {
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
   uint32_t m_xramp, m_yramp;    // ceil (2^32 / (2 * offset - 1)): get_ramp's division (schromotion.c:40-49)
   unsigned long long *stamps;   // scratch runs only (SCHRO_HIP_OBMC_STAMPS): per-workgroup phase stamps
+  // row kernel: the second plane of a job.  The U and V planes of a picture have the same
+  // blocks, vectors and sample windows, so one workgroup decodes a tile's blocks once and
+  // predicts both planes (nplanes == 2); everything not listed here is shared with plane A
+  int nplanes;
+  int comp_b;
+  const uint8_t *ref_b[2];
+  const void *residual_b;
+  uint8_t *out_b;
+  int residual_stride_b, out_stride_b;
 };
 
 // One picture's slices (lowdelay.hip).
@@ -290,7 +299,7 @@ int launch_obmc_stage (hipStream_t stream, const ObmcJob * d_jobs, int njobs, in
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
 int obmc_row_nd (const ObmcJob & job);
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
-    const uint32_t * d_order);
+    int max_planes, const uint32_t * d_order);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
