@@ -38,8 +38,11 @@ constexpr int kRThreads = 256;
 constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1)
 constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
 constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
-constexpr int kRBlkCap = 384;           // blocks whose footprint meets a tile
-constexpr int kRItemCap = 2048;         // their (block, row) items
+// blocks whose footprint meets a tile and their (block, row) items: by row length (8-pixel rows
+// and shorter are the small, many blocks of chroma planes and of the 8/4 block set)
+template < int ND > struct RowCaps {
+  static constexpr int kBlk = ND <= 2 ? 384 : 128, kItem = ND <= 2 ? 2048 : 1024;
+};
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
 constexpr int kRCls = 7;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 rim
 constexpr int kRRim = kRCls - 1;
@@ -429,6 +432,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[kRTH * kRAccW];
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
+  constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
   __shared__ uint16_t s_meta[kRBlkCap];         // class | first item within the class << 4
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
@@ -738,12 +742,14 @@ obmc_row_nd (const ObmcJob & j)
     return 0;
   // the blocks that can meet a 128x32 tile and their rows inside it fit the kernel's tables
   const int nbi = (kRTW - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
-  if (nbi * nbj > kRBlkCap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > kRItemCap)
-    return 0;
   if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1]) | (uintptr_t) j.ref_stride[0] | (uintptr_t) j.ref_stride[1]) & 15)
     return 0;
-  const int need = (j.xblen + 3) / 4;
-  return need <= 2 ? 2 : need;  // 2, 3 or 4
+  const int need = (j.xblen + 3) / 4, nd = need <= 2 ? 2 : need;        // 2, 3 or 4
+  const int blk_cap = nd <= 2 ? RowCaps < 2 >::kBlk : RowCaps < 3 >::kBlk;
+  const int item_cap = nd <= 2 ? RowCaps < 2 >::kItem : RowCaps < 3 >::kItem;
+  if (nbi * nbj > blk_cap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > item_cap)
+    return 0;
+  return nd;
 }
 
 int
