@@ -688,6 +688,10 @@ int schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src);
 /* schro_frame_shift_right (schroframe.c:1265-1293) on a device s16 / s32 frame */
 int schro_hipframe_shift_right (SchroHipFrame * frame, int shift);
 
+/* diagnostics: with SCHRO_HIP_OBMC_STAMPS set, the row / staged OBMC kernels record cycle stamps
+ * per phase and workgroup; this prints their medians to stderr (scratch runs only) */
+void schro_hip_obmc_stamps_dump (void);
+
 /* ---- several devices behind one decode loop -----------------------------
  *
  * One exec-domain thread per device, each with its own context -- the reference's

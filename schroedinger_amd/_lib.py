@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_synchronize", "schro_hip_stream",
     "schro_memory_domain_new_hip", "schro_memory_domain_free_hip", "schro_hip_domain_context",
     "schro_hip_context_domain",
+    "schro_hip_obmc_stamps_dump",
     "schro_hip_scheduler_new", "schro_hip_scheduler_new_virtual", "schro_hip_scheduler_free",
     "schro_hip_scheduler_n_devices", "schro_hip_scheduler_context", "schro_hip_scheduler_submit",
     "schro_hip_scheduler_retire", "schro_hip_scheduler_wait",
