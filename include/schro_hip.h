@@ -319,12 +319,16 @@ int schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * 
  * [0, 2w-2] x [0, 2h-2], which is what the reference's 32-pixel aprons
  * materialise.
  *
- * Memory layout of HP ("tiled 16x8"): OBMC gathers a 24-byte x 24-row window of
- * HP per 12x12 block and reference, and on MI355X the cost of that gather is
- * the number of 128-byte cache lines it touches.  HP is therefore stored so
- * that one line holds 16 bytes x 8 rows instead of 128 bytes of one row:
- *   offset (x, y) = (y >> 3) * 8 * stride + (x >> 4) * 128 + (y & 7) * 16 + (x & 15)
- * with stride % 16 == 0 and the buffer holding round_up (2*height, 8) rows of
+ * Memory layout of HP ("tiled"): OBMC gathers a 24-byte x 24-row window of HP per
+ * 12x12 block and reference -- every second row of it, or all of them at a
+ * vertical half position -- and on MI355X the cost of that gather is the number
+ * of 128-byte cache lines it touches.  HP is therefore stored so that one line
+ * holds 16 bytes of each of 8 rows OF ONE PARITY instead of 128 bytes of one row:
+ * a band of 16 rows is two "tile rows" of 8 * stride bytes, rows 0,2,..,14 of the
+ * band in the first and rows 1,3,..,15 in the second,
+ *   offset (x, y) = ((y >> 4) * 2 + (y & 1)) * 8 * stride + (x >> 4) * 128
+ *                   + ((y >> 1) & 7) * 16 + (x & 15)
+ * with stride % 16 == 0 and the buffer holding round_up (2*height, 16) rows of
  * `stride` bytes (the same size as a linear image of that many rows).
  * schro_hip_upsampled_bytes () gives stride and size,
  * schro_hip_upsampled_download () copies an HP image to the host in linear
@@ -332,7 +336,7 @@ int schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * 
 typedef struct {
   const uint8_t *src;
   int src_stride;
-  uint8_t *dst;                 /* tiled 16x8, see above */
+  uint8_t *dst;                 /* tiled, see above */
   int dst_stride;               /* bytes, >= 2*width, multiple of 16 */
   int width;
   int height;

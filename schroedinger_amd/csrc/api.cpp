@@ -962,7 +962,7 @@ schro_hip_upsampled_bytes (int width, int height, int *stride)
   const size_t st = round_up ((size_t) width * 2, 64);
   if (stride)
     *stride = (int) st;
-  return st * round_up ((size_t) height * 2, 8);
+  return st * round_up ((size_t) height * 2, kHpBand);
 }
 
 int
@@ -972,7 +972,7 @@ schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride
   SCHRO_HIP_REQUIRE (ctx && host && dev && width > 0 && height > 0 && dev_stride >= 2 * width
       && dev_stride % 16 == 0 && host_stride >= 2 * width, "upsampled_download: bad arguments");
   (void) hipSetDevice (ctx->device);
-  const size_t rows = round_up ((size_t) height * 2, 8);
+  const size_t rows = round_up ((size_t) height * 2, kHpBand);
   std::vector < uint8_t > raw ((size_t) dev_stride * rows);
   SCHRO_HIP_CHECK (hipMemcpyAsync (raw.data (), dev, raw.size (), hipMemcpyDeviceToHost, ctx->stream));
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
@@ -1610,8 +1610,8 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     c->v_shift = k ? v_shift : 0;
     int mul = upsampled ? 2 : 1;
     c->stride = (int) round_up ((size_t) c->width * mul * bpp, 64);
-    // half-pel images are tiled 16x8: whole tile rows
-    c->length = c->stride * (upsampled ? (int) round_up ((size_t) c->height * 2, 8) : c->height);
+    // half-pel images are tiled: whole bands of 16 rows
+    c->length = c->stride * (upsampled ? (int) round_up ((size_t) c->height * 2, kHpBand) : c->height);
     total += round_up ((size_t) c->length, 256);
   }
   void *base = schro_hip_domain_alloc (ctx, total);

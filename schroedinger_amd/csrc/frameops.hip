@@ -199,12 +199,11 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   __syncthreads ();
 
   // Phase 3: horizontal half-pel samples, interleave, store.  One lane = 8 pixels of one row =
-  // one 16-byte tile row of HP row 2y and the one of row 2y + 1 right behind it (32 contiguous
-  // bytes); the lanes of four neighbouring rows are neighbours, so four lanes write one whole
-  // 128-byte line (rows 2y .. 2y+7 of a tile) instead of eight lanes writing 8-byte pieces
-  // of sixteen.
-  static_assert (kThreads == (kUpTW / 8) * kUpTH, "one lane per 8 pixels of the tile");
-  const int ly = (tid & 3) | ((tid >> 6) << 2), g8 = (tid >> 2) & (kUpTW / 8 - 1);
+  // the 16-byte tile row of HP row 2y (in the band's even tile row) and the one of row 2y + 1
+  // (same place in the odd tile row); the lanes of eight neighbouring rows are neighbours, so
+  // eight lanes write two whole 128-byte lines instead of 8-byte pieces of sixteen.
+  static_assert (kThreads == (kUpTW / 8) * kUpTH && kUpTH % 8 == 0, "one lane per 8 pixels of the tile");
+  const int ly = (tid & 7) | ((tid >> 7) << 3), g8 = (tid >> 3) & (kUpTW / 8 - 1);
   const int gx = x0 + 8 * g8, gy = y0 + ly;
   if (gx >= w || gy >= h)
     return;
@@ -244,16 +243,17 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     __builtin_amdgcn_perm (d1[1], c0[1], 0x05010400u), __builtin_amdgcn_perm (d1[1], c0[1], 0x07030602u) };
   const u32x4 odd = { __builtin_amdgcn_perm (d3[0], c2[0], 0x05010400u), __builtin_amdgcn_perm (d3[0], c2[0], 0x07030602u),
     __builtin_amdgcn_perm (d3[1], c2[1], 0x05010400u), __builtin_amdgcn_perm (d3[1], c2[1], 0x07030602u) };
-  // tiled 16x8 (include/schro_hip.h): 2 gx is a multiple of 16 -- one tile row --, rows 2 gy
-  // and 2 gy + 1 are in the same tile, 16 bytes apart
+  // 2 gx is a multiple of 16 -- one tile row; rows 2 gy and 2 gy + 1 have the same slot in the
+  // even and the odd tile row of their band
   uint8_t *de = job.dst + hp_offset (2 * gx, 2 * gy, job.dst_stride);
+  uint8_t *dd = job.dst + hp_offset (2 * gx, 2 * gy + 1, job.dst_stride);
   if (gx + 8 <= w && (((uintptr_t) de) & 15) == 0) {
     gstore < u32x4 > (de, even);
-    gstore < u32x4 > (de + 16, odd);
+    gstore < u32x4 > (dd, odd);
   } else {
     for (int e = 0; e < 16 && gx + e / 2 < w; e++) {
       gstore < uint8_t > (de + e, (uint8_t) (even[e >> 2] >> (8 * (e & 3))));
-      gstore < uint8_t > (de + 16 + e, (uint8_t) (odd[e >> 2] >> (8 * (e & 3))));
+      gstore < uint8_t > (dd + e, (uint8_t) (odd[e >> 2] >> (8 * (e & 3))));
     }
   }
 }

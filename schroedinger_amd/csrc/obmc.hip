@@ -313,7 +313,7 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
 #pragma unroll
         for (int k = 0; k < 2; k++) {
           const int Y = clampi (hy + k, 0, 2 * job.h - 2);
-          rows[k] = job.ref[r] + (size_t) (Y >> 3) * 8 * (size_t) job.ref_stride[r] + (size_t) ((Y & 7) * 16);
+          rows[k] = job.ref[r] + hp_row_offset (Y, job.ref_stride[r]);
         }
         int p[2][9];
 #pragma unroll
@@ -491,7 +491,7 @@ struct ItemLane {
   int seg_bytes;                // byte offset of the segment inside the sample window
   int tw3;                      // tile width + 3 (range test of a segment)
   bool active;                  // lanes beyond the last whole item of a pass idle
-  // half-pel references (tiled 16x8): the load role of this lane -- one 16-byte chunk of
+  // half-pel references (tiled): the load role of this lane -- one 16-byte chunk of
   // each sample row of its OWN item
   uint8_t *stage;               // this wave's staging buffer
   int ld_x8;                    // chunk * 128 (byte offset of the chunk's tile column)
@@ -503,11 +503,11 @@ struct ItemLane {
 // stages, for each of its items, the aligned 16-byte chunks that cover the item's
 // 8 * nseg sample bytes of row(s) 2 row (+ 1) -- every lane loads two chunks, whatever
 // item they belong to -- then each lane reads its own 8 (+ 8) bytes back at the window's
-// byte phase.  16-byte chunk = one row of a 16x8 tile: the chunks of one item's two rows
-// mostly share a cache line, and so do those of the rows above and below.
+// byte phase.  16-byte chunk = one row of a tile (16 bytes x 8 rows of one parity): the chunks
+// of the rows above and below share its cache line.
 // load role: the 16-byte chunk (ld_x8 / 128) of sample rows 2 row (+ 1) of the block's window.
-// off_r is the offset of the window's first chunk in the tile row of its first sample row,
-// the phase (y & 7) of that row comes with it.
+// off_r is the offset of the window's first chunk in the band (16 rows) of its first sample
+// row, the phase (y & 15) of that row comes with it.
 template < int PC >
 __device__ __forceinline__ void
 tiled_load (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t own_phase, int row,
@@ -515,12 +515,15 @@ tiled_load (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t
 {
   static_assert (PC >= 1, "plain references are linear");
   const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
-  const uint32_t y0 = (own_phase & 7u) + 2u * (uint32_t) row;
-  const uint32_t o0 = (uint32_t) off_r + __umul24 (y0 >> 3, tile_row_bytes) + ((y0 & 7u) << 4) + (uint32_t) il.ld_x8;
+  // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
+  const uint32_t y0 = (own_phase & 15u) + 2u * (uint32_t) row;
+  const uint32_t o0 = (uint32_t) off_r + __umul24 (((y0 >> 3) & ~1u) | (y0 & 1u), tile_row_bytes) + ((y0 & 14u) << 3)
+      + (uint32_t) il.ld_x8;
   v[0] = gload < u32x4 > (job.ref[r] + o0);
   if constexpr (PC == 2) {
     const uint32_t y1 = y0 + 1u;
-    const uint32_t o1 = (uint32_t) off_r + __umul24 (y1 >> 3, tile_row_bytes) + ((y1 & 7u) << 4) + (uint32_t) il.ld_x8;
+    const uint32_t o1 = (uint32_t) off_r + __umul24 (((y1 >> 3) & ~1u) | (y1 & 1u), tile_row_bytes) + ((y1 & 14u) << 3)
+      + (uint32_t) il.ld_x8;
     v[1] = gload < u32x4 > (job.ref[r] + o1);
   }
 }
@@ -778,8 +781,8 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
         if (!inside)
           md |= 4 << r;
         // plain planes are linear.  Half-pel images are tiled: keep the offset of the window's
-        // first 16-byte chunk in the tile row of its first sample row, and the phases
-        // (y & 7) | (x & 15) << 4 of the first sample
+        // first 16-byte chunk in the band (16 rows, two tile rows) of its first sample row, and the
+        // phases (y & 15) | (x & 15) << 4 of the first sample
         if constexpr (PC == 0) {
           info.off[r] = inside ? gy0 * job.ref_stride[r] + gx0 : 0;
         } else {
@@ -788,8 +791,8 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
             inside = false;
             md |= 4 << r;
           }
-          info.off[r] = inside ? (gy0 >> 3) * (8 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
-          phases |= inside ? ((gy0 & 7) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+          info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
+          phases |= inside ? ((gy0 & 15) | ((gx0 & 15) << 4)) << (8 * r) : 0;
         }
         info.wpk[r] = wpk;
       }

@@ -37,7 +37,7 @@ obmc_weight_1d (int i, int blen, int offset)
 }
 
 // One reference sample at (sx, sy) in 1/2^prec pel units.
-// PC 0: plain plane.  PC 1: half-pel image (tiled 16x8).  PC 2: 1/4- or 1/8-pel bilinear
+// PC 0: plain plane.  PC 1: half-pel image (tiled).  PC 2: 1/4- or 1/8-pel bilinear
 // of four half-pel samples (orc_combine4_nxm_u8, schroorc.orc:1635-1662; the
 // avg2 / copy special cases of schroframe.c:2306-2350 are the same formula).
 template < int PC >

@@ -11,8 +11,8 @@
 //   * a lane owns a whole block ROW (12 luma pixels), not a 4-pixel segment: one item decode,
 //     one address computation, one weight-table read per row instead of three;
 //   * the lane loads its own row's 16-byte tile rows (adjacent lanes = adjacent rows of a
-//     block = the same 128-byte line of the 16x8-tiled half-pel image: one TA cycle per
-//     4 lanes) straight into registers and aligns them there (a two-level select by the
+//     block = sample rows of one parity = the same 128-byte line of the tiled half-pel image:
+//     one TA cycle per 4 lanes) straight into registers and aligns them there (a two-level select by the
 //     window's dword phase + v_alignbyte) -- no LDS staging buffer, which frees 11 KB of LDS;
 //   * prediction is byte-parallel: at half / quarter pel orc_combine4_nxm_u8
 //     (schroorc.orc:1635-1662) degenerates to copy / 2-sample / 4-sample rounding averages,
@@ -50,6 +50,9 @@ constexpr int kRRim = kRCls - 1;
 #define SCHRO_ROW_SERIAL 0
 #endif
 constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
+#ifndef SCHRO_ROW_WAVES
+#define SCHRO_ROW_WAVES 5
+#endif
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
@@ -133,7 +136,7 @@ predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r
 {
   constexpr int NCH = ND <= 2 ? 2 : 3;  // 16-byte tile rows that can hold the 2 * xblen + 15 bytes from the chunk's start
   constexpr int NU = 2 * ND + 1;        // dwords from the window's first dword on
-  const uint32_t tile_row_bytes = 8u * (uint32_t) ref_stride;
+  const uint32_t tile_row_bytes = 8u * (uint32_t) ref_stride;   // (two per band of 16 rows: even rows, odd rows)
   const uint32_t s = phase >> 4;        // x & 15 of the first sample
   const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
   const uint8_t *base = ref + off_r;
@@ -145,8 +148,9 @@ predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r
 #pragma unroll
   for (int v = 0; v < (RY ? 2 : 1); v++) {
     uint32_t c[4 * NCH + 2];
-    const uint32_t y = (phase & 7u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
-    const uint8_t *p = base + (__umul24 (y >> 3, tile_row_bytes) + ((y & 7u) << 4));
+    // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
+    const uint32_t y = (phase & 15u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
+    const uint8_t *p = base + (__umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3));
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j < NCH - 1 || last) {
@@ -548,8 +552,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
           inside = false;
         if (!inside && (mode & (r + 1)))
           clamped = true;
-        info.off[r] = inside ? (gy0 >> 3) * (8 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
-        phases |= inside ? ((gy0 & 7) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+        info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
+        phases |= inside ? ((gy0 & 15) | ((gx0 & 15) << 4)) << (8 * r) : 0;
         info.rxm[r] = (rx ? 0xfffffffeu : 0u) | (ry[r] ? 1u : 0u);
       }
       const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
@@ -672,25 +676,25 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // Waves per SIMD: the kernel is latency-bound between its barriers, so as many workgroups per CU
 // as fit: 30 KB of LDS allow five, and so do the registers of a 12-pixel row in flight (measured,
 // 8 x 2160p luma: 0.236 ms at 5 waves per SIMD, 0.272 at 6 -- spills)
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 1 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
 void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 2 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
 void obmc_row_kernel_3_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 3, 1 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
 void obmc_row_kernel_3_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 3, 2 > (jobs, njobs, order);

@@ -525,7 +525,8 @@ void obmc_stage_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint
       pitch = 16 * (ncx | 1);   // odd number of 16-byte units: 8 rows of a cache line hit 8 different bank groups
       nry = ymax - ymin + 1;
       const int ny8max = (kStageLoads * kSThreads) / (8 * ncx);
-      const int maxrows = min (kStageBytes / pitch, 8 * (ny8max - 1));
+      // (a band of 16 rows = two tile rows; the window's rows can start anywhere in a band)
+      const int maxrows = min (kStageBytes / pitch, 16 * ((ny8max >> 1) - 1));
       if (nry > maxrows) {
         ymin += (nry - maxrows) >> 1;
         nry = maxrows;
@@ -537,7 +538,7 @@ void obmc_stage_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint
     s_reg[r][3] = nry;
     s_reg[r][4] = pitch;
     s_reg[r][5] = valid;
-    s_reg[r][6] = valid ? ((ymin + nry - 1) >> 3) - (ymin >> 3) + 1 : 0;
+    s_reg[r][6] = valid ? 2 * (((ymin + nry - 1) >> 4) - (ymin >> 4) + 1) : 0;        // tile rows (8 rows of one parity)
     s_reg[r][7] = (int) div_magic (ncx);
   }
   __syncthreads ();
@@ -553,11 +554,10 @@ void obmc_stage_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint
       const int idx = tid + k * kSThreads;
       if (idx < nchunk) {
         const int q = idx >> 3, y8 = mdiv (q, ncx, m), cx = q - y8 * ncx;
-        const int yy = (ymin & ~7) + 8 * y8 + (idx & 7);
+        const int yy = (ymin & ~15) + 16 * (y8 >> 1) + (y8 & 1) + 2 * (idx & 7);
         if (yy >= ymin && yy < ymin + nry) {
           const int ym = min (yy, ymax_mem), cm = min (X0 + cx, cmax_mem);
-          v[k] = gload < u32x4 > (job.ref[r] + (size_t) (ym >> 3) * 8 * (size_t) job.ref_stride[r]
-              + (size_t) cm * 128 + (size_t) ((ym & 7) * 16));
+          v[k] = gload < u32x4 > (job.ref[r] + hp_row_offset (ym, job.ref_stride[r]) + (size_t) cm * 128);
         }
       }
     }
@@ -571,7 +571,7 @@ void obmc_stage_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint
       const int idx = tid + k * kSThreads;
       if (idx < nchunk) {
         const int q = idx >> 3, y8 = mdiv (q, ncx, m), cx = q - y8 * ncx;
-        const int yy = (ymin & ~7) + 8 * y8 + (idx & 7);
+        const int yy = (ymin & ~15) + 16 * (y8 >> 1) + (y8 & 1) + 2 * (idx & 7);
         if (yy >= ymin && yy < ymin + nry)
           *reinterpret_cast < u32x4 * >(s_stage + kStagePad + (yy - ymin) * pitch + 16 * cx) = v[k];
       }

@@ -219,11 +219,23 @@ div_magic (int d)
   return d <= 1 ? 0u : (uint32_t) ((0x100000000ull + (uint32_t) d - 1) / (uint32_t) d);
 }
 
-// byte offset of half-pel sample (x, y) in the tiled 16x8 layout (include/schro_hip.h)
+// Half-pel images (include/schro_hip.h): one 128-byte line = 16 bytes of each of 8 rows OF THE
+// SAME PARITY.  A band of 16 rows takes two tile rows (8 * stride bytes each), the even rows
+// first; row y sits in slot (y >> 1) & 7 of its tile row.
+constexpr int kHpBand = 16;     // rows per band; images hold whole bands
+
+// byte offset of the 16-byte tile row of row y in tile column 0
+__host__ __device__ __forceinline__ size_t
+hp_row_offset (int y, int stride)
+{
+  return ((size_t) (y >> 4) * 2 + (size_t) (y & 1)) * 8 * (size_t) stride + (size_t) (((y >> 1) & 7) * 16);
+}
+
+// byte offset of half-pel sample (x, y)
 __host__ __device__ __forceinline__ size_t
 hp_offset (int x, int y, int stride)
 {
-  return (size_t) (y >> 3) * 8 * (size_t) stride + (size_t) (x >> 4) * 128 + (size_t) ((y & 7) * 16 + (x & 15));
+  return hp_row_offset (y, stride) + (size_t) (x >> 4) * 128 + (size_t) (x & 15);
 }
 
 __device__ __forceinline__ int
