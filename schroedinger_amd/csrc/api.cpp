@@ -1275,9 +1275,54 @@ schro_hip_obmc_stamps_dump (void)
     if (v.empty ())
       continue;
     std::sort (v.begin (), v.end ());
-    fprintf (stderr, "stamp %d: median %llu  p10 %llu  p90 %llu  (n=%zu)\n", n, v[v.size () / 2], v[v.size () / 10],
-        v[v.size () * 9 / 10], v.size ());
+    unsigned long long sum = 0;
+    for (auto x : v)
+      sum += x;
+    fprintf (stderr, "stamp %d: median %llu  p10 %llu  p90 %llu  p99 %llu  max %llu  mean %llu  (n=%zu)\n", n, v[v.size () / 2],
+        v[v.size () / 10], v[v.size () * 9 / 10], v[v.size () * 99 / 100], v.back (), sum / v.size (), v.size ());
   }
+  // occupancy: workgroup lifetimes against the span of the workgroups that ran on the same CU
+  // (HW_ID: cu 8-11, sh 12, se 13-15; XCC_ID 0-3)
+  std::vector < std::pair < int, int > >by_cu;
+  for (int b = 0; b < 16384; b++)
+    if (h[b * 16 + 9])
+      by_cu.push_back ({ (int) (((h[b * 16 + 14] >> 8) & 0xff) | ((h[b * 16 + 15] & 0xf) << 8)), b });
+  std::sort (by_cu.begin (), by_cu.end ());
+  double life_all = 0, cap_all = 0;
+  unsigned long long span_max = 0, span_min = ~0ull;
+  size_t ncu = 0;
+  for (size_t i = 0; i < by_cu.size ();) {
+    size_t j = i;
+    unsigned long long t0 = ~0ull, t1 = 0, life = 0;
+    for (; j < by_cu.size () && by_cu[j].first == by_cu[i].first; j++) {
+      const int b = by_cu[j].second;
+      t0 = std::min (t0, h[b * 16 + 12]);
+      t1 = std::max (t1, h[b * 16 + 13]);
+      life += h[b * 16 + 13] - h[b * 16 + 12];
+    }
+    life_all += (double) life;
+    cap_all += (double) (t1 - t0);
+    span_max = std::max (span_max, t1 - t0);
+    span_min = std::min (span_min, t1 - t0);
+    ncu++;
+    i = j;
+  }
+  for (int x = 0; x < 16; x++) {
+    unsigned long long t0 = ~0ull, t1 = 0, life = 0;
+    size_t nw = 0;
+    for (int b = 0; b < 16384; b++)
+      if (h[b * 16 + 9] && (int) (h[b * 16 + 15] & 0xf) == x) {
+        t0 = std::min (t0, h[b * 16 + 12]);
+        t1 = std::max (t1, h[b * 16 + 13]);
+        life += h[b * 16 + 13] - h[b * 16 + 12];
+        nw++;
+      }
+    if (nw)
+      fprintf (stderr, "  XCD %d: %zu workgroups, span %llu ticks, mean lifetime %llu\n", x, nw, t1 - t0, life / nw);
+  }
+  if (ncu)
+    fprintf (stderr, "%zu workgroups on %zu CUs: per-CU span %llu .. %llu ticks, resident workgroups per CU %.2f\n",
+        by_cu.size (), ncu, span_min, span_max, life_all / cap_all);
 }
 
 static int
@@ -1339,6 +1384,43 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     std::stable_sort (keys.begin (), keys.end (),[](const Key & a, const Key & b) {
           return a.row != b.row ? a.row < b.row : a.ref < b.ref;
         });
+    // Every XCD runs a fixed eighth of the workgroups (xcd_tile_id: XCD x runs entries
+    // [x q + min (x, r), ...)).  The tiles on the picture's rim take the exact per-sample path
+    // for their outer blocks and live two to three times as long as the others (stamps: 57-72 k
+    // cycles against a median of 29 k), and the bands at the top and the bottom of the pictures
+    // hold most of them: with whole bands per XCD the first and the last XCD ran 25 % longer
+    // than the others.  So the rim tiles are dealt out evenly, and each XCD starts with its
+    // share of them (longest first), then runs its band of inner tiles.
+    {
+      auto is_rim = [&](const Key & k) {
+        const size_t j = k.entry >> 16;
+        const int t = (int) (k.entry & 0xffffu), tx = t % jobs[j].tiles_x, ty = t / jobs[j].tiles_x;
+        return tx == 0 || ty == 0 || tx == jobs[j].tiles_x - 1 || ty == tiles_y[j] - 1;
+      };
+      constexpr size_t kXcd = 8;
+      std::vector < Key > rim_sorted, rim, inner;
+      for (const Key & k : keys)
+        (is_rim (k) ? rim_sorted : inner).push_back (k);
+      // (every eighth one to an XCD: top / bottom rows, side columns and corners in equal parts)
+      for (size_t x = 0; x < kXcd; x++)
+        for (size_t k = x; k < rim_sorted.size (); k += kXcd)
+          rim.push_back (rim_sorted[k]);
+      const size_t q = keys.size () / kXcd, r = keys.size () % kXcd;
+      size_t ri = 0, ii = 0, out = 0;
+      for (size_t x = 0; x < kXcd; x++) {
+        const size_t n = q + (x < r ? 1 : 0);
+        size_t nr = rim.size () / kXcd + (x < rim.size () % kXcd ? 1 : 0);
+        nr = std::min (nr, n);
+        if (n - nr > inner.size () - ii)        // (more rim than inner tiles: small planes)
+          nr = n - (inner.size () - ii);
+        for (size_t k = 0; k < nr; k++)
+          keys[out++] = rim[ri++];
+        for (size_t k = nr; k < n; k++)
+          keys[out++] = inner[ii++];
+      }
+      if (ri != rim.size () || ii != inner.size () || out != keys.size ())
+        return set_error (SCHRO_HIP_EINVAL, "obmc tile order: rim / inner split does not add up");
+    }
     slot = lru;
     if (slot->copy_pending) {   // the mirror's previous upload: long done unless tables churn
       SCHRO_HIP_CHECK (hipEventSynchronize (slot->copied));
