@@ -320,7 +320,33 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
     int val[2][4] = { {0, 0, 0, 0}, {0, 0, 0, 0} };
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      if (mode & (r + 1)) {
+      if (!(mode & (r + 1)))
+        continue;
+      if constexpr (PC == 2) {
+        // fetch_ref < 2 > for four pixels at once: they are 8 eighth-pels apart, share the blend
+        // weights and read nine adjacent half-pel columns of two rows, each clamped on its own;
+        // samples whose weight is zero (integer positions) are not fetched
+        const int sx = fx[r] + 4 * seg * (1 << prec), sy = fy[r] + row * (1 << prec);
+        const int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
+        const int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
+        const uint8_t *r0 = refs[r] + hp_row_offset (clampi (hy, 0, 2 * job.h - 2), job.ref_stride[r]);
+        const uint8_t *r1 = refs[r] + hp_row_offset (clampi (hy + 1, 0, 2 * job.h - 2), job.ref_stride[r]);
+        int p0[9], p1[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const int X = clampi (hx + j, 0, 2 * job.w - 2);
+          const int col = (X >> 4) * 128 + (X & 15);
+          const bool need = (j & 1) == 0 || rx != 0;
+          p0[j] = need ? (int) gload < uint8_t > (r0 + col) : 0;
+          p1[j] = need && ry != 0 ? (int) gload < uint8_t > (r1 + col) : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int v = (4 - ry) * ((4 - rx) * p0[2 * e] + rx * p0[2 * e + 1])
+              + ry * ((4 - rx) * p1[2 * e] + rx * p1[2 * e + 1]);
+          val[r][e] = (v + 8) >> 4;
+        }
+      } else {
 #pragma unroll
         for (int e = 0; e < 4; e++)
           val[r][e] = fetch_ref < PC > (refs[r], job.ref_stride[r], job.w, job.h,
@@ -640,6 +666,20 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     io.out = pl ? job.out_b : job.out;
     io.residual_stride = pl ? job.residual_stride_b : job.residual_stride;
     io.out_stride = pl ? job.out_stride_b : job.out_stride;
+    // The residual of the fast finish is asked for before the passes where the registers allow
+    // (8 per lane, held through the passes): it streams from HBM, and fetched after the passes
+    // its latency was the tile's to wait for.
+#ifndef SCHRO_ROW_EARLY_RES
+#define SCHRO_ROW_EARLY_RES 1
+#endif
+    constexpr bool kEarlyRes = SCHRO_ROW_EARLY_RES != 0 && (SCHRO_ROW_EARLY_RES > 1 || (ND >= 3 && NP == 1));
+    const bool fast = row_finish_is_fast (job, io, x_lo, x_hi);
+    u32x4 res[kRTH * (kRTW / 8) / kRThreads];
+    if constexpr (kEarlyRes) {
+      if (fast)
+        row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+      __builtin_amdgcn_sched_barrier (0);
+    }
     int turn = 0;
 #if SCHRO_ROW_WHATIF >= 3
 #define SCHRO_ROW_CLASS(C) (void) turn
@@ -678,10 +718,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
     RSTAMP (5);
 #if SCHRO_ROW_WHATIF < 4
-    const bool fast = row_finish_is_fast (job, io, x_lo, x_hi);
-    u32x4 res[kRTH * (kRTW / 8) / kRThreads];
-    if (fast)
-      row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+    if constexpr (!kEarlyRes) {
+      if (fast)
+        row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+    }
     __syncthreads ();
     RSTAMP (6);
     row_finish (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
