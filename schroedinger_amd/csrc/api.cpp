@@ -1607,6 +1607,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order);
     if (r)
       return r;
+    if (g_stamps)               // scratch runs: the dump describes the last launch only
+      (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
       r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, paired ? 2 : 1, d_order)
