@@ -50,9 +50,6 @@ constexpr int kRRim = kRCls - 1;
 #define SCHRO_ROW_SERIAL 0
 #endif
 constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
-#ifndef SCHRO_ROW_WHATIF
-#define SCHRO_ROW_WHATIF 0
-#endif
 #ifndef SCHRO_ROW_WAVES
 #define SCHRO_ROW_WAVES 5
 #endif
@@ -157,11 +154,7 @@ predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j < NCH - 1 || last) {
-#if SCHRO_ROW_WHATIF == 1
-        const u32x4 q = { (uint32_t) (uintptr_t) p, (uint32_t) (uintptr_t) p + j, s, y };
-#else
         const u32x4 q = gload < u32x4 > (p + 128 * j);
-#endif
         c[4 * j + 0] = q.x;
         c[4 * j + 1] = q.y;
         c[4 * j + 2] = q.z;
@@ -241,14 +234,6 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   }
   if (it >= hi)
     return;
-#if SCHRO_ROW_WHATIF == 2
-  {
-#pragma unroll
-    for (int k = 0; k < ND; k++)
-      asm volatile ("" :: "v" (p[k]));
-    return;
-  }
-#endif
   int half;
   uint32_t *aw = acc_word (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
   // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go
@@ -528,9 +513,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
     const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
     nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
-#if SCHRO_ROW_WHATIF >= 6
-    nblk = 0;
-#endif
     const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
     const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;   // last valid half-pel sample column / row
     // the motion vectors of the first round start their way from memory beside the set-up
@@ -638,7 +620,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #pragma unroll
   for (int k = 0; k + 1 < kRCls; k++)
     ibase[k + 1] = ibase[k] + s_icnt[k];
-  for (int blk = tid; blk < (SCHRO_ROW_WHATIF >= 5 ? 0 : nblk); blk += kRThreads) {
+  for (int blk = tid; blk < nblk; blk += kRThreads) {
     const int meta = s_meta[blk], key = meta & 15;
     if (key == kRRim)
       continue;
@@ -681,12 +663,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       __builtin_amdgcn_sched_barrier (0);
     }
     int turn = 0;
-#if SCHRO_ROW_WHATIF >= 3
-#define SCHRO_ROW_CLASS(C) (void) turn
-#else
 #define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, \
     ibase[C], ibase[C + 1], exact, &turn)
-#endif
     SCHRO_ROW_CLASS (0);
     SCHRO_ROW_CLASS (1);
     SCHRO_ROW_CLASS (2);
@@ -717,7 +695,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       }
     }
     RSTAMP (5);
-#if SCHRO_ROW_WHATIF < 4
     if constexpr (!kEarlyRes) {
       if (fast)
         row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
@@ -725,10 +702,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     __syncthreads ();
     RSTAMP (6);
     row_finish (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
-#else
-    if (s_item[tid] == 0xfffe && acc[tid] == 77)
-      io.out[tid] = 1;
-#endif
     if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
       __syncthreads ();
       for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
