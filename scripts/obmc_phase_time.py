@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""OBMC alone on bench.py's workload (GPU box): wall time of a luma-only and a chroma-only batch
+over 20 launches, and -- with SCHRO_HIP_OBMC_STAMPS=1 -- the row kernel's in-kernel phase stamps
+(cycles since the workgroup started: 1 set-up, 2 decode, 3 items, 4 passes, 5 rim, 6 barrier,
+9 end; 10/11 one two-reference pass without / with the accumulate) and the residency per CU.
+PLANES=luma|chroma restricts the run; MOTION=random|smooth|const replaces the bench's motion
+field (uniform in +-16 pel per block) by a pan + slow zoom or by one vector per reference:
+the launch takes the same time with all three."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+import schroedinger_amd as sa  # noqa: E402
+import synth  # noqa: E402
+
+
+def main():
+    ctx = sa.Context(0)
+    wl = bench.Workload(ctx, 8, seed=1, queues=1)
+    wl.step()
+    ctx.synchronize()
+    b = wl.sets[0]
+    nbx, nby = wl.P["x_num_blocks"], wl.P["y_num_blocks"]
+    kind = os.environ.get("MOTION", "random")
+    jobs = b.obmc_jobs
+    if kind != "random":
+        jobs = []
+        for f in range(wl.frames):
+            mv = b.mv_np[f].copy()
+            mode = mv["flags"] & 3
+            if kind == "const":
+                vec = np.tile(np.array([5, -7, 3, 9], np.int16), (mv.shape[0], 1))
+            else:           # a pan + a slow zoom, +-1 quarter pel of noise
+                yy, xx = np.divmod(np.arange(nbx * nby), nbx)
+                n = synth.lcg(4 * nbx * nby, 77 + f).reshape(4, -1) % 3 - 1
+                vec = np.stack([5 + xx // 64 + n[0], -7 + xx // 48 + n[1], 3 + yy // 64 + n[2],
+                                9 - yy // 48 + n[3]], 1).astype(np.int16)
+            mv["v"] = np.where((mode == 0)[:, None], mv["v"], vec)
+            d_mv = ctx.upload_bytes(mv)
+            for k in range(3):
+                jobs.append(sa.obmc_plane(d_mv, wl.P, k, b.hp[0][k], b.hp[1][k], b.iwt_pairs[3 * f + k][1], b.out[f][k]))
+    which = os.environ.get("PLANES", "luma,chroma").split(",")
+    sets = (("luma", [j for i, j in enumerate(jobs) if i % 3 == 0]), ("chroma", [j for i, j in enumerate(jobs) if i % 3]))
+    for name, sel in sets:
+        if name not in which:
+            continue
+        for _ in range(3):
+            ctx.obmc_batch(sel)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.obmc_batch(sel)
+        ctx.synchronize()
+        print(kind, name, "%.4f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+    sa._lib.load().schro_hip_obmc_stamps_dump()
+
+
+if __name__ == "__main__":
+    main()
