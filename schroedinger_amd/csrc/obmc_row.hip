@@ -51,9 +51,6 @@ constexpr int kRRim = kRCls - 1;
 #define SCHRO_ROW_SERIAL 0
 #endif
 constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
-#ifndef SCHRO_ROW_WAVES
-#define SCHRO_ROW_WAVES 5
-#endif
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
@@ -275,7 +272,8 @@ __device__ __forceinline__ void
 row_class (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int npair, int lo, int hi, bool exact, int *turn)
 {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (wave-uniform values in scalar registers: the class loops are scalar branches, not exec masks)
+  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int npass = (hi - lo + 63) >> 6;
   constexpr int kWaves = kRThreads / 64;
   const int k0 = (wave - *turn) & (kWaves - 1);
@@ -620,7 +618,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   ibase[0] = 0;
 #pragma unroll
   for (int k = 0; k + 1 < kRCls; k++)
-    ibase[k + 1] = ibase[k] + s_icnt[k];
+    ibase[k + 1] = ibase[k] + __builtin_amdgcn_readfirstlane (s_icnt[k]);
   for (int blk = tid; blk < nblk; blk += kRThreads) {
     const int meta = s_meta[blk], key = meta & 15;
     if (key == kRRim)
@@ -634,8 +632,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     for (int r = 0; r < n; r++)
       ip[r] = (uint16_t) (blk | ((ra + r) << 9));
   }
-  const bool exact = s_wide != 0;       // a DC value outside 0..255 in the tile: 16-bit sums may wrap
-  const int nrim = s_nrim;
+  const bool exact = __builtin_amdgcn_readfirstlane (s_wide) != 0;      // a DC value outside 0..255 in the tile: 16-bit sums may wrap
+  const int nrim = __builtin_amdgcn_readfirstlane (s_nrim);
   __syncthreads ();
   RSTAMP (3);
 
@@ -720,28 +718,30 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #undef RSTAMP
 }
 
-// Waves per SIMD: the kernel is latency-bound between its barriers, so as many workgroups per CU
-// as fit: 30 KB of LDS allow five, and so do the registers of a 12-pixel row in flight (measured,
-// 8 x 2160p luma: 0.236 ms at 5 waves per SIMD, 0.272 at 6 -- spills)
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
+// Waves per SIMD: as many workgroups per CU as fit -- throughput grows with every resident
+// workgroup until vector issue saturates (luma, workgroups per CU -> tiles per 1000 cycles per CU:
+// 2 0.093, 3 0.130, 4 0.157, 5 0.171, 6 0.186).  The 12-pixel row fits 80 registers since the
+// class loops run on scalar registers: six waves per SIMD for luma (19 KB of LDS); 30 KB of LDS
+// hold the 6-pixel-row kernels (chroma) to five.
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 1 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
 void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 2 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_3_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 3, 1 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WAVES, SCHRO_ROW_WAVES)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
 void obmc_row_kernel_3_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 3, 2 > (jobs, njobs, order);
