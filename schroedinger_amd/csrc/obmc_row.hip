@@ -129,15 +129,21 @@ acc_word (uint32_t * acc, int par, int x, int y, int *half)
 // ONE class whatever their vertical phases)
 template < int ND, bool RY >
 __device__ __forceinline__ void
-predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r, uint32_t phase, int row, uint32_t rxm,
+predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, int ref_stride, int off_r, uint32_t phase, int row, uint32_t rxm,
     uint32_t ry1, uint32_t * out)
 {
   constexpr int NCH = ND <= 2 ? 2 : 3;  // 16-byte tile rows that can hold the 2 * xblen + 15 bytes from the chunk's start
   constexpr int NU = 2 * ND + 1;        // dwords from the window's first dword on
   const uint32_t tile_row_bytes = 8u * (uint32_t) ref_stride;   // (two per band of 16 rows: even rows, odd rows)
   const uint32_t s = phase >> 4;        // x & 15 of the first sample
+  // The tile rows come through buffer loads: 32-bit offsets from the plane's descriptor, and the
+  // last tile row -- needed only when the window reaches into it -- gets an offset beyond the
+  // buffer where it is not: such a load returns zeros without touching memory.  (As an
+  // exec-masked global load it was a branch, and the wait-count pass drains every outstanding
+  // load at a branch join: the four sample rows of a two-reference pass were four serial round
+  // trips.)
   const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
-  const uint8_t *base = ref + off_r;
+  constexpr uint32_t kBeyond = 0x80000000u;
   // (masks and v_bfi, not ?: on array elements: the compiler turns such a select into a
   // run-time index and moves the array to scratch memory)
   const uint32_t m2 = (s & 8u) ? 0xffffffffu : 0u, m1 = (s & 4u) ? 0xffffffffu : 0u;
@@ -148,16 +154,14 @@ predict_row (const ObmcJob & job, const uint8_t * ref, int ref_stride, int off_r
     uint32_t c[4 * NCH + 2];
     // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
     const uint32_t y = (phase & 15u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
-    const uint8_t *p = base + (__umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3));
+    const uint32_t p = (uint32_t) off_r + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-      if (j < NCH - 1 || last) {
-        const u32x4 q = gload < u32x4 > (p + 128 * j);
-        c[4 * j + 0] = q.x;
-        c[4 * j + 1] = q.y;
-        c[4 * j + 2] = q.z;
-        c[4 * j + 3] = q.w;
-      }
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) ((j < NCH - 1 || last ? p : kBeyond) + 128u * j), 0, 0);
+      c[4 * j + 0] = q.x;
+      c[4 * j + 1] = q.y;
+      c[4 * j + 2] = q.z;
+      c[4 * j + 3] = q.w;
     }
     // the window's dwords u[0 .. NU): c[q .. q + NU), q = s >> 2 in 0..3, by a two-level select
     uint32_t t[NU + 1], u[NU];
@@ -199,7 +203,12 @@ __device__ __forceinline__ void
 row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int npair, int it, int hi)
 {
-  const uint8_t *const ref0 = io.ref[0], *const ref1 = io.ref[1];
+  // the references as buffers of whole bands of 16 half-pel rows (include/schro_hip.h)
+  const int hp_rows = (2 * job.h + 15) & ~15;
+  const __amdgpu_buffer_rsrc_t ref0 = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[0], 0,
+      (int) ((uint32_t) job.ref_stride[0] * (uint32_t) hp_rows), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ref1 = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[1], 0,
+      (int) ((uint32_t) job.ref_stride[1] * (uint32_t) hp_rows), 0x00020000);
   const bool st = CLS == 0 && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
   const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
   const int e = s_item[min (it, hi - 1)];
