@@ -45,8 +45,9 @@ template < int ND > struct RowCaps {
   static constexpr int kBlk = ND <= 2 ? 384 : 128, kItem = ND <= 2 ? 2048 : 1024;
 };
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
-constexpr int kRCls = 7;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 rim
-constexpr int kRRim = kRCls - 1;
+constexpr int kRCls = 8;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 edge, 7 rim
+constexpr int kREdge = kRCls - 2;       // windows clamped vertically and / or folded weights, any mode: still a row per lane
+constexpr int kRRim = kRCls - 1;        // windows clamped horizontally, DC values outside 8 bits: per sample
 #ifndef SCHRO_ROW_SERIAL
 #define SCHRO_ROW_SERIAL 0
 #endif
@@ -127,7 +128,9 @@ acc_word (uint32_t * acc, int par, int x, int y, int *half)
 // (RY with ry1 == 0: "the second row" is the first one again -- the same cache lines -- and the
 // vertical average of a row with itself is that row; this lets blocks with two references be
 // ONE class whatever their vertical phases)
-template < int ND, bool RY >
+// ABS (edge class): off_r = first sample row << 17 | offset of the window's first chunk in a tile
+// row, and every sample row is clamped to the image on its own (fetch_ref's CLAMP on y)
+template < int ND, bool RY, bool ABS = false >
 __device__ __forceinline__ void
 predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, int ref_stride, int off_r, uint32_t phase, int row, uint32_t rxm,
     uint32_t ry1, uint32_t * out)
@@ -153,8 +156,14 @@ predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, int ref_stride, in
   for (int v = 0; v < (RY ? 2 : 1); v++) {
     uint32_t c[4 * NCH + 2];
     // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
-    const uint32_t y = (phase & 15u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
-    const uint32_t p = (uint32_t) off_r + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
+    uint32_t y, p;
+    if constexpr (ABS) {
+      y = (uint32_t) clampi ((off_r >> 17) + 2 * row + (v ? (int) ry1 : 0), 0, 2 * job.h - 2);
+      p = ((uint32_t) off_r & 0x1ffffu) + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
+    } else {
+      y = (phase & 15u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
+      p = (uint32_t) off_r + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
+    }
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) ((j < NCH - 1 || last ? p : kBeyond) + 128u * j), 0, 0);
@@ -220,6 +229,21 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = (uint32_t) (pl ? hb.dc_b : hb.mode_dc >> 8) * 0x01010101u;
+  } else if constexpr (CLS == kREdge) {
+    // any mode: both references are read (an unused one at offset 0) and the mode selects
+    uint32_t p1[ND];
+    const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
+    predict_row < ND, true, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
+    __builtin_amdgcn_sched_barrier (0);
+    predict_row < ND, true, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
+    const uint32_t mode = (uint32_t) hb.mode_dc & 3u;
+    const uint32_t dc = (uint32_t) ((pl ? hb.dc_b : hb.mode_dc >> 8) & 0xff) * 0x01010101u;
+    const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const uint32_t a = (p[k] & m0) | (p1[k] & ~m0), b = (p1[k] & m1) | (p[k] & ~m1);  // one reference: average it with itself
+      p[k] = mode ? lerp1 (a, b) : dc;
+    }
   } else if constexpr (CLS == 0) {
     uint32_t p1[ND];
     const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
@@ -245,7 +269,16 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   uint32_t *aw = acc_word (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
   // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go
   uint32_t w[2 * ND];
-  {
+  if constexpr (CLS == kREdge) {
+    // weights folded at the picture's rim (schromotion8.c:673-693): 1-D tables per edge type behind
+    // the plain products -- (left | right << 1) pairs of x weights, (top | bottom << 1) y weights
+    const uint32_t fb = ((uint32_t) hb.mode_dc >> 2) & 15u;
+    const uint32_t *wxf = s_wp + kRWCap + 8 * (fb >> 2), *wyf = s_wp + kRWCap + 32 + 32 * (fb & 3u);
+    const uint32_t wy2 = wyf[row] * 0x00010001u;
+#pragma unroll
+    for (int k = 0; k < 2 * ND; k++)
+      w[k] = __builtin_bit_cast (uint32_t, (u16x2) (__builtin_bit_cast (u16x2, wxf[k]) * __builtin_bit_cast (u16x2, wy2)));
+  } else {
     const u32x2 *wp = reinterpret_cast < const u32x2 * >(s_wp + 2 * ND * row);
 #pragma unroll
     for (int k = 0; k < ND; k++) {
@@ -475,7 +508,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   __shared__ uint16_t s_meta[kRBlkCap];         // class | first item within the class << 4
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
-  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap];
+  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap + 32 + 128];      // + folded x pairs, folded y (edge class)
   __shared__ int s_icnt[kRCls];                 // items of each class
   __shared__ int s_nrim, s_wide;
 
@@ -539,6 +572,29 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       const int r = i / (2 * ND), pr = i - r * (2 * ND);
       s_wp[i] = pr < npair ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
     }
+    // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
+    // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
+    // its first 2 * offset weights, the last one everything from the block step on
+    if (tid < 32 + 128) {
+      auto folded = [](const int *w1, int idx, int blen, int bsep, int off, int type) {
+        if (idx >= blen)
+          return 0;
+        int w = w1[idx];
+        if ((type & 1) && idx < 2 * off)
+          w += w1[2 * off - idx - 1];
+        if ((type & 2) && idx >= bsep)
+          w += w1[2 * (blen - off) - idx - 1];
+        return w;
+      };
+      if (tid < 32) {
+        const int type = tid >> 3, pr = tid & 7;
+        s_wp[kRWCap + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
+            | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
+      } else {
+        const int type = (tid - 32) >> 5, r = (tid - 32) & 31;
+        s_wp[kRWCap + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
+      }
+    }
     RSTAMP (1);
     for (int blk = tid; blk < nblk; blk += kRThreads) {
       const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
@@ -564,8 +620,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
       info.dc_b = pdc_b;
       info.mode_dc = mode | (pdc << 8);
-      int phases = 0, ry[2] = { 0, 0 };
-      bool clamped = false;
+      int phases = 0, ry[2] = { 0, 0 }, off_abs[2] = { 0, 0 };
+      bool clamped_h = false, clamped_v = false;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         int fx, fy;
@@ -580,24 +636,29 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         }
         // both bilinear taps of every sample of the block (conservative for integer positions)
         const int gx1 = gx0 + 2 * xblen - 1, gy1 = gy0 + 2 * (yblen - 1) + 1;
-        bool inside = gx0 >= 0 && gy0 >= 0 && gx1 <= gw && gy1 <= gh;
-        // every 16-byte tile row a lane may fetch lies inside the row pitch
-        if (inside && (gx0 & ~15) + 16 * (((gx0 & 15) + 2 * xblen + 15) >> 4) > job.ref_stride[r])
-          inside = false;
-        if (!inside && (mode & (r + 1)))
-          clamped = true;
+        // columns: the window inside the image, every 16-byte tile row a lane may fetch inside the
+        // row pitch (and the packed form of the edge class wide enough)
+        const bool in_h = gx0 >= 0 && gx1 <= gw && (gx0 & ~15) + 16 * (((gx0 & 15) + 2 * xblen + 15) >> 4) <= job.ref_stride[r]
+            && ((gx0 & ~15) << 3) < (1 << 17) && (unsigned) (gy0 + 16384) < 32768u;
+        const bool in_v = gy0 >= 0 && gy1 <= gh;
+        const bool used = (mode & (r + 1)) != 0;
+        clamped_h |= used && !in_h;
+        clamped_v |= used && !in_v;
+        const bool inside = in_h && in_v;
         info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
-        phases |= inside ? ((gy0 & 15) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+        off_abs[r] = in_h && used ? (int) (((uint32_t) gy0 << 17) | (uint32_t) ((gx0 & ~15) << 3)) : 0;
+        phases |= in_h ? ((inside ? gy0 & 15 : 0) | ((gx0 & 15) << 4)) << (8 * r) : 0;
         info.rxm[r] = (rx ? 0xfffffffeu : 0u) | (ry[r] ? 1u : 0u);
       }
       const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
       info.rows = ra | ((rb - ra) << 8) | (phases << 16);
-      const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + xblen > xfold_hi;
+      // weights fold where the block hangs over the picture's rim: top | bottom << 1 | left << 2 | right << 3
+      const int fold = (by < yoff ? 1 : 0) | (by + yblen > yfold_hi ? 2 : 0) | (bx < xoff ? 4 : 0) | (bx + xblen > xfold_hi ? 8 : 0);
       const bool wide_dc = mode == 0 && ((unsigned) pdc > 255u || (unsigned) pdc_b > 255u);
       if (wide_dc)
         s_wide = 1;
       int key;
-      if (clamped || fold || wide_dc || yblen * 2 * ND > kRWCap) {
+      if (clamped_h || wide_dc || yblen * 2 * ND > kRWCap || xblen > 16) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
         int fx, fy;
@@ -608,6 +669,12 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         info.rxm[0] = (uint32_t) fx;
         info.rxm[1] = (uint32_t) fy;
         s_rim[atomicAdd (&s_nrim, 1)] = (uint16_t) blk;
+      } else if (fold || clamped_v) {
+        // still a row per lane: sample rows clamped one by one, weights from the folded tables
+        key = kREdge;
+        info.off[0] = off_abs[0];
+        info.off[1] = off_abs[1];
+        info.mode_dc |= fold << 2;
       } else if (mode == 3) {
         key = 0;
       } else if (mode == 0) {
@@ -679,6 +746,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     SCHRO_ROW_CLASS (3);
     SCHRO_ROW_CLASS (4);
     SCHRO_ROW_CLASS (5);
+    SCHRO_ROW_CLASS (6);
 #undef SCHRO_ROW_CLASS
     RSTAMP (4);
     // picture-rim blocks: exact clamp / fold path
