@@ -97,18 +97,17 @@ constexpr int kUpDW = kUpTW / 4 + 2;    // LDS dwords per row: pixels x0-4 .. x0
 
 typedef short short2v __attribute__ ((ext_vector_type (2)));
 
+// bytes 0, 1 / 2, 3 of a dword as two 16-bit lanes (one v_perm_b32 each)
 __device__ __forceinline__ short2v
 lo_pair (uint32_t d)
 {
-  short2v r = { (short) (d & 0xff), (short) ((d >> 8) & 0xff) };
-  return r;
+  return __builtin_bit_cast (short2v, __builtin_amdgcn_perm (0u, d, 0x0c010c00u));
 }
 
 __device__ __forceinline__ short2v
 hi_pair (uint32_t d)
 {
-  short2v r = { (short) ((d >> 16) & 0xff), (short) (d >> 24) };
-  return r;
+  return __builtin_bit_cast (short2v, __builtin_amdgcn_perm (0u, d, 0x0c030c02u));
 }
 
 // taps {-1, 3, -7, 21, 21, -7, 3, -1}, clamp ((sum + 16) >> 5, 0, 255) on two lanes
@@ -123,18 +122,20 @@ mas8_pk (const short2v * r)
   return x;
 }
 
-// the same filter on 8 consecutive bytes: lo4 = samples 0..3, hi4 = samples 4..7
+// the same filter on 8 consecutive bytes: lo4 = samples 0..3, hi4 = samples 4..7, both with
+// every byte ^ 0x80 (the pixels as signed bytes s - 128): the taps sum to 32, so
+// sum (t * s) = sum (t * (s - 128)) + 4096, and two signed v_dot4c_i32_i8 take the place of four
+// unsigned dot products and a subtraction
 __device__ __forceinline__ int
 mas8_bytes (uint32_t lo4, uint32_t hi4)
 {
-  uint32_t pos = __builtin_amdgcn_udot4 (lo4, 0x15000300u, 16u, false);        // +3, +21 (+16)
-  pos = __builtin_amdgcn_udot4 (hi4, 0x00030015u, pos, false);                  // +21, +3
-  uint32_t neg = __builtin_amdgcn_udot4 (lo4, 0x00070001u, 0u, false);          // 1, 7
-  neg = __builtin_amdgcn_udot4 (hi4, 0x01000700u, neg, false);                  // 7, 1
-  return clampi (((int) (pos - neg)) >> 5, 0, 255);
+  int acc = __builtin_amdgcn_sdot4 ((int) lo4, (int) 0x15f903ffu, 4096 + 16, false);   // -1, 3, -7, 21
+  acc = __builtin_amdgcn_sdot4 ((int) hi4, (int) 0xff03f915u, acc, false);              // 21, -7, 3, -1
+  return clampi (acc >> 5, 0, 255);
 }
 
-// horizontal half-pel samples of the 4 pixels in dword d1 (d0 / d2: the dwords left / right)
+// horizontal half-pel samples of the 4 pixels in dword d1 (d0 / d2: the dwords left / right; all
+// three ^ 0x80808080)
 __device__ __forceinline__ void
 mas8_row4 (uint32_t d0, uint32_t d1, uint32_t d2, int *out)
 {
@@ -147,8 +148,11 @@ mas8_row4 (uint32_t d0, uint32_t d1, uint32_t d2, int *out)
 __global__ __launch_bounds__ (kThreads)
 void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
 {
-  __shared__ uint32_t s0[kUpTH + 7][kUpDW];     // integer pels, rows y0-3 .. y0+TH+3
-  __shared__ uint32_t s2[kUpTH][kUpDW];         // v-half
+  // LDS rows: dword i holds pixels x0 - 16 + 4 i .. + 3, so that 16-byte source chunks land
+  // aligned; the filters use dwords 3 .. 36 (pixels x0 - 4 .. x0 + TW + 3)
+  constexpr int kUpLD = kUpTW / 4 + 8, kUpCh = kUpLD / 4;
+  __shared__ __attribute__ ((aligned (16))) uint32_t s0[kUpTH + 7][kUpLD];     // integer pels, rows y0-3 .. y0+TH+3
+  __shared__ __attribute__ ((aligned (16))) uint32_t s2[kUpTH][kUpLD];         // v-half
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
@@ -157,28 +161,30 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   const int x0 = tx * kUpTW, y0 = ty * kUpTH;
   const int w = job.w, h = job.h;
   const int tid = threadIdx.x;
-  const bool src_al = ((((uintptr_t) job.src) | job.src_stride) & 3) == 0;
+  const bool src_al = ((((uintptr_t) job.src) | job.src_stride) & 15) == 0;
 
-  for (int it = tid; it < (kUpTH + 7) * kUpDW; it += kThreads) {
-    const int g = it % kUpDW, ly = it / kUpDW;
+  // one 16-byte chunk per lane (230 of them): picture coordinates clamped on the way in
+  for (int it = tid; it < (kUpTH + 7) * kUpCh; it += kThreads) {
+    const int ly = it / kUpCh, c = it - ly * kUpCh;
     const int gy = clampi (y0 - 3 + ly, 0, h - 1);
-    const int gx = x0 - 4 + 4 * g;
+    const int gx = x0 - 16 + 16 * c;
     const uint8_t *row = job.src + (size_t) gy * job.src_stride;
-    uint32_t d;
-    if (src_al && gx >= 0 && gx + 4 <= w) {
-      d = gload < uint32_t > (row + gx);
+    u32x4 q;
+    if (src_al && gx >= 0 && gx + 16 <= w) {
+      q = gload < u32x4 > (row + gx);
     } else {
-      d = 0;
+      uint32_t d[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        d |= (uint32_t) gload < uint8_t > (row + clampi (gx + k, 0, w - 1)) << (8 * k);
+      for (int k = 0; k < 16; k++)
+        d[k >> 2] |= (uint32_t) gload < uint8_t > (row + clampi (gx + k, 0, w - 1)) << (8 * (k & 3));
+      q = (u32x4) { d[0], d[1], d[2], d[3] };
     }
-    s0[ly][g] = d;
+    *reinterpret_cast < u32x4 * >(&s0[ly][4 * c]) = q;
   }
   __syncthreads ();
 
   for (int it = tid; it < kUpTH * kUpDW; it += kThreads) {
-    const int g = it % kUpDW, ly = it / kUpDW;
+    const int g = it % kUpDW + 3, ly = it / kUpDW;
     uint32_t out;
     if (y0 + ly >= h - 1) {
       out = s0[ly + 3][g];      // last row of the v-half is a copy (schroframe.c:1642-1644)
@@ -191,8 +197,7 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
         hi[k] = hi_pair (d);
       }
       const short2v a = mas8_pk (lo), b = mas8_pk (hi);
-      out = (uint32_t) (uint16_t) a.x | ((uint32_t) (uint16_t) a.y << 8)
-          | ((uint32_t) (uint16_t) b.x << 16) | ((uint32_t) (uint16_t) b.y << 24);
+      out = __builtin_amdgcn_perm (__builtin_bit_cast (uint32_t, b), __builtin_bit_cast (uint32_t, a), 0x06040200u);
     }
     s2[ly][g] = out;
   }
@@ -207,34 +212,44 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   const int gx = x0 + 8 * g8, gy = y0 + ly;
   if (gx >= w || gy >= h)
     return;
-  const int gd = 2 * g8;                // LDS dword of the 4 pixels left of this lane's
+  const int gd = 2 * g8 + 3;            // LDS dword of the 4 pixels left of this lane's
   uint32_t c0[2], c2[2], d1[2], d3[2];
   {
     const uint32_t a0 = s0[ly + 3][gd], a1 = s0[ly + 3][gd + 1], a2 = s0[ly + 3][gd + 2], a3 = s0[ly + 3][gd + 3];
     const uint32_t b0 = s2[ly][gd], b1 = s2[ly][gd + 1], b2 = s2[ly][gd + 2], b3 = s2[ly][gd + 3];
+    constexpr uint32_t kS = 0x80808080u;        // pixels as signed bytes for the dot products
     int p1[8], p3[8];
-    mas8_row4 (a0, a1, a2, p1);
-    mas8_row4 (a1, a2, a3, p1 + 4);
-    mas8_row4 (b0, b1, b2, p3);
-    mas8_row4 (b1, b2, b3, p3 + 4);
+    mas8_row4 (a0 ^ kS, a1 ^ kS, a2 ^ kS, p1);
+    mas8_row4 (a1 ^ kS, a2 ^ kS, a3 ^ kS, p1 + 4);
+    mas8_row4 (b0 ^ kS, b1 ^ kS, b2 ^ kS, p3);
+    mas8_row4 (b1 ^ kS, b2 ^ kS, b3 ^ kS, p3 + 4);
     c0[0] = a1;
     c0[1] = a2;
     c2[0] = b1;
     c2[1] = b2;
+    // the tile holds the picture's last column or row (a whole-workgroup branch): copies there
+    const bool edge_tile = x0 + kUpTW >= w || y0 + kUpTH >= h;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      d1[half] = d3[half] = 0;
+      if (edge_tile) {
+        d1[half] = d3[half] = 0;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
-        // schro_frame_mc_edgeextend_horiz overwrites it the same way)
-        const bool lastcol = gx + 4 * half + e >= w - 1;
-        int v1 = lastcol ? (int) ((c0[half] >> (8 * e)) & 0xff) : p1[4 * half + e];
-        int v3 = lastcol ? (int) ((c2[half] >> (8 * e)) & 0xff) : p3[4 * half + e];
-        if (gy >= h - 1)
-          v3 = v1;              // last row of the hv-half comes from the h-half (schroframe.c:2028)
-        d1[half] |= (uint32_t) v1 << (8 * e);
-        d3[half] |= (uint32_t) v3 << (8 * e);
+        for (int e = 0; e < 4; e++) {
+          // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
+          // schro_frame_mc_edgeextend_horiz overwrites it the same way)
+          const bool lastcol = gx + 4 * half + e >= w - 1;
+          int v1 = lastcol ? (int) ((c0[half] >> (8 * e)) & 0xff) : p1[4 * half + e];
+          int v3 = lastcol ? (int) ((c2[half] >> (8 * e)) & 0xff) : p3[4 * half + e];
+          if (gy >= h - 1)
+            v3 = v1;            // last row of the hv-half comes from the h-half (schroframe.c:2028)
+          d1[half] |= (uint32_t) v1 << (8 * e);
+          d3[half] |= (uint32_t) v3 << (8 * e);
+        }
+      } else {
+        d1[half] = (uint32_t) p1[4 * half] | ((uint32_t) p1[4 * half + 1] << 8) | ((uint32_t) p1[4 * half + 2] << 16)
+            | ((uint32_t) p1[4 * half + 3] << 24);
+        d3[half] = (uint32_t) p3[4 * half] | ((uint32_t) p3[4 * half + 1] << 8) | ((uint32_t) p3[4 * half + 2] << 16)
+            | ((uint32_t) p3[4 * half + 3] << 24);
       }
     }
   }
