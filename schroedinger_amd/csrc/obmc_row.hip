@@ -36,13 +36,13 @@ namespace schro {
 namespace {
 
 constexpr int kRThreads = 256;
-constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1)
+constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1); the kernels take the height as TH
 constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
 constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
 // blocks whose footprint meets a tile and their (block, row) items: by row length (8-pixel rows
 // and shorter are the small, many blocks of chroma planes and of the 8/4 block set)
 template < int ND > struct RowCaps {
-  static constexpr int kBlk = ND <= 2 ? 384 : 128, kItem = ND <= 2 ? 2048 : 1024;
+  static constexpr int kBlk = ND <= 2 ? 352 : 128, kItem = ND <= 2 ? 1792 : 1024;
 };
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
 constexpr int kRCls = 8;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 edge, 7 rim
@@ -56,15 +56,36 @@ constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
 
-struct __attribute__ ((aligned (16))) RowBlk {
+struct __attribute__ ((aligned (8))) RowBlk {
   int16_t y, x;                 // block origin relative to the tile
-  int dc_b;                     // DC value of the job's second plane
-  int mode_dc;                  // bits 0-1 mode, bits 8..: DC value (first plane)
+  int dcs;                      // DC values of the job's planes, 16 bits each (first plane low)
+  int flags;                    // bits 0-1 mode, 2-5 weights fold at top | bottom | left | right,
+                                // 6 + 2 r: reference r's window at a horizontal half position, 7 + 2 r: at a vertical one
   int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
-  int off[2];                   // offset of the window's first 16-byte chunk in its tile row (rim: fx, fy of ref 0)
-  uint32_t rxm[2];              // bits 1..: all ones when the window sits at a horizontal half position,
-                                // bit 0: at a vertical one (rim: fx, fy of ref 1)
+  int off[2];                   // offset of the window's first 16-byte chunk in its tile row; edge class: first
+                                // sample row << 17 | chunk offset; rim: fx | fy << 16 of reference r
 };
+static_assert (sizeof (RowBlk) == 24, "24-byte block records: 384 of them beside the accumulator, six chroma workgroups per CU");
+
+// all ones when reference r's window sits at a horizontal half position (v_bfe_i32)
+__device__ __forceinline__ uint32_t
+blk_rx_mask (const RowBlk & hb, int r)
+{
+  return (uint32_t) ((int32_t) ((uint32_t) hb.flags << (25 - 2 * r)) >> 31);
+}
+
+__device__ __forceinline__ uint32_t
+blk_ry (const RowBlk & hb, int r)
+{
+  return ((uint32_t) hb.flags >> (7 + 2 * r)) & 1u;
+}
+
+__device__ __forceinline__ int
+blk_dc (const RowBlk & hb, int pl)
+{
+  return pl ? hb.dcs >> 16 : (int) (int16_t) hb.dcs;
+}
+
 
 // obmc_weight_1d (obmc_common.h; schromotion.c:40-69) with get_ramp's division by
 // 2 * offset - 1 done as a multiplication (m = ceil (2^32 / (2 * offset - 1)), from the host)
@@ -224,20 +245,19 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   const RowBlk & hb = s_hot[e & 0x1ff];
   const int row = e >> 9;
   uint32_t p[ND];
-  auto rx_mask = [] (uint32_t f) { return (uint32_t) ((int32_t) f >> 1); };       // bits 1.. smeared over the word
   if constexpr (CLS == 5) {
 #pragma unroll
     for (int k = 0; k < ND; k++)
-      p[k] = (uint32_t) (pl ? hb.dc_b : hb.mode_dc >> 8) * 0x01010101u;
+      p[k] = (uint32_t) blk_dc (hb, pl) * 0x01010101u;
   } else if constexpr (CLS == kREdge) {
     // any mode: both references are read (an unused one at offset 0) and the mode selects
     uint32_t p1[ND];
     const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-    predict_row < ND, true, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
+    predict_row < ND, true, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, blk_rx_mask (hb, 0), blk_ry (hb, 0), p);
     __builtin_amdgcn_sched_barrier (0);
-    predict_row < ND, true, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
-    const uint32_t mode = (uint32_t) hb.mode_dc & 3u;
-    const uint32_t dc = (uint32_t) ((pl ? hb.dc_b : hb.mode_dc >> 8) & 0xff) * 0x01010101u;
+    predict_row < ND, true, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, blk_rx_mask (hb, 1), blk_ry (hb, 1), p1);
+    const uint32_t mode = (uint32_t) hb.flags & 3u;
+    const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int k = 0; k < ND; k++) {
@@ -247,9 +267,9 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   } else if constexpr (CLS == 0) {
     uint32_t p1[ND];
     const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-    predict_row < ND, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, rx_mask (hb.rxm[0]), hb.rxm[0] & 1u, p);
+    predict_row < ND, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, blk_rx_mask (hb, 0), blk_ry (hb, 0), p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight
-    predict_row < ND, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, rx_mask (hb.rxm[1]), hb.rxm[1] & 1u, p1);
+    predict_row < ND, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, blk_rx_mask (hb, 1), blk_ry (hb, 1), p1);
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
@@ -257,7 +277,7 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
     constexpr int r = CLS >= 3 ? 1 : 0;
     constexpr bool RY = CLS == 2 || CLS == 4;
     const uint32_t ph = ((uint32_t) hb.rows >> (16 + 8 * r)) & 0xffu;
-    predict_row < ND, RY > (job, r ? ref1 : ref0, job.ref_stride[r], hb.off[r], ph, row, rx_mask (hb.rxm[r]), 1u, p);
+    predict_row < ND, RY > (job, r ? ref1 : ref0, job.ref_stride[r], hb.off[r], ph, row, blk_rx_mask (hb, r), 1u, p);
   }
   if (st) {
     asm volatile ("" :: "v" (p[0]));
@@ -272,7 +292,7 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   if constexpr (CLS == kREdge) {
     // weights folded at the picture's rim (schromotion8.c:673-693): 1-D tables per edge type behind
     // the plain products -- (left | right << 1) pairs of x weights, (top | bottom << 1) y weights
-    const uint32_t fb = ((uint32_t) hb.mode_dc >> 2) & 15u;
+    const uint32_t fb = ((uint32_t) hb.flags >> 2) & 15u;
     const uint32_t *wxf = s_wp + kRWCap + 8 * (fb >> 2), *wyf = s_wp + kRWCap + 32 + 32 * (fb & 3u);
     const uint32_t wy2 = wyf[row] * 0x00010001u;
 #pragma unroll
@@ -418,17 +438,21 @@ row_finish_is_fast (const ObmcJob & job, const PlaneIO & io, int x_lo, int x_hi)
 }
 
 // the fast finish's residual: 8 pixels of two rows per lane, fetched before the tile's last barrier
+template < int TH > constexpr int kRFinishRounds = (TH * (kRTW / 8) + kRThreads - 1) / kRThreads;
+
+template < int TH >
 __device__ __forceinline__ void
 row_finish_prefetch (const PlaneIO & io, int tid, int x_lo, int y_lo, int y_hi, u32x4 * res)
 {
 #pragma unroll
-  for (int n = 0; n < kRTH * (kRTW / 8) / kRThreads; n++) {
+  for (int n = 0; n < kRFinishRounds < TH >; n++) {
     const int it = tid + n * kRThreads, g = it & (kRTW / 8 - 1), y = y_lo + (it >> 4);
-    if (y < y_hi)
+    if (y < y_hi && it < TH * (kRTW / 8))
       res[n] = gload < u32x4 > ((const char *) io.residual + (size_t) y * io.residual_stride + 2 * (x_lo + 8 * g));
   }
 }
 
+template < int TH >
 __device__ __forceinline__ void
 row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, int tid, int x_lo, int y_lo,
     int x_hi, int y_hi, bool fast, const u32x4 * res)
@@ -436,12 +460,12 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
   if (fast) {
     // one lane: 8 pixels of one row, packed 16-bit arithmetic (the reference's adds wrap at 16 bits)
 #pragma unroll
-    for (int n = 0; n < kRTH * (kRTW / 8) / kRThreads; n++) {
+    for (int n = 0; n < kRFinishRounds < TH >; n++) {
       const int it = tid + n * kRThreads;
       const int g = it & (kRTW / 8 - 1), yy = it >> 4;
-      static_assert (kRTW / 8 == 16 && (kRTH * (kRTW / 8)) % kRThreads == 0, "8-pixel groups per tile row");
+      static_assert (kRTW / 8 == 16, "8-pixel groups per tile row");
       const int y = y_lo + yy;
-      if (y >= y_hi)
+      if (y >= y_hi || it >= TH * (kRTW / 8))
         continue;
       const uint32_t *ap = acc + yy * kRAccW + (kRMargin / 2 + 4 * g);
       uint32_t av[4];
@@ -478,7 +502,7 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
     return;
   }
   // orc_rrshift6_add_s16_2d / _s32_2d on one pixel per lane and step
-  for (int it = tid; it < kRTH * kRTW; it += kRThreads) {
+  for (int it = tid; it < TH * kRTW; it += kRThreads) {
     const int xx = it & (kRTW - 1), yy = it >> 7;
     static_assert (kRTW == 128, "tile row = 128 pixels");
     const int x = x_lo + xx, y = y_lo + yy;
@@ -497,11 +521,11 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
   }
 }
 
-template < int ND, int NP >
+template < int ND, int NP, int TH = kRTH >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  __shared__ __attribute__ ((aligned (16))) uint32_t acc[kRTH * kRAccW];
+  __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * kRAccW];
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
   constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
@@ -522,12 +546,12 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
   const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x;
-  const int x_lo = tx * kRTW, y_lo = ty * kRTH;
-  const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + kRTH, job.h);
+  const int x_lo = tx * kRTW, y_lo = ty * TH;
+  const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
-  static_assert ((kRTH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
-  for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
+  static_assert ((TH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
+  for (int it = tid; it < TH * kRAccW / 4; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
   if (tid < job.xblen)
     s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
@@ -618,8 +642,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         return interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
       };
       const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
-      info.dc_b = pdc_b;
-      info.mode_dc = mode | (pdc << 8);
+      info.dcs = (int) (((uint32_t) pdc & 0xffffu) | ((uint32_t) pdc_b << 16));
+      info.flags = mode;
       int phases = 0, ry[2] = { 0, 0 }, off_abs[2] = { 0, 0 };
       bool clamped_h = false, clamped_v = false;
 #pragma unroll
@@ -648,7 +672,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
         off_abs[r] = in_h && used ? (int) (((uint32_t) gy0 << 17) | (uint32_t) ((gx0 & ~15) << 3)) : 0;
         phases |= in_h ? ((inside ? gy0 & 15 : 0) | ((gx0 & 15) << 4)) << (8 * r) : 0;
-        info.rxm[r] = (rx ? 0xfffffffeu : 0u) | (ry[r] ? 1u : 0u);
+        info.flags |= ((rx ? 1 : 0) | (ry[r] ? 2 : 0)) << (6 + 2 * r);
       }
       const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
       info.rows = ra | ((rb - ra) << 8) | (phases << 16);
@@ -661,20 +685,19 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       if (clamped_h || wide_dc || yblen * 2 * ND > kRWCap || xblen > 16) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
+        // (16 bits each: obmc_row_nd keeps planes whose origins do not fit away from this kernel)
         int fx, fy;
         mv_origin (job, bx, by, v01, v23, 0, &fx, &fy);
-        info.off[0] = fx;
-        info.off[1] = fy;
+        info.off[0] = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
         mv_origin (job, bx, by, v01, v23, 1, &fx, &fy);
-        info.rxm[0] = (uint32_t) fx;
-        info.rxm[1] = (uint32_t) fy;
+        info.off[1] = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
         s_rim[atomicAdd (&s_nrim, 1)] = (uint16_t) blk;
       } else if (fold || clamped_v) {
         // still a row per lane: sample rows clamped one by one, weights from the folded tables
         key = kREdge;
         info.off[0] = off_abs[0];
         info.off[1] = off_abs[1];
-        info.mode_dc |= fold << 2;
+        info.flags |= fold << 2;
       } else if (mode == 3) {
         key = 0;
       } else if (mode == 0) {
@@ -731,10 +754,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #endif
     constexpr bool kEarlyRes = SCHRO_ROW_EARLY_RES != 0 && (SCHRO_ROW_EARLY_RES > 1 || (ND >= 3 && NP == 1));
     const bool fast = row_finish_is_fast (job, io, x_lo, x_hi);
-    u32x4 res[kRTH * (kRTW / 8) / kRThreads];
+    u32x4 res[kRFinishRounds < TH >];
     if constexpr (kEarlyRes) {
       if (fast)
-        row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+        row_finish_prefetch < TH > (io, tid, x_lo, y_lo, y_hi, res);
       __builtin_amdgcn_sched_barrier (0);
     }
     int turn = 0;
@@ -762,8 +785,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         const int y = by + r2, xs = bx + 4 * s2;
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
-        const int fx[2] = { hb.off[0], (int) hb.rxm[0] }, fy[2] = { hb.off[1], (int) hb.rxm[1] };
-        const int md = pl ? (hb.mode_dc & 3) | (hb.dc_b << 8) : hb.mode_dc;
+        const int fx[2] = { (int) (int16_t) hb.off[0], (int) (int16_t) hb.off[1] }, fy[2] = { hb.off[0] >> 16, hb.off[1] >> 16 };
+        const int md = (hb.flags & 3) | (blk_dc (hb, pl) << 8);
         if (job.prec == 1)
           row_slow < 1 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
         else
@@ -773,14 +796,14 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     RSTAMP (5);
     if constexpr (!kEarlyRes) {
       if (fast)
-        row_finish_prefetch (io, tid, x_lo, y_lo, y_hi, res);
+        row_finish_prefetch < TH > (io, tid, x_lo, y_lo, y_hi, res);
     }
     __syncthreads ();
     RSTAMP (6);
-    row_finish (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+    row_finish < TH > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
     if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
       __syncthreads ();
-      for (int it = tid; it < kRTH * kRAccW / 4; it += kRThreads)
+      for (int it = tid; it < TH * kRAccW / 4; it += kRThreads)
         reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
       __syncthreads ();
     }
@@ -800,13 +823,13 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // 2 0.093, 3 0.130, 4 0.157, 5 0.171, 6 0.186).  The 12-pixel row fits 80 registers since the
 // class loops run on scalar registers: six waves per SIMD for luma (19 KB of LDS); 30 KB of LDS
 // hold the 6-pixel-row kernels (chroma) to five.
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 1 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 2, 2 > (jobs, njobs, order);
@@ -869,6 +892,9 @@ int
 obmc_row_nd (const ObmcJob & j)
 {
   if (j.prec < 1 || j.prec > 2 || j.xblen > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
+    return 0;
+  // rim blocks keep their clamped fetch origins (get_block: at most (size + 32) << prec) in 16 bits
+  if (((std::max (j.w, j.h) + 32) << j.prec) > 32767)
     return 0;
   // the blocks that can meet a 128x32 tile and their rows inside it fit the kernel's tables
   const int nbi = (kRTW - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
