@@ -690,7 +690,14 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       nl = 0;
   }
 
-  std::vector < IwtJob > jobs, rjobs;
+  // s32 Haar levels (the low-delay 10-bit configurations): the element-wise form of iiwt_haar.hip
+  const bool use_haar = iiwt_haar_supported (filter, bpp)
+      && !(getenv ("SCHRO_HIP_IIWT_HAAR") && atoi (getenv ("SCHRO_HIP_IIWT_HAAR")) == 0);
+  int hcols = 1, hrows = 1;
+  if (use_haar)
+    iiwt_haar_geometry (&hcols, &hrows);
+
+  std::vector < IwtJob > jobs, rjobs, hjobs;
   for (int level = depth - 1; level >= 0; level--) {
     if (nl && level >= fb && level < fb + nl) {
       if (level == fb + nl - 1) {
@@ -700,9 +707,10 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       }
       continue;
     }
-    int tile_base = 0, rtile_base = 0;
+    int tile_base = 0, rtile_base = 0, htile_base = 0;
     jobs.clear ();
     rjobs.clear ();
+    hjobs.clear ();
     // a level of fewer register tiles than the chip has SIMDs twice over is latency, not
     // bandwidth: use the small form (4 useful row pairs per wave)
     int lruc = ruc, lrur = rur, lrmin = rmin, small = 0;
@@ -754,7 +762,12 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
       j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
       j.pad = 0;
-      if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= lrmin) {
+      if (use_haar && iiwt_haar_job_ok (j)) {
+        j.tiles_x = div_up (nc, hcols);
+        j.tile_base = htile_base;
+        htile_base += j.tiles_x * div_up (nr, hrows);
+        hjobs.push_back (j);
+      } else if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= lrmin) {
         j.tiles_x = div_up (nc, lruc);
         j.tile_base = rtile_base;
         rtile_base += j.tiles_x * div_up (nr, lrur);
@@ -766,10 +779,12 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         jobs.push_back (j);
       }
     }
-    void *d_rjobs = nullptr, *d_jobs = nullptr;
+    void *d_rjobs = nullptr, *d_jobs = nullptr, *d_hjobs = nullptr;
     int r = 0;
     if (!rjobs.empty ())
       r = push_args (ctx, rjobs.data (), sizeof (IwtJob) * rjobs.size (), &d_rjobs);
+    if (!r && !hjobs.empty ())
+      r = push_args (ctx, hjobs.data (), sizeof (IwtJob) * hjobs.size (), &d_hjobs);
     if (!r && !jobs.empty ())
       r = push_args (ctx, jobs.data (), sizeof (IwtJob) * jobs.size (), &d_jobs);
     if (r)
@@ -777,6 +792,8 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
     if (d_rjobs)
       r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter, small);
+    if (!r && d_hjobs)
+      r = launch_iiwt_haar (ctx->stream, (const IwtJob *) d_hjobs, (int) hjobs.size (), htile_base, filter);
     if (!r && d_jobs)
       r = launch_iiwt_level (ctx->stream, (const IwtJob *) d_jobs, (int) jobs.size (), tile_base, filter, bpp);
     if (r)

@@ -278,6 +278,11 @@ void iiwt_fused_job_fill (void *job, const void *src, int src_stride, int bpp, i
     int tile_base);
 int launch_iiwt_fused (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles,
     int filter, int bpp, int nl);
+// element-wise s32 Haar level (iiwt_haar.hip)
+bool iiwt_haar_supported (int filter, int bpp);
+bool iiwt_haar_job_ok (const IwtJob & j);
+void iiwt_haar_geometry (int *cols, int *rows);
+int launch_iiwt_haar (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter);
 // register form of one level (iiwt_reg.hip): s16, filters with a small lifting halo
 bool iiwt_reg_supported (int filter, int bpp);
 void iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pairs,
