@@ -52,6 +52,22 @@ def test_upsample_extremes(ctx):
         check_planes(gpu_upsample(ctx, pic), O.UpComp(pic))
 
 
+def test_upsample_unaligned_sources(ctx):
+    # The kernel stages 16-byte source chunks; a component that is a window of a larger
+    # plane (any byte offset, the parent's pitch) takes the byte-by-byte gather instead.
+    import schroedinger_amd as sa
+    big = synth.picture_u8(70, 200, seed=11, blur=False)
+    parent = ctx.upload(big)
+    for (y0, x0, h, w) in [(0, 1, 20, 40), (3, 5, 33, 130), (7, 16, 16, 128), (1, 67, 9, 131), (2, 3, 1, 1)]:
+        pic = np.ascontiguousarray(big[y0:y0 + h, x0:x0 + w])
+        src = sa.SubPlane(parent, y0, x0, h, w)
+        dst = ctx.hp_plane(h, w).fill(0x5a)
+        ctx.upsample_batch([(src, dst)])
+        check_planes(dst.download(), O.UpComp(pic))
+        dst.free()
+    parent.free()
+
+
 @pytest.mark.parametrize("dtype", [np.int16, np.int32])
 def test_convert_crop_and_saturate(ctx, dtype):
     # iwt-padded 64x48 source, 61x45 picture: crop as schrovirtframe.c:1853 does
