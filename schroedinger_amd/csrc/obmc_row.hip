@@ -3,8 +3,9 @@
 //
 // Same arithmetic and the same outer structure as obmc.hip's item kernel (a 256-thread
 // workgroup owns a 128x32 output tile and a 16-bit accumulator tile in LDS; blocks are decoded
-// once per tile, sorted by class, expanded into (block, row) items; picture-rim blocks take the
-// exact per-sample path; finish = round, add the residual, clamp, store) -- what changes is the
+// once per tile, sorted by class, expanded into (block, row) items; blocks whose windows leave the
+// image horizontally take the exact per-sample path; finish = round, add the residual, clamp,
+// store) -- what changes is the
 // hot loop, which r01's counters showed to be instruction issue (156 M VALU wave-instructions
 // per 8 x 2160p, ~100 lane-operations per output sample):
 //
@@ -12,8 +13,8 @@
 //     one address computation, one weight-table read per row instead of three;
 //   * the lane loads its own row's 16-byte tile rows (adjacent lanes = adjacent rows of a
 //     block = sample rows of one parity = the same 128-byte line of the tiled half-pel image:
-//     one TA cycle per 4 lanes) straight into registers and aligns them there (a two-level select by the
-//     window's dword phase + v_alignbyte) -- no LDS staging buffer, which frees 11 KB of LDS;
+//     one TA cycle per 4 lanes) with buffer loads straight into registers and aligns them there (a
+//     two-level select by the window's dword phase + v_alignbyte) -- no LDS staging buffer;
 //   * prediction is byte-parallel: at half / quarter pel orc_combine4_nxm_u8
 //     (schroorc.orc:1635-1662) degenerates to copy / 2-sample / 4-sample rounding averages,
 //     v_lerp_u8 on four pixels per instruction (exact, see avg4); the horizontal phase is a
@@ -820,9 +821,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 
 // Waves per SIMD: as many workgroups per CU as fit -- throughput grows with every resident
 // workgroup until vector issue saturates (luma, workgroups per CU -> tiles per 1000 cycles per CU:
-// 2 0.093, 3 0.130, 4 0.157, 5 0.171, 6 0.186).  The 12-pixel row fits 80 registers since the
-// class loops run on scalar registers: six waves per SIMD for luma (19 KB of LDS); 30 KB of LDS
-// hold the 6-pixel-row kernels (chroma) to five.
+// 2 0.093, 3 0.130, 4 0.157, 5 0.171, 6 0.186; seven need 72 registers and spill).  The 12-pixel
+// row fits 80 registers since the class loops run on scalar registers: six waves per SIMD for luma
+// (18.6 KB of LDS) and, with 24-byte block records and tables of 352 blocks / 1792 items
+// (26.4 KB), for the 6-pixel-row kernels (chroma) too.
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
