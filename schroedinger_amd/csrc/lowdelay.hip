@@ -12,6 +12,7 @@
 #include "schro_hip_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace schro {
 
@@ -227,8 +228,13 @@ void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
           | (uintptr_t) job.stride[0] | (uintptr_t) job.stride[1] | (uintptr_t) job.stride[2]) & 15) == 0;
   const int nsub = 1 + 3 * P.depth;
   BitReader b = yb;             // (one reader in registers: a reference to either would live in scratch)
+  // The luma codes and the (interleaved) chroma codes of a slice are two bit strings whose start
+  // positions the slice header gives: with two workgroups per 64 slices (gridDim.z == 2) one
+  // decodes the luma strings and the other the chroma strings -- twice the waves, half the serial
+  // chain per lane (256 instead of 512 codes for 32x8 slices of 4:2:2).
+  const int k_first = gridDim.z == 2 ? (int) blockIdx.z : 0, k_last = gridDim.z == 2 ? (int) blockIdx.z : 1;
 #pragma unroll 1
-  for (int k = 0; k < 2; k++) {
+  for (int k = k_first; k <= k_last; k++) {
     if (k)
       b = uvb;
     const int iwt_w = k ? P.iwt_cw : P.iwt_lw, iwt_h = k ? P.iwt_ch : P.iwt_lh;
@@ -600,7 +606,9 @@ void dc_predict_kernel (const DcJob * __restrict__ jobs)
 int
 launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith)
 {
-  const dim3 grid ((unsigned) ((P.nh * P.nv + 63) / 64), (unsigned) njobs);
+  // (SCHRO_HIP_SLICE_SPLIT=0: one workgroup decodes both strings of its slices)
+  static const bool split = !getenv ("SCHRO_HIP_SLICE_SPLIT") || atoi (getenv ("SCHRO_HIP_SLICE_SPLIT")) != 0;
+  const dim3 grid ((unsigned) ((P.nh * P.nv + 63) / 64), (unsigned) njobs, split ? 2u : 1u);
   if (bpp == 4)
     hipLaunchKernelGGL ((slice_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), 0, stream, d_jobs, P);
   else if (arith == SCHRO_HIP_LOWDELAY_FAST16)
