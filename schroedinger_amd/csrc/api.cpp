@@ -1348,7 +1348,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
 {
   *d_order = nullptr;
   static const bool enabled = !getenv ("SCHRO_HIP_OBMC_ORDER") || atoi (getenv ("SCHRO_HIP_OBMC_ORDER")) != 0;
-  if (!enabled || variant < 1 || jobs.size () < 2 || jobs.size () > 0xffff)
+  if (!enabled || variant < 1 || jobs.empty () || jobs.size () > 0xffff)
     return 0;
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h] (uint64_t v) {
