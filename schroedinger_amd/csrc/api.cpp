@@ -250,6 +250,10 @@ schro_hip_context_new (int device)
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
   }
+  {
+    hipDeviceProp_t prop;
+    ctx->cus = hipGetDeviceProperties (&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
   ctx->cur = 0;
   memset (ctx->marks, 0, sizeof (ctx->marks));
   ctx->arg_clock = 0;
@@ -1254,12 +1258,13 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
 // is never drained here.
 // scratch runs only: SCHRO_HIP_OBMC_STAMPS=1 gives the staged kernel a buffer for per-phase
 // cycle stamps; schro_hip_obmc_stamps_dump () prints their medians
-// SCHRO_HIP_OBMC_MERGE=0: every plane its own job in the row kernel (A/B runs)
-static bool
-obmc_row_merge_enabled ()
+// SCHRO_HIP_OBMC_MERGE=0: every plane its own job in the row kernel (A/B runs); 2: pairs always
+static int
+obmc_row_merge_mode ()
 {
-  static const bool on = !getenv ("SCHRO_HIP_OBMC_MERGE") || atoi (getenv ("SCHRO_HIP_OBMC_MERGE")) != 0;
-  return on;
+  // 0: never, 1: where it pays (default), 2: always (the tests run the pair kernels on small pictures)
+  static const int mode = getenv ("SCHRO_HIP_OBMC_MERGE") ? atoi (getenv ("SCHRO_HIP_OBMC_MERGE")) : 1;
+  return mode;
 }
 
 static unsigned long long *g_stamps;
@@ -1561,9 +1566,17 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   }
   // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
   // ONE job whose tile workgroups decode the blocks once; such pairs form their own launch
-  for (int p = 0; p + 1 < nplanes; p++) {
+  // -- unless the batch is so small that the planes' tiles, one workgroup each, still fit the
+  // device's slots at once (six per CU): then a pair's workgroup only runs twice as long (one
+  // 2160p picture: 510 pair tiles against 1536 slots)
+  long pair_tiles = 0;
+  for (int p = 0; p < nplanes; p++)
+    if (row_nd[p] && all[p].comp != 0)
+      pair_tiles += (long) ((all[p].w + 127) / 128) * ((all[p].h + 31) / 32);
+  const bool pairs_pay = obmc_row_merge_mode () == 2 || (obmc_row_merge_mode () == 1 && pair_tiles > 6L * ctx->cus);
+  for (int p = 0; pairs_pay && p + 1 < nplanes; p++) {
     const ObmcJob & a = all[p], &b = all[p + 1];
-    if (row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && obmc_row_merge_enabled () && a.comp == 1 && b.comp == 2
+    if (row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && a.comp == 1 && b.comp == 2
         && a.mvs == b.mvs && a.w == b.w && a.h == b.h && a.nbx == b.nbx && a.nby == b.nby && a.xblen == b.xblen
         && a.yblen == b.yblen && a.xbsep == b.xbsep && a.ybsep == b.ybsep && a.mv_shift_x == b.mv_shift_x
         && a.mv_shift_y == b.mv_shift_y && a.res_bpp == b.res_bpp && a.ref_stride[0] == b.ref_stride[0]

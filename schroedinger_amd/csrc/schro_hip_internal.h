@@ -398,6 +398,7 @@ struct SchroHipContext {
   void *scratch_q[kQueues];
   size_t scratch_size_q[kQueues];
   void *&scratch_ref () { return scratch_q[cur]; }
+  int cus;                      // compute units of the device (launch shaping)
 };
 
 namespace schro {

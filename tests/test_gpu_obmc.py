@@ -203,3 +203,19 @@ def test_staged_kernel_parity_in_a_child_process():
                         "test_default_weights or test_dc_values or test_rotating"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_pair_kernels_parity_in_a_child_process():
+    # A U + V pair runs as one job (obmc_row_kernel_*_2) only where the batch has more tiles than
+    # the device has workgroup slots; SCHRO_HIP_OBMC_MERGE=2 (read once per process) pairs always,
+    # so the default-weight matrix of this file -- all chroma formats, block sets, precisions, near
+    # and far vectors, DC values outside 8 bits, rotating references -- goes through those kernels
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SCHRO_HIP_OBMC_MERGE="2")
+    here = os.path.abspath(__file__)
+    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
+                        "test_default_weights or test_dc_values or test_rotating or test_ragged"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
