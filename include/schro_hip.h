@@ -311,41 +311,44 @@ int schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * 
 
 /* Half-pel upsampling of one u8 component; replaces
  * schro_upsampled_frame_upsample (schroframe.c:2000-2030) /
- * schro_upsampled_gpuframe_upsample.  Device layout of an upsampled
- * component is ONE interleaved image HP of 2*width x 2*height bytes:
- *   HP[2y][2x] = integer pel, HP[2y][2x+1] = h-half, HP[2y+1][2x] = v-half,
- *   HP[2y+1][2x+1] = hv-half  (the reference's planes 0,1,2,3).
- * No aprons are stored: the OBMC kernel clamps the half-pel coordinate to
- * [0, 2w-2] x [0, 2h-2], which is what the reference's 32-pixel aprons
- * materialise.
+ * schro_upsampled_gpuframe_upsample.  The device holds the reference's four planes of an
+ * upsampled component -- half-pel sample (X, Y), 0 <= X < 2 * width, 0 <= Y < 2 * height, lives in
+ *   plane (X & 1) + 2 * (Y & 1)   (0 integer pel, 1 h-half, 2 v-half, 3 hv-half)
+ * at column X >> 1, row Y >> 1 -- in ONE buffer, tiled for the OBMC gather (r03 layout):
  *
- * Memory layout of HP ("tiled"): OBMC gathers a 24-byte x 24-row window of HP per
- * 12x12 block and reference -- every second row of it, or all of them at a
- * vertical half position -- and on MI355X the cost of that gather is the number
- * of 128-byte cache lines it touches.  HP is therefore stored so that one line
- * holds 16 bytes of each of 8 rows OF ONE PARITY instead of 128 bytes of one row:
- * a band of 16 rows is two "tile rows" of 8 * stride bytes, rows 0,2,..,14 of the
- * band in the first and rows 1,3,..,15 in the second,
- *   offset (x, y) = ((y >> 4) * 2 + (y & 1)) * 8 * stride + (x >> 4) * 128
- *                   + ((y >> 1) & 7) * 16 + (x & 15)
- * with stride % 16 == 0 and the buffer holding round_up (2*height, 16) rows of
- * `stride` bytes (the same size as a linear image of that many rows).
- * schro_hip_upsampled_bytes () gives stride and size,
- * schro_hip_upsampled_download () copies an HP image to the host in linear
- * order.  Plain (not upsampled) frames are linear. */
+ *   - a plane row is cut into 32-byte chunks that advance by 16 columns, so every column is
+ *     stored twice and any run of up to 17 samples (one row of a block up to 16 wide, plus the
+ *     X + 1 tap) starts in some chunk and ends in the same one: a lane fetches it with one
+ *     byte-aligned load and needs no alignment or even / odd split instructions;
+ *   - one 128-byte cache line = the same chunk of 4 consecutive rows of one plane; the four
+ *     planes' lines of a (band of 4 rows, chunk) are adjacent, so the other taps of a quarter- or
+ *     eighth-pel position are +-128 / +-256 bytes away and a tap the position does not use is
+ *     never fetched;
+ *   - 32 replicated columns in front of column 0 and behind column width - 1 (get_block clamps a
+ *     block's origin to 32 pixels outside the picture, schromotion8.c:329-330), with the
+ *     reference's own apron sources (schroframe.c:2012-2029: planes 0 and 1 repeat plane 0's edge
+ *     sample, planes 2 and 3 plane 2's) = the half-pel column clamped to [0, 2 * width - 2]; rows
+ *     have no aprons, the kernels clamp the half-pel row to [0, 2 * height - 2].
+ *
+ *   offset (X, Y) = (y >> 2) * stride + (xp >> 4) * 512 + plane * 128 + (y & 3) * 32 + (xp & 15)
+ *   with y = Y >> 1, xp = (X >> 1) + 32; the second home of the column is 16 bytes into the chunk
+ *   before: offset - 512 + 16.  stride = bytes per band of 4 rows = 512 * ((width + 79) / 16 + 1);
+ *   the buffer holds ceil (height / 4) bands and must be 128-byte aligned.
+ * schro_hip_upsampled_bytes () gives stride and size, schro_hip_upsampled_download () copies the
+ * half-pel image to the host in linear order.  Plain (not upsampled) frames are linear. */
 typedef struct {
   const uint8_t *src;
   int src_stride;
-  uint8_t *dst;                 /* tiled, see above */
-  int dst_stride;               /* bytes, >= 2*width, multiple of 16 */
+  uint8_t *dst;                 /* the four tiled planes, see above */
+  int dst_stride;               /* bytes per band of 4 rows, from schro_hip_upsampled_bytes */
   int width;
   int height;
 } SchroHipUpsamplePlane;
 
-/* bytes to allocate for the HP image of a width x height component; *stride
- * receives its row pitch */
+/* bytes to allocate for the half-pel planes of a width x height component; *stride
+ * receives the band pitch */
 size_t schro_hip_upsampled_bytes (int width, int height, int *stride);
-/* HP image (2*width x 2*height bytes, tiled, on the device) -> linear host rows */
+/* half-pel planes (on the device) -> linear host rows of 2 * width samples, 2 * height of them */
 int schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride,
     const void *dev, int dev_stride, int width, int height);
 
@@ -362,7 +365,7 @@ int schro_hip_upsample_batch (SchroHipContext * ctx,
  * chroma_h_shift/chroma_v_shift when component > 0 exactly as
  * schromotion8.c:730-758 does.
  * ref1/ref2: mv_precision == 0 -> plain u8 planes (width x height);
- *            mv_precision >= 1 -> interleaved half-pel images (see above).
+ *            mv_precision >= 1 -> tiled half-pel planes (see above), strides = their band pitch.
  *            ref2 may be NULL when no block uses it. */
 typedef struct {
   const void *mvs;

@@ -70,7 +70,7 @@ class DevicePlane:
 
 class HpPlane(DevicePlane):
     """The half-pel (2x upsampled) image of a width x height u8 component: 2*height x
-    2*width samples in the tiled layout of include/schro_hip.h."""
+    2*width samples as the four tiled half-pel planes of include/schro_hip.h."""
 
     def __init__(self, ctx, height, width):
         self.ctx = ctx

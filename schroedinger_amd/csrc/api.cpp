@@ -980,29 +980,26 @@ schro_hip_upsampled_bytes (int width, int height, int *stride)
 {
   if (width <= 0 || height <= 0)
     return 0;
-  const size_t st = round_up ((size_t) width * 2, 64);
+  const size_t st = (size_t) hp_chunks (width) * 512;
   if (stride)
     *stride = (int) st;
-  return st * round_up ((size_t) height * 2, kHpBand);
+  return st * (size_t) div_up (height, kHpBandRows);
 }
 
 int
 schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride, const void *dev,
     int dev_stride, int width, int height)
 {
-  SCHRO_HIP_REQUIRE (ctx && host && dev && width > 0 && height > 0 && dev_stride >= 2 * width
-      && dev_stride % 16 == 0 && host_stride >= 2 * width, "upsampled_download: bad arguments");
+  SCHRO_HIP_REQUIRE (ctx && host && dev && width > 0 && height > 0 && dev_stride >= hp_chunks (width) * 512
+      && dev_stride % 512 == 0 && host_stride >= 2 * width, "upsampled_download: bad arguments");
   (void) hipSetDevice (ctx->device);
-  const size_t rows = round_up ((size_t) height * 2, kHpBand);
-  std::vector < uint8_t > raw ((size_t) dev_stride * rows);
+  std::vector < uint8_t > raw ((size_t) dev_stride * (size_t) div_up (height, kHpBandRows));
   SCHRO_HIP_CHECK (hipMemcpyAsync (raw.data (), dev, raw.size (), hipMemcpyDeviceToHost, ctx->stream));
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
   for (int y = 0; y < 2 * height; y++) {
     uint8_t *d = (uint8_t *) host + (size_t) y * host_stride;
-    for (int x = 0; x < 2 * width; x += 16) {
-      const int n = std::min (16, 2 * width - x);
-      memcpy (d + x, raw.data () + hp_offset (x, y, dev_stride), (size_t) n);
-    }
+    for (int x = 0; x < 2 * width; x++)
+      d[x] = raw[hp_offset (x, y, dev_stride)];
   }
   return 0;
 }
@@ -1219,8 +1216,9 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
   for (int p = 0; p < nplanes; p++) {
     const SchroHipUpsamplePlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0
-        && pl.dst_stride >= 2 * pl.width && pl.dst_stride % 16 == 0 && pl.src_stride >= pl.width,
-        "upsample_batch: plane %d invalid (the half-pel image needs a stride that is a multiple of 16)", p);
+        && pl.dst_stride >= hp_chunks (pl.width) * 512 && pl.dst_stride % 512 == 0 && pl.src_stride >= pl.width
+        && ((uintptr_t) pl.dst & 127) == 0,
+        "upsample_batch: plane %d invalid (half-pel image: 128-byte aligned, stride from schro_hip_upsampled_bytes)", p);
     UpsampleJob & j = jobs[p];
     j.src = pl.src;
     j.dst = pl.dst;
@@ -1489,14 +1487,9 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   auto variant_of = [](const SchroHipObmcPlane & pl) {
     return (pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1 && pl.picture_weight_bits == 1) ? 1 : 0;
   };
-  // SCHRO_HIP_OBMC_KERNEL=staged: default weights and half-pel references whose block geometry
-  // fits its tables run the LDS-staged kernel (obmc_stage.hip) instead of the item kernel.
-  // Bit-exact and far fewer instructions, but measured slower on 8 x 2160p (r02: luma 0.60 ms
-  // vs 0.275 ms): 77 KB of LDS per tile leave two workgroups per CU to hide a chain of seven
-  // barrier phases with two global round trips in it.
-  static const bool use_staged = getenv ("SCHRO_HIP_OBMC_KERNEL") && strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "staged") == 0;
-  // default for half- / quarter-pel references and blocks up to 16 wide: the row kernel
-  // (obmc_row.hip); SCHRO_HIP_OBMC_KERNEL=item keeps obmc.hip's item kernel for A/B runs
+  // default weights, half- / quarter-pel references and blocks up to 16 wide: the row kernel
+  // (obmc_row.hip); SCHRO_HIP_OBMC_KERNEL=item sends them to obmc.hip's item kernel (A/B runs: the
+  // second formulation the parity tests compare)
   static const bool use_row = !getenv ("SCHRO_HIP_OBMC_KERNEL") || strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
   std::vector < ObmcJob > all (nplanes);
   std::vector < int >key (nplanes), row_nd (nplanes);
@@ -1558,10 +1551,9 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     j.w = pl.width;
     j.h = pl.height;
     const int variant = variant_of (pl);
-    const int nd_staged = (variant == 1 && use_staged) ? obmc_stage_nd (j) : 0;
-    const int nd_row = (variant == 1 && use_row && !nd_staged) ? obmc_row_nd (j) : 0;
+    const int nd_row = (variant == 1 && use_row) ? obmc_row_nd (j) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
-    key[p] = pl.mv_precision | (variant << 4) | ((nd_staged ? nd_staged : nd_row) << 8) | (nd_row ? 1 << 16 : 0);
+    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0);
     row_nd[p] = nd_row;
   }
   // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
@@ -1598,7 +1590,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       for (int p = first; p < nplanes; p++)
         if (!done[p] && key[p] == key[first])
           nd = std::max (nd, row_nd[p]);
-    const int variant = nd ? (row ? 3 : 2) : ((key[first] >> 4) & 15);
+    const int variant = nd ? 3 : ((key[first] >> 4) & 15);
     const bool paired = (key[first] >> 17) & 1;
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
@@ -1642,7 +1634,6 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
       r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, paired ? 2 : 1, d_order)
-          : nd ? launch_obmc_stage (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, d_order)
           : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
     }
     if (r)
@@ -1722,10 +1713,13 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     c->height = k ? ch : height;
     c->h_shift = k ? h_shift : 0;
     c->v_shift = k ? v_shift : 0;
-    int mul = upsampled ? 2 : 1;
-    c->stride = (int) round_up ((size_t) c->width * mul * bpp, 64);
-    // half-pel images are tiled: whole bands of 16 rows
-    c->length = c->stride * (upsampled ? (int) round_up ((size_t) c->height * 2, kHpBand) : c->height);
+    c->stride = (int) round_up ((size_t) c->width * bpp, 64);
+    c->length = c->stride * c->height;
+    if (upsampled) {            // the four half-pel planes, tiled (include/schro_hip.h): stride = bytes per band of 4 rows
+      int st = 0;
+      c->length = (int) schro_hip_upsampled_bytes (c->width, c->height, &st);
+      c->stride = st;
+    }
     total += round_up ((size_t) c->length, 256);
   }
   void *base = schro_hip_domain_alloc (ctx, total);

@@ -203,17 +203,17 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   }
   __syncthreads ();
 
-  // Phase 3: horizontal half-pel samples, interleave, store.  One lane = 8 pixels of one row =
-  // the 16-byte tile row of HP row 2y (in the band's even tile row) and the one of row 2y + 1
-  // (same place in the odd tile row); the lanes of eight neighbouring rows are neighbours, so
-  // eight lanes write two whole 128-byte lines instead of 8-byte pieces of sixteen.
-  static_assert (kThreads == (kUpTW / 8) * kUpTH && kUpTH % 8 == 0, "one lane per 8 pixels of the tile");
-  const int ly = (tid & 7) | ((tid >> 7) << 3), g8 = (tid >> 3) & (kUpTW / 8 - 1);
+  // Phase 3: horizontal half-pel samples, store.  One lane = 8 pixels of one row of all four
+  // planes; adjacent lanes = adjacent 8-pixel groups of the same row, a wave = 4 rows x 128 pixels
+  // = whole 128-byte lines of the tiled planes (schro_hip_internal.h: 32-byte chunks advancing by
+  // 16 columns, 4 rows per line).  A lane pair swaps its 8 bytes (DPP) so that both hold the pair's
+  // 16 pixels: the even lane stores them as the first half of their own chunk, the odd lane as the
+  // second half of the chunk before.
+  static_assert (kThreads == (kUpTW / 8) * kUpTH && kUpTH % kHpBandRows == 0, "one lane per 8 pixels of the tile");
+  const int ly = tid >> 4, g8 = tid & 15;
   const int gx = x0 + 8 * g8, gy = y0 + ly;
-  if (gx >= w || gy >= h)
-    return;
   const int gd = 2 * g8 + 3;            // LDS dword of the 4 pixels left of this lane's
-  uint32_t c0[2], c2[2], d1[2], d3[2];
+  uint32_t pl[4][2];                    // planes 0..3 (integer, h-half, v-half, hv-half), 2 dwords each
   {
     const uint32_t a0 = s0[ly + 3][gd], a1 = s0[ly + 3][gd + 1], a2 = s0[ly + 3][gd + 2], a3 = s0[ly + 3][gd + 3];
     const uint32_t b0 = s2[ly][gd], b1 = s2[ly][gd + 1], b2 = s2[ly][gd + 2], b3 = s2[ly][gd + 3];
@@ -223,52 +223,98 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     mas8_row4 (a1 ^ kS, a2 ^ kS, a3 ^ kS, p1 + 4);
     mas8_row4 (b0 ^ kS, b1 ^ kS, b2 ^ kS, p3);
     mas8_row4 (b1 ^ kS, b2 ^ kS, b3 ^ kS, p3 + 4);
-    c0[0] = a1;
-    c0[1] = a2;
-    c2[0] = b1;
-    c2[1] = b2;
+    pl[0][0] = a1;
+    pl[0][1] = a2;
+    pl[2][0] = b1;
+    pl[2][1] = b2;
     // the tile holds the picture's last column or row (a whole-workgroup branch): copies there
     const bool edge_tile = x0 + kUpTW >= w || y0 + kUpTH >= h;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       if (edge_tile) {
-        d1[half] = d3[half] = 0;
+        pl[1][half] = pl[3][half] = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
           // schro_frame_mc_edgeextend_horiz overwrites it the same way)
           const bool lastcol = gx + 4 * half + e >= w - 1;
-          int v1 = lastcol ? (int) ((c0[half] >> (8 * e)) & 0xff) : p1[4 * half + e];
-          int v3 = lastcol ? (int) ((c2[half] >> (8 * e)) & 0xff) : p3[4 * half + e];
+          int v1 = lastcol ? (int) ((pl[0][half] >> (8 * e)) & 0xff) : p1[4 * half + e];
+          int v3 = lastcol ? (int) ((pl[2][half] >> (8 * e)) & 0xff) : p3[4 * half + e];
           if (gy >= h - 1)
             v3 = v1;            // last row of the hv-half comes from the h-half (schroframe.c:2028)
-          d1[half] |= (uint32_t) v1 << (8 * e);
-          d3[half] |= (uint32_t) v3 << (8 * e);
+          pl[1][half] |= (uint32_t) v1 << (8 * e);
+          pl[3][half] |= (uint32_t) v3 << (8 * e);
         }
       } else {
-        d1[half] = (uint32_t) p1[4 * half] | ((uint32_t) p1[4 * half + 1] << 8) | ((uint32_t) p1[4 * half + 2] << 16)
+        pl[1][half] = (uint32_t) p1[4 * half] | ((uint32_t) p1[4 * half + 1] << 8) | ((uint32_t) p1[4 * half + 2] << 16)
             | ((uint32_t) p1[4 * half + 3] << 24);
-        d3[half] = (uint32_t) p3[4 * half] | ((uint32_t) p3[4 * half + 1] << 8) | ((uint32_t) p3[4 * half + 2] << 16)
+        pl[3][half] = (uint32_t) p3[4 * half] | ((uint32_t) p3[4 * half + 1] << 8) | ((uint32_t) p3[4 * half + 2] << 16)
             | ((uint32_t) p3[4 * half + 3] << 24);
       }
     }
   }
-  // interleave: even HP row = (integer, h-half) pairs, odd row = (v-half, hv-half)
-  const u32x4 even = { __builtin_amdgcn_perm (d1[0], c0[0], 0x05010400u), __builtin_amdgcn_perm (d1[0], c0[0], 0x07030602u),
-    __builtin_amdgcn_perm (d1[1], c0[1], 0x05010400u), __builtin_amdgcn_perm (d1[1], c0[1], 0x07030602u) };
-  const u32x4 odd = { __builtin_amdgcn_perm (d3[0], c2[0], 0x05010400u), __builtin_amdgcn_perm (d3[0], c2[0], 0x07030602u),
-    __builtin_amdgcn_perm (d3[1], c2[1], 0x05010400u), __builtin_amdgcn_perm (d3[1], c2[1], 0x07030602u) };
-  // 2 gx is a multiple of 16 -- one tile row; rows 2 gy and 2 gy + 1 have the same slot in the
-  // even and the odd tile row of their band
-  uint8_t *de = job.dst + hp_offset (2 * gx, 2 * gy, job.dst_stride);
-  uint8_t *dd = job.dst + hp_offset (2 * gx, 2 * gy + 1, job.dst_stride);
-  if (gx + 8 <= w && (((uintptr_t) de) & 15) == 0) {
-    gstore < u32x4 > (de, even);
-    gstore < u32x4 > (dd, odd);
-  } else {
-    for (int e = 0; e < 16 && gx + e / 2 < w; e++) {
-      gstore < uint8_t > (de + e, (uint8_t) (even[e >> 2] >> (8 * (e & 3))));
-      gstore < uint8_t > (dd + e, (uint8_t) (odd[e >> 2] >> (8 * (e & 3))));
+  const int stride = job.dst_stride;
+  // the pair's 16 pixels start at padded column xp16 (a multiple of 16)
+  const int odd = g8 & 1, xp16 = gx - 8 * odd + kHpApron;
+  uint8_t *row = job.dst + hp_row_offset (min (gy, h - 1), stride);
+  // whole pair inside the picture (a whole-wave property except in the tile on the right edge)
+  const bool pair_in = gx - 8 * odd + 16 <= w;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    // neighbour's dwords: quad_perm [1, 0, 3, 2]
+    const uint32_t n0 = (uint32_t) __builtin_amdgcn_mov_dpp ((int) pl[p][0], 0xb1, 0xf, 0xf, true);
+    const uint32_t n1 = (uint32_t) __builtin_amdgcn_mov_dpp ((int) pl[p][1], 0xb1, 0xf, 0xf, true);
+    if (pair_in && gy < h) {
+      const u32x4 v = odd ? (u32x4) { n0, n1, pl[p][0], pl[p][1] } : (u32x4) { pl[p][0], pl[p][1], n0, n1 };
+      // even lane: bytes 0..15 of chunk xp16 >> 4; odd lane: bytes 16..31 of the chunk before
+      gstore < u32x4 > (row + (size_t) ((xp16 >> 4) - odd) * 512 + (size_t) (p * 128 + 16 * odd), v);
+    } else if (gy < h) {
+      // ragged right edge: byte by byte, both homes of every column
+      for (int e = 0; e < 8 && gx + e < w; e++) {
+        const uint8_t v = (uint8_t) (pl[p][e >> 2] >> (8 * (e & 3)));
+        const int xp = gx + e + kHpApron;
+        gstore < uint8_t > (row + hp_col_offset (xp) + p * 128, v);
+        gstore < uint8_t > (row + hp_col_offset (xp - 16) + p * 128 + 16, v);
+      }
+    }
+  }
+  // Aprons (tiles on the left / right edge of the picture): kHpApron columns in front of column 0
+  // and everything behind column w - 1 to the end of the row's last chunk repeat the edge sample --
+  // of plane 0 in planes 0 and 1, of plane 2 in planes 2 and 3 (schro_frame_mc_edgeextend_horiz's
+  // sources in schro_upsampled_frame_upsample, schroframe.c:2012-2029) = the half-pel column
+  // clamped to [0, 2w - 2].  LDS dword i of a row holds pixels x0 - 16 + 4 i ..
+  if (x0 == 0) {
+    // columns 0..31 padded: chunk 0 whole, chunk 1's first half; three 16-byte pieces per (row, plane)
+    for (int it = tid; it < kUpTH * 4 * 3; it += kThreads) {
+      const int piece = it % 3, p = (it / 3) & 3, r = it / 12;
+      if (y0 + r >= h)
+        continue;
+      const uint32_t e = ((p < 2 ? s0[r + 3][4] : s2[r][4]) & 0xffu) * 0x01010101u;
+      uint8_t *d = job.dst + hp_row_offset (y0 + r, stride) + (size_t) (piece == 2 ? 512 : 16 * piece) + p * 128;
+      gstore < u32x4 > (d, (u32x4) { e, e, e, e });
+    }
+  }
+  if (x0 + kUpTW >= w) {
+    // padded columns w + 32 .. end: every chunk that holds one of them, byte by byte at the boundary
+    const int nch = stride >> 9, first = w + kHpApron, c_lo = max (0, (first >> 4) - 1);
+    const int ndw = (nch - c_lo) * 8;   // dwords per (row, plane)
+    const int xl = w - 1 - (x0 - 16);   // position of the last column in the LDS row
+    for (int it = tid; it < kUpTH * 4 * ndw; it += kThreads) {
+      const int dwi = it % ndw, p = (it / ndw) & 3, r = it / (4 * ndw);
+      if (y0 + r >= h)
+        continue;
+      const int c = c_lo + (dwi >> 3), o = (dwi & 7) * 4, col = 16 * c + o;     // padded column of the dword's first byte
+      if (col + 3 < first)
+        continue;
+      const uint32_t src = p < 2 ? s0[r + 3][xl >> 2] : s2[r][xl >> 2];
+      const uint32_t e = ((src >> (8 * (xl & 3))) & 0xffu) * 0x01010101u;
+      uint8_t *d = job.dst + hp_row_offset (y0 + r, stride) + (size_t) c * 512 + p * 128 + o;
+      if (col >= first) {
+        gstore < uint32_t > (d, e);
+      } else {
+        for (int k = first - col; k < 4; k++)
+          gstore < uint8_t > (d + k, (uint8_t) e);
+      }
     }
   }
 }

@@ -309,19 +309,13 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
         const int sx = bi.fx[r] + 4 * seg * (1 << prec), sy = bi.fy[r] + row * (1 << prec);
         const int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
         const int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
-        const uint8_t *rows[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const int Y = clampi (hy + k, 0, 2 * job.h - 2);
-          rows[k] = job.ref[r] + hp_row_offset (Y, job.ref_stride[r]);
-        }
+        const int Y0 = clampi (hy, 0, 2 * job.h - 2), Y1 = clampi (hy + 1, 0, 2 * job.h - 2);
         int p[2][9];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
           const int X = clampi (hx + j, 0, 2 * job.w - 2);
-          const int col = (X >> 4) * 128 + (X & 15);
-          p[0][j] = gload < uint8_t > (rows[0] + col);
-          p[1][j] = gload < uint8_t > (rows[1] + col);
+          p[0][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y0, job.ref_stride[r]));
+          p[1][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y1, job.ref_stride[r]));
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -476,14 +470,15 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
 constexpr int kItemBlkCap = 192;        // decoded blocks per chunk (<= kThreads: one per thread)
 constexpr int kItemCap = 1536;          // (block, row) items per chunk
 constexpr int kItemWCap = 256;          // (row, segment) weight words; larger blocks take the rim path
-constexpr int kItemStage = 2752;        // staging bytes per wave (half-pel references) incl. spare chunks
 
 struct __attribute__ ((aligned (16))) HotBlk {
   int y, x;                     // block origin relative to the tile
   int mode_dc;                  // as BlkInfo
   int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
-  int off[2];                   // first sample of the window: byte offset (plain plane) / of its chunk's tile row (half-pel image)
+  int off[2];                   // first sample of the window: byte offset (plain plane); half-pel image: padded column of
+                                // its plane | parities of the half-pel origin << 16 (x) / << 17 (y)
   uint32_t wpk[2];              // packed bilinear weights
+  int ya[2];                    // half-pel image: plane row of the window's first sample
 };
 
 struct ItemLane {
@@ -491,78 +486,41 @@ struct ItemLane {
   int seg_bytes;                // byte offset of the segment inside the sample window
   int tw3;                      // tile width + 3 (range test of a segment)
   bool active;                  // lanes beyond the last whole item of a pass idle
-  // half-pel references (tiled): the load role of this lane -- one 16-byte chunk of
-  // each sample row of its OWN item
-  uint8_t *stage;               // this wave's staging buffer
-  int ld_x8;                    // chunk * 128 (byte offset of the chunk's tile column)
-  int ld_wr;                    // where the row-0 chunk is staged (lanes without a chunk: a spare one)
-  int rd_base, rd_row1;         // compute role: staged bytes of this segment, second row
 };
 
-// Four predicted pixels of one reference from a tiled half-pel image.  The wave first
-// stages, for each of its items, the aligned 16-byte chunks that cover the item's
-// 8 * nseg sample bytes of row(s) 2 row (+ 1) -- every lane loads two chunks, whatever
-// item they belong to -- then each lane reads its own 8 (+ 8) bytes back at the window's
-// byte phase.  16-byte chunk = one row of a tile (16 bytes x 8 rows of one parity): the chunks
-// of the rows above and below share its cache line.
-// load role: the 16-byte chunk (ld_x8 / 128) of sample rows 2 row (+ 1) of the block's window.
-// off_r is the offset of the window's first chunk in the band (16 rows) of its first sample
-// row, the phase (y & 15) of that row comes with it.
+// Four predicted pixels of one reference from the half-pel planes (schro_hip_internal.h): the
+// segment's samples are four contiguous bytes of the plane the window's origin selects, the other
+// taps of a quarter / eighth-pel position four contiguous bytes of the neighbouring planes; one
+// byte-aligned dword load each, then v_perm_b32 + v_dot4_u32_u8 per pixel (orc_combine4_nxm_u8).
 template < int PC >
 __device__ __forceinline__ void
-tiled_load (const ObmcJob & job, int r, const ItemLane & il, int off_r, uint32_t own_phase, int row,
-    u32x4 * v)
+hp_predict4 (const ObmcJob & job, int r, int off_r, int ya, int row, int seg, uint32_t wpk, int *val)
 {
   static_assert (PC >= 1, "plain references are linear");
-  const uint32_t tile_row_bytes = 8u * (uint32_t) job.ref_stride[r];
-  // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
-  const uint32_t y0 = (own_phase & 15u) + 2u * (uint32_t) row;
-  const uint32_t o0 = (uint32_t) off_r + __umul24 (((y0 >> 3) & ~1u) | (y0 & 1u), tile_row_bytes) + ((y0 & 14u) << 3)
-      + (uint32_t) il.ld_x8;
-  v[0] = gload < u32x4 > (job.ref[r] + o0);
-  if constexpr (PC == 2) {
-    const uint32_t y1 = y0 + 1u;
-    const uint32_t o1 = (uint32_t) off_r + __umul24 (((y1 >> 3) & ~1u) | (y1 & 1u), tile_row_bytes) + ((y1 & 14u) << 3)
-      + (uint32_t) il.ld_x8;
-    v[1] = gload < u32x4 > (job.ref[r] + o1);
-  }
-}
-
-// compute role: stage the wave's chunks, read this lane's 8 (+ 8) bytes back at the window's
-// byte phase, four predicted pixels
-template < int PC >
-__device__ __forceinline__ void
-tiled_predict (const ItemLane & il, const u32x4 * v, uint32_t own_phase, uint32_t wpk, int *val)
-{
-  const u32x4 v0 = v[0], v1 = v[PC == 2 ? 1 : 0];
-  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-  *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr) = v0;
-  if constexpr (PC == 2)
-    *reinterpret_cast < u32x4 * >(il.stage + il.ld_wr + il.rd_row1) = v1;
-  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier ();
-  const int off = il.rd_base + (int) (own_phase >> 4);          // + (x of the first sample & 15)
-  const uint32_t *p = reinterpret_cast < const uint32_t * >(il.stage + (off & ~3));
-  const uint32_t sh = off & 3;
-  const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
-  const uint32_t alo = __builtin_amdgcn_alignbyte (a1, a0, sh), ahi = __builtin_amdgcn_alignbyte (a2, a1, sh);
+  const int stride = job.ref_stride[r];
+  const int xp = (off_r & 0xffff) + 4 * seg, px = (off_r >> 16) & 1, py = (off_r >> 17) & 1;
+  const int y = ya + row;
+  const uint8_t *a = job.ref[r] + hp_row_offset (y, stride) + hp_col_offset (xp) + (px + 2 * py) * 128;
+  const uint32_t A = gload < u32_u > (a);
   if constexpr (PC == 1) {
-    val[0] = alo & 0xff;
-    val[1] = (alo >> 16) & 0xff;
-    val[2] = ahi & 0xff;
-    val[3] = (ahi >> 16) & 0xff;
+    val[0] = A & 0xff;
+    val[1] = (A >> 8) & 0xff;
+    val[2] = (A >> 16) & 0xff;
+    val[3] = A >> 24;
     (void) wpk;
   } else {
-    const uint32_t *q = reinterpret_cast < const uint32_t * >(il.stage + (off & ~3) + il.rd_row1);
-    const uint32_t b0 = q[0], b1 = q[1], b2 = q[2];
-    const uint32_t blo = __builtin_amdgcn_alignbyte (b1, b0, sh), bhi = __builtin_amdgcn_alignbyte (b2, b1, sh);
-    val[0] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x05040100u), wpk, 8u, false) >> 4);
-    val[1] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (blo, alo, 0x07060302u), wpk, 8u, false) >> 4);
-    val[2] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x05040100u), wpk, 8u, false) >> 4);
-    val[3] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (bhi, ahi, 0x07060302u), wpk, 8u, false) >> 4);
+    // X + 1: the other column parity, one column on when X is odd (that column is in the same
+    // chunk: chunks hold 32 bytes and advance by 16); Y + 1: the other row parity, one row on when Y is odd
+    const int dB = px ? 1 - 128 : 128;
+    const uint8_t *c = job.ref[r] + hp_row_offset (y + py, stride) + hp_col_offset (xp) + (px + 2 * (py ^ 1)) * 128;
+    const uint32_t B = gload < u32_u > (a + dB), C = gload < u32_u > (c), D = gload < u32_u > (c + dB);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t sel = 0x0c0c0000u | (uint32_t) e | ((uint32_t) (4 + e) << 8);
+      const uint32_t t = __builtin_amdgcn_perm (B, A, sel), u = __builtin_amdgcn_perm (D, C, sel);
+      val[e] = (int) (__builtin_amdgcn_udot4 (__builtin_amdgcn_perm (u, t, 0x05040100u), wpk, 8u, false) >> 4);
+    }
   }
-  __builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier ();     // the next staging pass may overwrite
 }
 
 // one pass of one class: CLS 0 both references, 1 / 2 one reference, 3 DC
@@ -590,16 +548,9 @@ item_pass (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, co
         fetch4_inside < PC > (job.ref[1] + (hb.off[1] + (row * kStep) * job.ref_stride[1] + il.seg_bytes),
             job.ref_stride[1], hb.wpk[1], v1);
     } else {
-      // all loads of the pass go out before the first is waited for (a two-deep pipeline
-      // across passes was measured too: no gain, and it spills at 5 waves per SIMD)
-      const uint32_t ph0 = ((uint32_t) hb.rows >> (16 + 8 * r0)) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-      u32x4 c0[2], c1[2];
-      tiled_load < PC > (job, r0, il, hb.off[r0], ph0, row, c0);
+      hp_predict4 < PC > (job, r0, hb.off[r0], hb.ya[r0], row, il.seg, hb.wpk[r0], v0);
       if constexpr (CLS == 0)
-        tiled_load < PC > (job, 1, il, hb.off[1], ph1, row, c1);
-      tiled_predict < PC > (il, c0, ph0, hb.wpk[r0], v0);
-      if constexpr (CLS == 0)
-        tiled_predict < PC > (il, c1, ph1, hb.wpk[1], v1);
+        hp_predict4 < PC > (job, 1, hb.off[1], hb.ya[1], row, il.seg, hb.wpk[1], v1);
     }
     if constexpr (CLS != 0) {
 #pragma unroll
@@ -650,7 +601,6 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
   __shared__ uint16_t s_start[kThreads + 2];    // first item of each sorted block
   __shared__ int s_cnt[8];
   __shared__ int s_wide;
-  __shared__ __attribute__ ((aligned (16))) uint8_t s_stage[PC == 0 ? 1 : kThreads / 64][PC == 0 ? 16 : kItemStage];
 
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   // which tile: position bid of the host's tile order (obmc_tile_order: the same rows of all
@@ -687,7 +637,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
   const int gh = PC == 0 ? job.h - 1 : 2 * job.h - 2;
   constexpr int kStep = PC == 0 ? 1 : 2;        // samples per pixel step
   // block geometry of the plane: from the host (obmc_item_geometry)
-  const int nseg = job.nseg, nch = job.nch, lpi = job.lpi, item_bytes = job.item_bytes;
+  const int nseg = job.nseg, lpi = job.lpi;
   const int IPW = job.ipw, chunk_cap = job.chunk_cap;
   ItemLane il;
   il.slot = mdiv (lane, lpi, job.m_lpi);
@@ -696,11 +646,6 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
   il.seg_bytes = il.seg * (4 * kStep);
   il.tw3 = x_hi - x_lo + 3;
   il.active = il.slot < IPW && sub < nseg;
-  il.stage = s_stage[PC == 0 ? 0 : wave];
-  il.rd_base = il.slot * item_bytes + 8 * il.seg;
-  il.rd_row1 = 16 * nch;
-  il.ld_x8 = 128 * min (sub, nch - 1);
-  il.ld_wr = il.slot < IPW && sub < nch ? il.slot * item_bytes + 16 * sub : kItemStage - 16 - il.rd_row1;
   TileCtx tc;
   tc.x_lo = x_lo;
   tc.x_hi = x_hi;
@@ -755,7 +700,6 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
       // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
       int p = interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
       int md = mode | (p << 8);
-      int phases = 0;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         int fx, fy;
@@ -780,25 +724,19 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
         bool inside = gx0 >= 0 && gy0 >= 0 && gx1 <= gw && gy1 <= gh;
         if (!inside)
           md |= 4 << r;
-        // plain planes are linear.  Half-pel images are tiled: keep the offset of the window's
-        // first 16-byte chunk in the band (16 rows, two tile rows) of its first sample row, and the
-        // phases (y & 15) | (x & 15) << 4 of the first sample
+        // plain planes are linear; half-pel planes: padded column and row of the first sample in its plane
         if constexpr (PC == 0) {
           info.off[r] = inside ? gy0 * job.ref_stride[r] + gx0 : 0;
+          info.ya[r] = 0;
         } else {
-          // every chunk a lane may fetch lies inside the row pitch
-          if (inside && (gx0 & ~15) + 16 * nch > job.ref_stride[r]) {
-            inside = false;
-            md |= 4 << r;
-          }
-          info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
-          phases |= inside ? ((gy0 & 15) | ((gx0 & 15) << 4)) << (8 * r) : 0;
+          info.off[r] = inside ? ((gx0 >> 1) + kHpApron) | ((gx0 & 1) << 16) | ((gy0 & 1) << 17) : 0;
+          info.ya[r] = inside ? gy0 >> 1 : 0;
         }
         info.wpk[r] = wpk;
       }
       info.mode_dc = md;
       const int ra = max (0, -info.y), rb = min (yblen, y_hi - by);
-      info.rows = ra | ((rb - ra) << 8) | (phases << 16);
+      info.rows = ra | ((rb - ra) << 8);
       const bool clamped = ((md >> 2) & md & 3) != 0;
       const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + nseg * 4 > xfold_hi;
       // (a DC value outside 0..255 would carry between the halves of an accumulator word)
@@ -933,17 +871,12 @@ void
 obmc_item_geometry (ObmcJob * j)
 {
   const int nseg = (j->xblen + 3) >> 2;
-  // half-pel references: 16-byte chunks per sample row of an item.  The lanes of an item are
-  // its load role too (lane k: chunk k of both sample rows), so an item takes
-  // max (segments, chunks) lanes
-  const int nch = ((nseg + 1) >> 1) + 1, nrow = j->prec >= 2 ? 2 : 1;
-  const int lpi = j->prec == 0 ? nseg : std::max (nseg, nch);
+  const int lpi = nseg;         // an item's lanes: one per 4-pixel segment
   j->nseg = nseg;
-  j->nch = nch;
+  j->nch = 0;
   j->lpi = lpi;
-  j->item_bytes = nrow * nch * 16 + 16;         // + 16: items start on different LDS banks
-  j->ipw = j->prec == 0 ? 64 / lpi              // items per wave pass
-      : std::min (64 / lpi, (kItemStage - 32 - 16 * nch) / j->item_bytes);
+  j->item_bytes = 0;
+  j->ipw = 64 / lpi;            // items per wave pass
   j->chunk_cap = std::min (kItemBlkCap, kItemCap / std::min (j->yblen, kFTH));
   j->m_tiles_x = div_magic (j->tiles_x);
   j->m_xbsep = div_magic (j->xbsep);

@@ -11,15 +11,18 @@
 //
 //   * a lane owns a whole block ROW (12 luma pixels), not a 4-pixel segment: one item decode,
 //     one address computation, one weight-table read per row instead of three;
-//   * the lane loads its own row's 16-byte tile rows (adjacent lanes = adjacent rows of a
-//     block = sample rows of one parity = the same 128-byte line of the tiled half-pel image:
-//     one TA cycle per 4 lanes) with buffer loads straight into registers and aligns them there (a
-//     two-level select by the window's dword phase + v_alignbyte) -- no LDS staging buffer;
+//   * r03: the half-pel image is four planes (schro_hip_internal.h), so the samples of a block
+//     row are contiguous bytes of one plane and the other taps of a quarter-pel position contiguous
+//     bytes of the neighbouring planes, +-128 / +-256 bytes away in the same band of lines: the lane
+//     fetches each with ONE byte-aligned buffer load of the row's length (chunks of 32 bytes that
+//     advance by 16 columns: a run never leaves its chunk) -- no alignment, phase-select or
+//     even / odd split instructions at all (r02: 132 of a two-reference pass's 265), and no
+//     horizontal clamp either (aprons);
 //   * prediction is byte-parallel: at half / quarter pel orc_combine4_nxm_u8
 //     (schroorc.orc:1635-1662) degenerates to copy / 2-sample / 4-sample rounding averages,
-//     v_lerp_u8 on four pixels per instruction (exact, see avg4); the horizontal phase is a
-//     v_bfi select (lerp (E, E) = E), the vertical phase a class of the item sort; both
-//     references of a block are blended with one more v_lerp_u8 (avgub);
+//     v_lerp_u8 on four pixels per instruction (exact, see predict_row); a tap the window's phase
+//     does not use is the first tap again (same address: lerp (a, a) = a); both references of a
+//     block are blended with one more v_lerp_u8 (avgub);
 //   * weights are u16 pairs (v_pk_mul_lo_u16) and two pixels share an accumulator word, so a
 //     row is accumulated with xblen / 2 ds_add_u32 instead of xblen.
 // Eighth-pel (arbitrary bilinear weights) and plain references stay with obmc.hip.
@@ -39,7 +42,11 @@ namespace {
 constexpr int kRThreads = 256;
 constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1); the kernels take the height as TH
 constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
-constexpr int kRAccW = 84;              // accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels, 16-byte rows
+// accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels = 81 words.  An ODD pitch: the lanes of
+// a pass are rows of blocks whose origins are multiples of 4 words apart, so with the r02 pitch of 84
+// every address of an accumulate had the same word index mod 4 and 64 lanes met in 8 of the 32 banks
+// (7.2 extra cycles per ds_add, simulated; 2.3 with 85)
+constexpr int kRAccW = 85;
 // blocks whose footprint meets a tile and their (block, row) items: by row length (8-pixel rows
 // and shorter are the small, many blocks of chroma planes and of the 8/4 block set)
 template < int ND > struct RowCaps {
@@ -48,37 +55,34 @@ template < int ND > struct RowCaps {
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
 constexpr int kRCls = 8;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 edge, 7 rim
 constexpr int kREdge = kRCls - 2;       // windows clamped vertically and / or folded weights, any mode: still a row per lane
-constexpr int kRRim = kRCls - 1;        // windows clamped horizontally, DC values outside 8 bits: per sample
-#ifndef SCHRO_ROW_SERIAL
-#define SCHRO_ROW_SERIAL 0
-#endif
-constexpr bool kRowSerial = SCHRO_ROW_SERIAL != 0;
+constexpr int kRRim = kRCls - 1;        // DC values outside 8 bits, geometries beyond the weight table: per sample
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+
+// one reference's window of a block
+struct __attribute__ ((aligned (4))) RowRef {
+  int base;                     // byte offset of the window's first sample inside a band of lines: chunk, byte in the
+                                // chunk, plane (edge class: without the row-parity part of the plane; rim: fx | fy << 16)
+  uint32_t ydb;                 // plane row of that sample (edge class: its half-pel row, signed) | dB << 16: the X + 1 taps
+                                // are dB bytes on (+128: the other column parity; 1 - 128: and one column on; 0: not used)
+  int dci;                      // dC << 16 | inc: the Y + 1 taps are dC bytes and inc plane rows on (+256, 0 | -256, 1 | 0, 0)
+};
 
 struct __attribute__ ((aligned (8))) RowBlk {
   int16_t y, x;                 // block origin relative to the tile
   int dcs;                      // DC values of the job's planes, 16 bits each (first plane low)
   int flags;                    // bits 0-1 mode, 2-5 weights fold at top | bottom | left | right,
-                                // 6 + 2 r: reference r's window at a horizontal half position, 7 + 2 r: at a vertical one
-  int rows;                     // first block row inside the tile | rows inside << 8 | window phases << 16
-  int off[2];                   // offset of the window's first 16-byte chunk in its tile row; edge class: first
-                                // sample row << 17 | chunk offset; rim: fx | fy << 16 of reference r
+                                // 6 + r: reference r's window at a vertical quarter position (edge class)
+  int rows;                     // first block row inside the tile | rows inside << 8
+  RowRef r[2];
 };
-static_assert (sizeof (RowBlk) == 24, "24-byte block records: 384 of them beside the accumulator, six chroma workgroups per CU");
-
-// all ones when reference r's window sits at a horizontal half position (v_bfe_i32)
-__device__ __forceinline__ uint32_t
-blk_rx_mask (const RowBlk & hb, int r)
-{
-  return (uint32_t) ((int32_t) ((uint32_t) hb.flags << (25 - 2 * r)) >> 31);
-}
+static_assert (sizeof (RowBlk) == 40, "block records: 128 (luma) / 352 (chroma) of them beside the accumulator");
 
 __device__ __forceinline__ uint32_t
 blk_ry (const RowBlk & hb, int r)
 {
-  return ((uint32_t) hb.flags >> (7 + 2 * r)) & 1u;
+  return ((uint32_t) hb.flags >> (6 + r)) & 1u;
 }
 
 __device__ __forceinline__ int
@@ -146,100 +150,92 @@ acc_word (uint32_t * acc, int par, int x, int y, int *half)
 }
 
 // ---- one reference's prediction of a block row: ND dwords of 4 pixels ---------------------
-// RY: the window sits at a vertical half position (two sample rows)
-// (RY with ry1 == 0: "the second row" is the first one again -- the same cache lines -- and the
-// vertical average of a row with itself is that row; this lets blocks with two references be
-// ONE class whatever their vertical phases)
-// ABS (edge class): off_r = first sample row << 17 | offset of the window's first chunk in a tile
-// row, and every sample row is clamped to the image on its own (fetch_ref's CLAMP on y)
+// ND dwords from byte offset `off` of the reference (any alignment; beyond the buffer: zeros)
+template < int ND >
+__device__ __forceinline__ void
+load_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, uint32_t * d)
+{
+  if constexpr (ND == 2) {
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) off, 0, 0);
+    d[0] = q.x;
+    d[1] = q.y;
+  } else if constexpr (ND == 3) {
+    typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
+    const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) off, 0, 0);
+    d[0] = q.x;
+    d[1] = q.y;
+    d[2] = q.z;
+  } else {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) off, 0, 0);
+    d[0] = q.x;
+    d[1] = q.y;
+    d[2] = q.z;
+    d[3] = q.w;
+  }
+}
+
+// byte offset of plane row y inside the image: band (4 rows) * stride + 32 * row in the band
+__device__ __forceinline__ uint32_t
+row_ofs (uint32_t y, uint32_t stride)
+{
+  return __umul24 (y >> 2, stride) + ((y & 3u) << 5);
+}
+
+// RY: the class may hold windows at a vertical quarter position (four taps); else two taps (the
+// window's own plane and the X + 1 plane).  A tap the window's phase does not use has the first
+// tap's address (dB / dC 0): the same line again, and lerp (a, a) = a.
+// ABS (edge class): rr.ydb holds the window's first HALF-PEL row, signed, and every sample row is
+// clamped to the image on its own (fetch_ref's CLAMP on y): the row's parity picks the plane
 template < int ND, bool RY, bool ABS = false >
 __device__ __forceinline__ void
-predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, int ref_stride, int off_r, uint32_t phase, int row, uint32_t rxm,
-    uint32_t ry1, uint32_t * out)
+predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, const RowRef & rr, uint32_t ry, int row, uint32_t * out)
 {
-  constexpr int NCH = ND <= 2 ? 2 : 3;  // 16-byte tile rows that can hold the 2 * xblen + 15 bytes from the chunk's start
-  constexpr int NU = 2 * ND + 1;        // dwords from the window's first dword on
-  const uint32_t tile_row_bytes = 8u * (uint32_t) ref_stride;   // (two per band of 16 rows: even rows, odd rows)
-  const uint32_t s = phase >> 4;        // x & 15 of the first sample
-  // The tile rows come through buffer loads: 32-bit offsets from the plane's descriptor, and the
-  // last tile row -- needed only when the window reaches into it -- gets an offset beyond the
-  // buffer where it is not: such a load returns zeros without touching memory.  (As an
-  // exec-masked global load it was a branch, and the wait-count pass drains every outstanding
-  // load at a branch join: the four sample rows of a two-reference pass were four serial round
-  // trips.)
-  const bool last = (int) s + 2 * job.xblen > 16 * (NCH - 1);
-  constexpr uint32_t kBeyond = 0x80000000u;
-  // (masks and v_bfi, not ?: on array elements: the compiler turns such a select into a
-  // run-time index and moves the array to scratch memory)
-  const uint32_t m2 = (s & 8u) ? 0xffffffffu : 0u, m1 = (s & 4u) ? 0xffffffffu : 0u;
-  const uint32_t sh = s & 3u;
-  uint32_t h[RY ? 2 : 1][ND], x[RY ? 2 : 1][ND];
-#pragma unroll
-  for (int v = 0; v < (RY ? 2 : 1); v++) {
-    uint32_t c[4 * NCH + 2];
-    // row y of the band the window starts in: tile row 2 * (y >> 4) + (y & 1), slot (y >> 1) & 7
-    uint32_t y, p;
-    if constexpr (ABS) {
-      y = (uint32_t) clampi ((off_r >> 17) + 2 * row + (v ? (int) ry1 : 0), 0, 2 * job.h - 2);
-      p = ((uint32_t) off_r & 0x1ffffu) + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
-    } else {
-      y = (phase & 15u) + 2u * (uint32_t) row + (v ? ry1 : 0u);
-      p = (uint32_t) off_r + __umul24 (((y >> 3) & ~1u) | (y & 1u), tile_row_bytes) + ((y & 14u) << 3);
-    }
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) ((j < NCH - 1 || last ? p : kBeyond) + 128u * j), 0, 0);
-      c[4 * j + 0] = q.x;
-      c[4 * j + 1] = q.y;
-      c[4 * j + 2] = q.z;
-      c[4 * j + 3] = q.w;
-    }
-    // the window's dwords u[0 .. NU): c[q .. q + NU), q = s >> 2 in 0..3, by a two-level select
-    uint32_t t[NU + 1], u[NU];
-#pragma unroll
-    for (int i = 0; i < NU + 1; i++)
-      t[i] = (c[i + 2] & m2) | (c[i] & ~m2);
-#pragma unroll
-    for (int i = 0; i < NU; i++)
-      u[i] = (t[i + 1] & m1) | (t[i] & ~m1);
+  const int dB = (int) rr.ydb >> 16;
+  uint32_t offA, offC = 0;
+  if constexpr (ABS) {
+    const int hy = (int) (int16_t) (rr.ydb & 0xffffu) + 2 * row, gh = 2 * job.h - 2;
+    const uint32_t Y0 = (uint32_t) clampi (hy, 0, gh), Y1 = (uint32_t) clampi (hy + (int) ry, 0, gh);
+    offA = (uint32_t) rr.base + ((Y0 & 1u) << 8) + row_ofs (Y0 >> 1, stride);
+    offC = (uint32_t) rr.base + ((Y1 & 1u) << 8) + row_ofs (Y1 >> 1, stride);
+  } else {
+    const uint32_t y = (rr.ydb & 0xffffu) + (uint32_t) row;
+    offA = (uint32_t) rr.base + row_ofs (y, stride);
+    if constexpr (RY)
+      offC = (uint32_t) (rr.base + (rr.dci >> 16)) + row_ofs (y + ((uint32_t) rr.dci & 1u), stride);
+  }
+  uint32_t a[ND], b[ND];
+  load_run < ND > (ref, offA, a);
+  load_run < ND > (ref, offA + (uint32_t) dB, b);
+  if constexpr (RY || ABS) {
+    uint32_t c[ND], d[ND];
+    load_run < ND > (ref, offC, c);
+    load_run < ND > (ref, offC + (uint32_t) dB, d);
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-      const uint32_t lo = __builtin_amdgcn_alignbyte (u[2 * k + 1], u[2 * k], sh);
-      const uint32_t hi = __builtin_amdgcn_alignbyte (u[2 * k + 2], u[2 * k + 1], sh);
-      const uint32_t e = __builtin_amdgcn_perm (hi, lo, 0x06040200u);       // half-pel columns hx + 2k
-      const uint32_t o = __builtin_amdgcn_perm (hi, lo, 0x07050301u);       // hx + 1 + 2k
-      const uint32_t o2 = (o & rxm) | (e & ~rxm);       // integer horizontal position: average e with itself
-      h[v][k] = lerp1 (e, o2);
-      x[v][k] = e ^ o2;
-    }
-    if constexpr (kRowSerial)
-      __builtin_amdgcn_sched_barrier (0);       // a sample row at a time: fewer registers in flight, more waves
-  }
-#pragma unroll
-  for (int k = 0; k < ND; k++) {
-    if constexpr (RY) {
       // per byte (a + b + c + d + 2) >> 2 exactly: with c1 = (a+b+1)>>1, c2 = (c+d+1)>>1 and l = the
       // bit an average rounded up by, (c1 + c2 + 1 - (l1 | l2)) >> 1; for a + a + c + c: (a + c + 1) >> 1
-      out[k] = __builtin_amdgcn_lerp (h[0][k], h[1][k], ~(x[0][k] | x[1][k]));
-    } else {
-      out[k] = h[0][k];
+      const uint32_t h0 = lerp1 (a[k], b[k]), h1 = lerp1 (c[k], d[k]);
+      out[k] = __builtin_amdgcn_lerp (h0, h1, ~((a[k] ^ b[k]) | (c[k] ^ d[k])));
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      out[k] = lerp1 (a[k], b[k]);
   }
 }
 
 // one pass: every lane predicts one (block, row) item and adds it into the accumulator tile
-// CLS 0-3 both references, 4-5 the first, 6-7 the second, 8 DC
+// CLS 0 both references, 1-2 the first (two / four taps), 3-4 the second, 5 DC, 6 edge
+struct RowRefs {
+  __amdgpu_buffer_rsrc_t rsrc[2];       // the plane's references as buffers: whole bands of 4 rows
+  uint32_t stride[2];
+};
+
 template < int ND, int CLS, bool EXACT >
 __device__ __forceinline__ void
-row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
-    const uint32_t * s_wp, uint32_t * acc, int par, int npair, int it, int hi)
+row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlk * s_hot,
+    const uint32_t * s_wp, uint32_t * acc, int par, int it, int hi)
 {
-  // the references as buffers of whole bands of 16 half-pel rows (include/schro_hip.h)
-  const int hp_rows = (2 * job.h + 15) & ~15;
-  const __amdgpu_buffer_rsrc_t ref0 = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[0], 0,
-      (int) ((uint32_t) job.ref_stride[0] * (uint32_t) hp_rows), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ref1 = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[1], 0,
-      (int) ((uint32_t) job.ref_stride[1] * (uint32_t) hp_rows), 0x00020000);
   const bool st = CLS == 0 && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
   const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
   const int e = s_item[min (it, hi - 1)];
@@ -253,10 +249,9 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
   } else if constexpr (CLS == kREdge) {
     // any mode: both references are read (an unused one at offset 0) and the mode selects
     uint32_t p1[ND];
-    const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-    predict_row < ND, true, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, blk_rx_mask (hb, 0), blk_ry (hb, 0), p);
+    predict_row < ND, true, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
     __builtin_amdgcn_sched_barrier (0);
-    predict_row < ND, true, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, blk_rx_mask (hb, 1), blk_ry (hb, 1), p1);
+    predict_row < ND, true, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
     const uint32_t mode = (uint32_t) hb.flags & 3u;
     const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
@@ -267,18 +262,16 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
     }
   } else if constexpr (CLS == 0) {
     uint32_t p1[ND];
-    const uint32_t ph0 = ((uint32_t) hb.rows >> 16) & 0xffu, ph1 = ((uint32_t) hb.rows >> 24) & 0xffu;
-    predict_row < ND, true > (job, ref0, job.ref_stride[0], hb.off[0], ph0, row, blk_rx_mask (hb, 0), blk_ry (hb, 0), p);
+    predict_row < ND, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], 0u, row, p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight
-    predict_row < ND, true > (job, ref1, job.ref_stride[1], hb.off[1], ph1, row, blk_rx_mask (hb, 1), blk_ry (hb, 1), p1);
+    predict_row < ND, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], 0u, row, p1);
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
   } else {
     constexpr int r = CLS >= 3 ? 1 : 0;
     constexpr bool RY = CLS == 2 || CLS == 4;
-    const uint32_t ph = ((uint32_t) hb.rows >> (16 + 8 * r)) & 0xffu;
-    predict_row < ND, RY > (job, r ? ref1 : ref0, job.ref_stride[r], hb.off[r], ph, row, blk_rx_mask (hb, r), 1u, p);
+    predict_row < ND, RY > (job, refs.rsrc[r], refs.stride[r], hb.r[r], 0u, row, p);
   }
   if (st) {
     asm volatile ("" :: "v" (p[0]));
@@ -308,7 +301,6 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
       w[2 * k + 1] = q.y;
     }
   }
-  (void) npair;
 #pragma unroll
   for (int k = 0; k < 2 * ND; k++) {
     const uint32_t px = __builtin_amdgcn_perm (0u, p[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
@@ -332,8 +324,8 @@ row_pass (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_it
 // wave 3 with none)
 template < int ND, int CLS >
 __device__ __forceinline__ void
-row_class (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_item, const RowBlk * s_hot,
-    const uint32_t * s_wp, uint32_t * acc, int par, int npair, int lo, int hi, bool exact, int *turn)
+row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlk * s_hot,
+    const uint32_t * s_wp, uint32_t * acc, int par, int lo, int hi, bool exact, int *turn)
 {
   // (wave-uniform values in scalar registers: the class loops are scalar branches, not exec masks)
   const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -343,10 +335,10 @@ row_class (const ObmcJob & job, int pl, const PlaneIO & io, const uint16_t * s_i
   *turn = (*turn + npass) & (kWaves - 1);
   if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, true > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+      row_pass < ND, CLS, true > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   } else {
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, false > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, lo + 64 * k + lane, hi);
+      row_pass < ND, CLS, false > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   }
 }
 
@@ -376,16 +368,14 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
         const int sx = fx[r] + 4 * seg * (1 << prec), sy = fy[r] + row * (1 << prec);
         const int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
         const int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
-        const uint8_t *r0 = refs[r] + hp_row_offset (clampi (hy, 0, 2 * job.h - 2), job.ref_stride[r]);
-        const uint8_t *r1 = refs[r] + hp_row_offset (clampi (hy + 1, 0, 2 * job.h - 2), job.ref_stride[r]);
+        const int Y0 = clampi (hy, 0, 2 * job.h - 2), Y1 = clampi (hy + 1, 0, 2 * job.h - 2);
         int p0[9], p1[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) {
           const int X = clampi (hx + j, 0, 2 * job.w - 2);
-          const int col = (X >> 4) * 128 + (X & 15);
           const bool need = (j & 1) == 0 || rx != 0;
-          p0[j] = need ? (int) gload < uint8_t > (r0 + col) : 0;
-          p1[j] = need && ry != 0 ? (int) gload < uint8_t > (r1 + col) : 0;
+          p0[j] = need ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y0, job.ref_stride[r])) : 0;
+          p1[j] = need && ry != 0 ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y1, job.ref_stride[r])) : 0;
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -478,11 +468,10 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
         av[2] = __builtin_amdgcn_alignbit (w3, w2, 16);
         av[3] = __builtin_amdgcn_alignbit (w4, w3, 16);
       } else {
-        const u32x4 a = *reinterpret_cast < const u32x4 * >(ap);
-        av[0] = a.x;
-        av[1] = a.y;
-        av[2] = a.z;
-        av[3] = a.w;
+        av[0] = ap[0];          // (rows are an odd number of words apart: no 16-byte reads)
+        av[1] = ap[1];
+        av[2] = ap[2];
+        av[3] = ap[3];
       }
       const int x = x_lo + 8 * g;
       const u32x4 r = res[n];
@@ -567,7 +556,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 
   const int xblen = job.xblen, yblen = job.yblen;
   const int par = job.xoff & 1;         // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
-  const int npair = xblen >> 1;
   const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
   int nblk;
   {
@@ -580,7 +568,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
     nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
     const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
-    const int gw = 2 * job.w - 2, gh = 2 * job.h - 2;   // last valid half-pel sample column / row
+    const int gh = 2 * job.h - 2;       // last valid half-pel sample row
     // the motion vectors of the first round start their way from memory beside the set-up
     uint32_t mv_pre[3] = { 0u, 0u, 0u };
     if (tid < nblk) {
@@ -595,7 +583,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     // 2 * ND words, zero beyond the block's width
     for (int i = tid; i < yblen * 2 * ND && i < kRWCap; i += kRThreads) {
       const int r = i / (2 * ND), pr = i - r * (2 * ND);
-      s_wp[i] = pr < npair ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
+      s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
     }
     // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
     // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
@@ -645,59 +633,61 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
       info.dcs = (int) (((uint32_t) pdc & 0xffffu) | ((uint32_t) pdc_b << 16));
       info.flags = mode;
-      int phases = 0, ry[2] = { 0, 0 }, off_abs[2] = { 0, 0 };
-      bool clamped_h = false, clamped_v = false;
+      int ry[2] = { 0, 0 };
+      RowRef in_ref[2], edge_ref[2];    // the window as the row classes / the edge class address it
+      bool off_h = false, clamped_v = false;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         int fx, fy;
         mv_origin (job, bx, by, v01, v23, r, &fx, &fy);
-        int gx0 = fx, gy0 = fy, rx = 0;
-        if (prec >= 2) {
-          const int x8 = prec == 2 ? fx * 2 : fx, y8 = prec == 2 ? fy * 2 : fy;
-          rx = x8 & 3;
-          ry[r] = y8 & 3;
-          gx0 = x8 >> 2;
-          gy0 = y8 >> 2;
-        }
-        // both bilinear taps of every sample of the block (conservative for integer positions)
-        const int gx1 = gx0 + 2 * xblen - 1, gy1 = gy0 + 2 * (yblen - 1) + 1;
-        // columns: the window inside the image, every 16-byte tile row a lane may fetch inside the
-        // row pitch (and the packed form of the edge class wide enough)
-        const bool in_h = gx0 >= 0 && gx1 <= gw && (gx0 & ~15) + 16 * (((gx0 & 15) + 2 * xblen + 15) >> 4) <= job.ref_stride[r]
-            && ((gx0 & ~15) << 3) < (1 << 17) && (unsigned) (gy0 + 16384) < 32768u;
-        const bool in_v = gy0 >= 0 && gy1 <= gh;
+        // half-pel origin and quarter phases (prec 1: half-pel units; prec 2: quarter-pel units)
+        const int hx = prec >= 2 ? fx >> 1 : fx, hy = prec >= 2 ? fy >> 1 : fy;
+        const int rx = prec >= 2 ? fx & 1 : 0;
+        ry[r] = prec >= 2 ? fy & 1 : 0;
         const bool used = (mode & (r + 1)) != 0;
-        clamped_h |= used && !in_h;
+        // columns: get_block's clamp keeps every window inside the aprons (32 pixels either side); the
+        // test is a guard, not a case
+        const int xp = (hx >> 1) + kHpApron, px = hx & 1, py = hy & 1;
+        const bool in_h = xp >= 0 && (xp >> 4) < (job.ref_stride[r] >> 9) && (unsigned) (hy + 16384) < 32768u;
+        // rows: both taps of every sample row of the block inside the image, else clamped row by row
+        const bool in_v = hy >= 0 && hy + 2 * (yblen - 1) + 1 <= gh;
+        off_h |= used && !in_h;
         clamped_v |= used && !in_v;
-        const bool inside = in_h && in_v;
-        info.off[r] = inside ? (gy0 >> 4) * (16 * job.ref_stride[r]) + ((gx0 & ~15) << 3) : 0;
-        off_abs[r] = in_h && used ? (int) (((uint32_t) gy0 << 17) | (uint32_t) ((gx0 & ~15) << 3)) : 0;
-        phases |= in_h ? ((inside ? gy0 & 15 : 0) | ((gx0 & 15) << 4)) << (8 * r) : 0;
-        info.flags |= ((rx ? 1 : 0) | (ry[r] ? 2 : 0)) << (6 + 2 * r);
+        const int colbase = in_h && used ? (xp >> 4) * 512 + (xp & 15) + px * 128 : 0;
+        const uint32_t dB = in_h && used && rx ? (uint32_t) (px ? 1 - 128 : 128) : 0u;
+        in_ref[r].base = colbase + (in_h && used ? py * 256 : 0);
+        in_ref[r].ydb = (in_h && in_v && used ? (uint32_t) (hy >> 1) : 0u) | (dB << 16);
+        in_ref[r].dci = in_h && used && ry[r] ? (py ? (int) (((uint32_t) -256 << 16) | 1u) : (int) (256u << 16)) : 0;
+        edge_ref[r].base = colbase;
+        edge_ref[r].ydb = (in_h && used ? (uint32_t) hy & 0xffffu : 0u) | (dB << 16);
+        edge_ref[r].dci = 0;
+        info.flags |= (in_h && used && ry[r] ? 1 : 0) << (6 + r);
       }
+      info.r[0] = in_ref[0];
+      info.r[1] = in_ref[1];
       const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
-      info.rows = ra | ((rb - ra) << 8) | (phases << 16);
+      info.rows = ra | ((rb - ra) << 8);
       // weights fold where the block hangs over the picture's rim: top | bottom << 1 | left << 2 | right << 3
       const int fold = (by < yoff ? 1 : 0) | (by + yblen > yfold_hi ? 2 : 0) | (bx < xoff ? 4 : 0) | (bx + xblen > xfold_hi ? 8 : 0);
       const bool wide_dc = mode == 0 && ((unsigned) pdc > 255u || (unsigned) pdc_b > 255u);
       if (wide_dc)
         s_wide = 1;
       int key;
-      if (clamped_h || wide_dc || yblen * 2 * ND > kRWCap || xblen > 16) {
+      if (off_h || wide_dc || yblen * 2 * ND > kRWCap || xblen > 16) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
         // (16 bits each: obmc_row_nd keeps planes whose origins do not fit away from this kernel)
         int fx, fy;
         mv_origin (job, bx, by, v01, v23, 0, &fx, &fy);
-        info.off[0] = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
+        info.r[0].base = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
         mv_origin (job, bx, by, v01, v23, 1, &fx, &fy);
-        info.off[1] = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
+        info.r[1].base = (int) (((uint32_t) fx & 0xffffu) | ((uint32_t) fy << 16));
         s_rim[atomicAdd (&s_nrim, 1)] = (uint16_t) blk;
       } else if (fold || clamped_v) {
         // still a row per lane: sample rows clamped one by one, weights from the folded tables
         key = kREdge;
-        info.off[0] = off_abs[0];
-        info.off[1] = off_abs[1];
+        info.r[0] = edge_ref[0];
+        info.r[1] = edge_ref[1];
         info.flags |= fold << 2;
       } else if (mode == 3) {
         key = 0;
@@ -762,7 +752,15 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       __builtin_amdgcn_sched_barrier (0);
     }
     int turn = 0;
-#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, io, s_item, s_hot, s_wp, acc, par, npair, \
+    // the references as buffers of whole bands of 4 plane rows (schro_hip_internal.h)
+    RowRefs refs;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      refs.stride[r] = (uint32_t) job.ref_stride[r];
+      refs.rsrc[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[r], 0,
+          (int) ((uint32_t) job.ref_stride[r] * (uint32_t) ((job.h + 3) >> 2)), 0x00020000);
+    }
+#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
     ibase[C], ibase[C + 1], exact, &turn)
     SCHRO_ROW_CLASS (0);
     SCHRO_ROW_CLASS (1);
@@ -786,7 +784,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         const int y = by + r2, xs = bx + 4 * s2;
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
-        const int fx[2] = { (int) (int16_t) hb.off[0], (int) (int16_t) hb.off[1] }, fy[2] = { hb.off[0] >> 16, hb.off[1] >> 16 };
+        const int fx[2] = { (int) (int16_t) hb.r[0].base, (int) (int16_t) hb.r[1].base }, fy[2] = { hb.r[0].base >> 16, hb.r[1].base >> 16 };
         const int md = (hb.flags & 3) | (blk_dc (hb, pl) << 8);
         if (job.prec == 1)
           row_slow < 1 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
@@ -900,7 +898,9 @@ obmc_row_nd (const ObmcJob & j)
     return 0;
   // the blocks that can meet a 128x32 tile and their rows inside it fit the kernel's tables
   const int nbi = (kRTW - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
-  if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1]) | (uintptr_t) j.ref_stride[0] | (uintptr_t) j.ref_stride[1]) & 15)
+  if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1])) & 127)
+    return 0;
+  if (((j.ref_stride[0] | j.ref_stride[1]) & 511) || j.ref_stride[0] < hp_chunks (j.w) * 512 || j.ref_stride[1] < hp_chunks (j.w) * 512)
     return 0;
   const int need = (j.xblen + 3) / 4, nd = need <= 2 ? 2 : need;        // 2, 3 or 4
   const int blk_cap = nd <= 2 ? RowCaps < 2 >::kBlk : RowCaps < 3 >::kBlk;

@@ -219,23 +219,48 @@ div_magic (int d)
   return d <= 1 ? 0u : (uint32_t) ((0x100000000ull + (uint32_t) d - 1) / (uint32_t) d);
 }
 
-// Half-pel images (include/schro_hip.h): one 128-byte line = 16 bytes of each of 8 rows OF THE
-// SAME PARITY.  A band of 16 rows takes two tile rows (8 * stride bytes each), the even rows
-// first; row y sits in slot (y >> 1) & 7 of its tile row.
-constexpr int kHpBand = 16;     // rows per band; images hold whole bands
+// Half-pel images (include/schro_hip.h), r03 layout.  The four planes of the reference's upsampled
+// frame (integer, h-half, v-half, hv-half: plane = (X & 1) + 2 * (Y & 1) of half-pel sample (X, Y))
+// are kept apart, so a block row's prediction samples are CONTIGUOUS bytes of one plane (no
+// even / odd split in the kernel) and a tap the block's phase does not use is never fetched.
+// A plane row is stored as 32-byte chunks that advance by 16 columns -- every column sits in two
+// chunks -- so any run of up to 17 bytes starts inside some chunk and ends inside the same one: a
+// lane fetches its row with ONE byte-aligned load, no alignment or phase-select instructions.  One
+// 128-byte line = the same chunk of 4 consecutive rows of one plane; the lines of the four planes
+// of a (band of 4 rows, chunk) are adjacent (512 bytes), so the other taps of a window are at
+// +-128 / +-256 bytes.  kHpApron replicated columns lie in front of column 0 and behind the last
+// one -- get_block clamps a block's origin to 32 pixels outside the picture (schromotion8.c:
+// 329-330) -- with the reference's sources (schroframe.c:2012-2029: planes 0 and 1 repeat plane
+// 0's edge, planes 2 and 3 plane 2's), which is the clamp of the half-pel column to [0, 2w - 2];
+// rows are clamped by the kernels.  `stride` = bytes per band of 4 rows = chunks * 512.
+constexpr int kHpApron = 32;
+constexpr int kHpBandRows = 4;
 
-// byte offset of the 16-byte tile row of row y in tile column 0
+__host__ __device__ __forceinline__ int
+hp_chunks (int w)
+{
+  return (w + 2 * kHpApron + 15) / 16 + 1;
+}
+
+// padded column xp (= plane column + kHpApron) inside its band: chunk xp >> 4, byte xp & 15 (the
+// same column is also byte 16 + (xp & 15) of chunk (xp >> 4) - 1)
+__host__ __device__ __forceinline__ size_t
+hp_col_offset (int xp)
+{
+  return (size_t) (xp >> 4) * 512 + (size_t) (xp & 15);
+}
+
 __host__ __device__ __forceinline__ size_t
 hp_row_offset (int y, int stride)
 {
-  return ((size_t) (y >> 4) * 2 + (size_t) (y & 1)) * 8 * (size_t) stride + (size_t) (((y >> 1) & 7) * 16);
+  return (size_t) (y >> 2) * (size_t) stride + (size_t) ((y & 3) * 32);
 }
 
-// byte offset of half-pel sample (x, y)
+// byte offset of half-pel sample (X, Y), 0 <= X <= 2w - 1, 0 <= Y <= 2h - 1
 __host__ __device__ __forceinline__ size_t
-hp_offset (int x, int y, int stride)
+hp_offset (int X, int Y, int stride)
 {
-  return hp_row_offset (y, stride) + (size_t) (x >> 4) * 128 + (size_t) (x & 15);
+  return hp_row_offset (Y >> 1, stride) + hp_col_offset ((X >> 1) + kHpApron) + (size_t) (((X & 1) + 2 * (Y & 1)) * 128);
 }
 
 __device__ __forceinline__ int
@@ -309,10 +334,6 @@ void dequant_tile_geometry (int *tw, int *th);
 void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t * offset);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order);
-// staged kernel (obmc_stage.hip): prediction dwords per block row, 0 = geometry not supported
-int obmc_stage_nd (const ObmcJob & job);
-int launch_obmc_stage (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
-    const uint32_t * d_order);
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
 int obmc_row_nd (const ObmcJob & job);
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,

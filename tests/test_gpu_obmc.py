@@ -190,14 +190,15 @@ def test_rotating_references_in_a_batch(ctx):
             assert np.array_equal(out.download(), want), "rotation %d plane %d" % (rot, n)
 
 
-def test_staged_kernel_parity_in_a_child_process():
-    # obmc_stage.hip (opt-in: SCHRO_HIP_OBMC_KERNEL=staged, read once per process) runs the
-    # default-weight cases of this file -- all chroma formats, block sets, precisions 1-3, near
-    # and far vectors, DC values outside 8 bits -- in a child process, against the same oracle
+def test_item_kernel_parity_in_a_child_process():
+    # obmc.hip's item kernel -- the second formulation of the default-weight case, the default for
+    # plain and eighth-pel references only -- takes every case (SCHRO_HIP_OBMC_KERNEL=item, read
+    # once per process): all chroma formats, block sets, precisions 1-3, near and far vectors, DC
+    # values outside 8 bits, in a child process against the same oracle
     import os
     import subprocess
     import sys
-    env = dict(os.environ, SCHRO_HIP_OBMC_KERNEL="staged")
+    env = dict(os.environ, SCHRO_HIP_OBMC_KERNEL="item")
     here = os.path.abspath(__file__)
     p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
                         "test_default_weights or test_dc_values or test_rotating"],
