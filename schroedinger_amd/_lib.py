@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libschro_hip.so")
+# SCHRO_HIP_LIB: another build of the same library (A/B runs of kernel variants on the GPU box)
+LIB_PATH = os.environ.get("SCHRO_HIP_LIB") or os.path.join(_HERE, "libschro_hip.so")
 
 # every extern "C" symbol include/schro_hip.h declares
 EXPORTED_SYMBOLS = [

@@ -53,9 +53,20 @@ template < int ND > struct RowCaps {
   static constexpr int kBlk = ND <= 2 ? 352 : 128, kItem = ND <= 2 ? 1792 : 1024;
 };
 constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
-constexpr int kRCls = 8;                // 0 both references, 1-2 the first (ry 0 / 1), 3-4 the second, 5 DC, 6 edge, 7 rim
-constexpr int kREdge = kRCls - 2;       // windows clamped vertically and / or folded weights, any mode: still a row per lane
-constexpr int kRRim = kRCls - 1;        // DC values outside 8 bits, geometries beyond the weight table: per sample
+// Item classes (one straight-line pass body each): both references / the first / the second / DC /
+// edge (windows clamped vertically and / or folded weights, any mode: still a row per lane) / rim (DC
+// values outside 8 bits, geometries beyond the weight table: per sample).  Inside the reference
+// classes the items are SORTED by which taps their windows need -- slot = class base + (X + 1 tap |
+// Y + 1 taps << 1) per reference -- so the 64 items of a pass mostly agree, and a pass fetches a tap
+// only if one of its lanes needs it (wave-uniform branches on ballots): at quarter pel a window
+// needs 1, 2 or 4 of the 4 taps with probability 1/4, 1/2, 1/4.
+constexpr int kRBoth = 0, kRRef0 = 1, kRRef1 = 2, kRDc = 3, kREdge = 4, kRRim = 5;
+constexpr int kRSlots = 16 + 4 + 4 + 3;
+__host__ __device__ constexpr int
+row_slot_base (int cls)
+{
+  return cls == kRBoth ? 0 : cls == kRRef0 ? 16 : cls == kRRef1 ? 20 : cls == kRDc ? 24 : cls == kREdge ? 25 : 26;
+}
 
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
@@ -150,28 +161,57 @@ acc_word (uint32_t * acc, int par, int x, int y, int *half)
 }
 
 // ---- one reference's prediction of a block row: ND dwords of 4 pixels ---------------------
-// ND dwords from byte offset `off` of the reference (any alignment; beyond the buffer: zeros)
+// ND dwords from byte offset `off` of the reference (any alignment; beyond the buffer: zeros).
+// The load itself is dword-aligned and one dword longer, the bytes are shifted into place with
+// v_alignbyte: a byte-aligned load of n dwords takes the texture path n times as long as a
+// dword-aligned one (scripts/ta_rate_bench.hip: 16 / 48 cycles per wave for 12 bytes per lane), and
+// with one such load per tap the passes were bound by exactly that (TA busy 76 %).
+template < int ND > struct RawRun {
+  uint32_t c[ND + 1];           // the dwords from the dword-aligned address on
+  uint32_t sh;                  // where the run starts in the first one
+};
+
 template < int ND >
 __device__ __forceinline__ void
-load_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, uint32_t * d)
+issue_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, RawRun < ND > &r)
 {
+  const uint32_t al = off & ~3u;
+  r.sh = off & 3u;
+#ifdef SCHRO_ROW_DBG_NOLOAD     // (scratch builds: what the passes cost without their memory traffic)
+  for (int k = 0; k <= ND; k++)
+    r.c[k] = al + k;
+  return;
+#endif
   if constexpr (ND == 2) {
-    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) off, 0, 0);
-    d[0] = q.x;
-    d[1] = q.y;
-  } else if constexpr (ND == 3) {
     typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
-    const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) off, 0, 0);
-    d[0] = q.x;
-    d[1] = q.y;
-    d[2] = q.z;
+    const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) al, 0, 0);
+    r.c[0] = q.x;
+    r.c[1] = q.y;
+    r.c[2] = q.z;
+  } else if constexpr (ND == 3) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, 0);
+    r.c[0] = q.x;
+    r.c[1] = q.y;
+    r.c[2] = q.z;
+    r.c[3] = q.w;
   } else {
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) off, 0, 0);
-    d[0] = q.x;
-    d[1] = q.y;
-    d[2] = q.z;
-    d[3] = q.w;
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, 0);
+    const u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al + 16, 0, 0);       // (8 bytes: as fast as 4)
+    r.c[0] = q.x;
+    r.c[1] = q.y;
+    r.c[2] = q.z;
+    r.c[3] = q.w;
+    r.c[4] = q2.x;
   }
+}
+
+template < int ND >
+__device__ __forceinline__ void
+align_run (const RawRun < ND > &r, uint32_t * d)
+{
+#pragma unroll
+  for (int k = 0; k < ND; k++)
+    d[k] = __builtin_amdgcn_alignbyte (r.c[k + 1], r.c[k], r.sh);
 }
 
 // byte offset of plane row y inside the image: band (4 rows) * stride + 32 * row in the band
@@ -181,35 +221,72 @@ row_ofs (uint32_t y, uint32_t stride)
   return __umul24 (y >> 2, stride) + ((y & 3u) << 5);
 }
 
-// RY: the class may hold windows at a vertical quarter position (four taps); else two taps (the
-// window's own plane and the X + 1 plane).  A tap the window's phase does not use has the first
-// tap's address (dB / dC 0): the same line again, and lerp (a, a) = a.
+// A tap the window's phase does not use has the first tap's address (dB / dC 0): the same line
+// again, and lerp (a, a) = a -- and is not fetched at all when no lane of the pass uses it (the items
+// are sorted by that, see the slots).
 // ABS (edge class): rr.ydb holds the window's first HALF-PEL row, signed, and every sample row is
 // clamped to the image on its own (fetch_ref's CLAMP on y): the row's parity picks the plane
-template < int ND, bool RY, bool ABS = false >
+template < int ND, bool ABS = false >
 __device__ __forceinline__ void
 predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, const RowRef & rr, uint32_t ry, int row, uint32_t * out)
 {
   const int dB = (int) rr.ydb >> 16;
   uint32_t offA, offC = 0;
+  bool any_b, any_c;
   if constexpr (ABS) {
     const int hy = (int) (int16_t) (rr.ydb & 0xffffu) + 2 * row, gh = 2 * job.h - 2;
     const uint32_t Y0 = (uint32_t) clampi (hy, 0, gh), Y1 = (uint32_t) clampi (hy + (int) ry, 0, gh);
     offA = (uint32_t) rr.base + ((Y0 & 1u) << 8) + row_ofs (Y0 >> 1, stride);
     offC = (uint32_t) rr.base + ((Y1 & 1u) << 8) + row_ofs (Y1 >> 1, stride);
+    any_b = any_c = true;
   } else {
     const uint32_t y = (rr.ydb & 0xffffu) + (uint32_t) row;
     offA = (uint32_t) rr.base + row_ofs (y, stride);
-    if constexpr (RY)
+#ifdef SCHRO_ROW_ALL_TAPS       // (A/B builds: every pass fetches four taps)
+    any_b = any_c = true;
+#else
+    any_b = __ballot (dB != 0) != 0;
+    any_c = __ballot (rr.dci != 0) != 0;
+#endif
+    if (any_c)
       offC = (uint32_t) (rr.base + (rr.dci >> 16)) + row_ofs (y + ((uint32_t) rr.dci & 1u), stride);
   }
-  uint32_t a[ND], b[ND];
-  load_run < ND > (ref, offA, a);
-  load_run < ND > (ref, offA + (uint32_t) dB, b);
-  if constexpr (RY || ABS) {
-    uint32_t c[ND], d[ND];
-    load_run < ND > (ref, offC, c);
-    load_run < ND > (ref, offC + (uint32_t) dB, d);
+  // every load of the pass goes out before the first result is touched (a use in front of a branch
+  // makes the compiler wait there: two round trips per reference instead of one)
+  RawRun < ND > qa, qb, qc, qd;
+  issue_run < ND > (ref, offA, qa);
+  if (any_b)
+    issue_run < ND > (ref, offA + (uint32_t) dB, qb);
+  if (any_c) {
+    issue_run < ND > (ref, offC, qc);
+    if (any_b)
+      issue_run < ND > (ref, offC + (uint32_t) dB, qd);
+  }
+  uint32_t a[ND];
+  align_run < ND > (qa, a);
+  if (!any_c) {
+    if (!any_b) {
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        out[k] = a[k];
+    } else {
+      uint32_t b[ND];
+      align_run < ND > (qb, b);
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        out[k] = lerp1 (a[k], b[k]);
+    }
+  } else if (!any_b) {
+    uint32_t c[ND];
+    align_run < ND > (qc, c);
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      out[k] = lerp1 (a[k], c[k]);      // (a + a + c + c + 2) >> 2
+  } else {
+    uint32_t b[ND], c[ND], d[ND];
+    align_run < ND > (qb, b);
+    align_run < ND > (qc, c);
+    align_run < ND > (qd, d);
 #pragma unroll
     for (int k = 0; k < ND; k++) {
       // per byte (a + b + c + d + 2) >> 2 exactly: with c1 = (a+b+1)>>1, c2 = (c+d+1)>>1 and l = the
@@ -217,15 +294,10 @@ predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, c
       const uint32_t h0 = lerp1 (a[k], b[k]), h1 = lerp1 (c[k], d[k]);
       out[k] = __builtin_amdgcn_lerp (h0, h1, ~((a[k] ^ b[k]) | (c[k] ^ d[k])));
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < ND; k++)
-      out[k] = lerp1 (a[k], b[k]);
   }
 }
 
 // one pass: every lane predicts one (block, row) item and adds it into the accumulator tile
-// CLS 0 both references, 1-2 the first (two / four taps), 3-4 the second, 5 DC, 6 edge
 struct RowRefs {
   __amdgpu_buffer_rsrc_t rsrc[2];       // the plane's references as buffers: whole bands of 4 rows
   uint32_t stride[2];
@@ -236,22 +308,24 @@ __device__ __forceinline__ void
 row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlk * s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int it, int hi)
 {
-  const bool st = CLS == 0 && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
+#ifdef SCHRO_ROW_STAMPS
+  const bool st = CLS == kRBoth && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
   const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
+#endif
   const int e = s_item[min (it, hi - 1)];
   const RowBlk & hb = s_hot[e & 0x1ff];
   const int row = e >> 9;
   uint32_t p[ND];
-  if constexpr (CLS == 5) {
+  if constexpr (CLS == kRDc) {
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = (uint32_t) blk_dc (hb, pl) * 0x01010101u;
   } else if constexpr (CLS == kREdge) {
     // any mode: both references are read (an unused one at offset 0) and the mode selects
     uint32_t p1[ND];
-    predict_row < ND, true, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
+    predict_row < ND, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
     __builtin_amdgcn_sched_barrier (0);
-    predict_row < ND, true, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
+    predict_row < ND, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
     const uint32_t mode = (uint32_t) hb.flags & 3u;
     const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
@@ -260,23 +334,24 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
       const uint32_t a = (p[k] & m0) | (p1[k] & ~m0), b = (p1[k] & m1) | (p[k] & ~m1);  // one reference: average it with itself
       p[k] = mode ? lerp1 (a, b) : dc;
     }
-  } else if constexpr (CLS == 0) {
+  } else if constexpr (CLS == kRBoth) {
     uint32_t p1[ND];
-    predict_row < ND, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], 0u, row, p);
-    __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight
-    predict_row < ND, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], 0u, row, p1);
+    predict_row < ND > (job, refs.rsrc[0], refs.stride[0], hb.r[0], 0u, row, p);
+    __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight (both at once: measured slower)
+    predict_row < ND > (job, refs.rsrc[1], refs.stride[1], hb.r[1], 0u, row, p1);
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
   } else {
-    constexpr int r = CLS >= 3 ? 1 : 0;
-    constexpr bool RY = CLS == 2 || CLS == 4;
-    predict_row < ND, RY > (job, refs.rsrc[r], refs.stride[r], hb.r[r], 0u, row, p);
+    constexpr int r = CLS == kRRef1 ? 1 : 0;
+    predict_row < ND > (job, refs.rsrc[r], refs.stride[r], hb.r[r], 0u, row, p);
   }
+#ifdef SCHRO_ROW_STAMPS
   if (st) {
     asm volatile ("" :: "v" (p[0]));
     job.stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime () - t0;
   }
+#endif
   if (it >= hi)
     return;
   int half;
@@ -309,13 +384,19 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
       acc_add_exact (aw + k, 0, v & 0xffffu);
       acc_add_exact (aw + k, 1, v >> 16);
     } else {
+#ifdef SCHRO_ROW_DBG_NOACC      // (scratch builds: the passes without the LDS atomics)
+      asm volatile ("" :: "v" (v), "v" (aw));
+#else
       atomicAdd (aw + k, v);    // sums of pred * weight <= 255 * 64: no carry between the halves
+#endif
     }
   }
+#ifdef SCHRO_ROW_STAMPS
   if (st) {
     __builtin_amdgcn_s_waitcnt (0);
     job.stamps[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime () - t0;
   }
+#endif
 }
 
 // the passes of one class; *turn counts the passes of the classes before it, so that the four
@@ -519,11 +600,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
   constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
-  __shared__ uint16_t s_meta[kRBlkCap];         // class | first item within the class << 4
+  __shared__ uint16_t s_meta[kRBlkCap];         // slot | first item within the slot << 5
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
   __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap + 32 + 128];      // + folded x pairs, folded y (edge class)
-  __shared__ int s_icnt[kRCls];                 // items of each class
+  __shared__ int s_icnt[kRSlots];               // items of each slot
   __shared__ int s_nrim, s_wide;
 
   const uint64_t t_start = __builtin_amdgcn_s_memtime ();
@@ -547,7 +628,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
   if (tid >= 64 && tid - 64 < job.yblen)
     s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
-  if (tid >= 128 && tid < 128 + kRCls)
+  if (tid >= 128 && tid < 128 + kRSlots)
     s_icnt[tid - 128] = 0;
   if (tid == 192) {
     s_nrim = 0;
@@ -690,35 +771,50 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         info.r[1] = edge_ref[1];
         info.flags |= fold << 2;
       } else if (mode == 3) {
-        key = 0;
+        key = kRBoth;
       } else if (mode == 0) {
-        key = 5;
+        key = kRDc;
       } else {
-        key = mode == 1 ? 1 + (ry[0] ? 1 : 0) : 3 + (ry[1] ? 1 : 0);
+        key = mode == 1 ? kRRef0 : kRRef1;
       }
+      // which taps the windows need: the slot inside the class
+      const int taps0 = (in_ref[0].ydb >> 16 ? 1 : 0) | (in_ref[0].dci ? 2 : 0), taps1 = (in_ref[1].ydb >> 16 ? 1 : 0) | (in_ref[1].dci ? 2 : 0);
+      const int slot = row_slot_base (key) + (key == kRBoth ? taps0 | (taps1 << 2) : key == kRRef0 ? taps0 : key == kRRef1 ? taps1 : 0);
       s_hot[blk] = info;
       // the block's rows take the next free items of its class (any order within a class will do)
-      const int istart = key == kRRim ? 0 : atomicAdd (&s_icnt[key], rb - ra);
-      s_meta[blk] = (uint16_t) (key | (istart << 4));
+      const int istart = key == kRRim ? 0 : atomicAdd (&s_icnt[slot], rb - ra);
+      s_meta[blk] = (uint16_t) (slot | (istart << 5));
     }
   }
   __syncthreads ();
   RSTAMP (2);
-  int ibase[kRCls];             // first item of each class
-  ibase[0] = 0;
+  // first item of each slot: lane l of every wave scans the counters (no further barrier)
+  int sbase;
+  {
+    const int lane = tid & 63;
+    const int cnt = lane < kRSlots ? s_icnt[lane] : 0;
+    int incl = cnt;
 #pragma unroll
-  for (int k = 0; k + 1 < kRCls; k++)
-    ibase[k + 1] = ibase[k] + __builtin_amdgcn_readfirstlane (s_icnt[k]);
-  for (int blk = tid; blk < nblk; blk += kRThreads) {
-    const int meta = s_meta[blk], key = meta & 15;
-    if (key == kRRim)
+    for (int d = 1; d < 32; d <<= 1) {
+      const int up = __shfl_up (incl, d);
+      if (lane >= d)
+        incl += up;
+    }
+    sbase = incl - cnt;
+  }
+  int ibase[kRRim + 1];         // first item of each class
+#pragma unroll
+  for (int c = 0; c <= kRRim; c++)
+    ibase[c] = __builtin_amdgcn_readlane (sbase, row_slot_base (c));
+  for (int b0 = 0; b0 < nblk; b0 += kRThreads) {       // (every lane takes part in the shuffle)
+    const int blk = b0 + tid;
+    const bool have = blk < nblk;
+    const int meta = have ? s_meta[blk] : 0, slot = meta & 31;
+    const int ib = __shfl (sbase, slot);
+    if (!have || slot == row_slot_base (kRRim))
       continue;
-    int ib = 0;
-#pragma unroll
-    for (int k = 0; k < kRCls; k++)
-      ib = key == k ? ibase[k] : ib;
     const int rows = s_hot[blk].rows, ra = rows & 0xff, n = (rows >> 8) & 0xff;
-    uint16_t *ip = s_item + ib + (meta >> 4);
+    uint16_t *ip = s_item + ib + (meta >> 5);
     for (int r = 0; r < n; r++)
       ip[r] = (uint16_t) (blk | ((ra + r) << 9));
   }
@@ -760,16 +856,19 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       refs.rsrc[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[r], 0,
           (int) ((uint32_t) job.ref_stride[r] * (uint32_t) ((job.h + 3) >> 2)), 0x00020000);
     }
+#ifdef SCHRO_ROW_DBG_NOPASS     // (scratch builds: everything but the passes)
+    if (job.w < 0)
+#endif
+    {
 #define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
     ibase[C], ibase[C + 1], exact, &turn)
-    SCHRO_ROW_CLASS (0);
-    SCHRO_ROW_CLASS (1);
-    SCHRO_ROW_CLASS (2);
-    SCHRO_ROW_CLASS (3);
-    SCHRO_ROW_CLASS (4);
-    SCHRO_ROW_CLASS (5);
-    SCHRO_ROW_CLASS (6);
+    SCHRO_ROW_CLASS (kRBoth);
+    SCHRO_ROW_CLASS (kRRef0);
+    SCHRO_ROW_CLASS (kRRef1);
+    SCHRO_ROW_CLASS (kRDc);
+    SCHRO_ROW_CLASS (kREdge);
 #undef SCHRO_ROW_CLASS
+    }
     RSTAMP (4);
     // picture-rim blocks: exact clamp / fold path
     if (nrim > 0) {
@@ -817,12 +916,12 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #undef RSTAMP
 }
 
-// Waves per SIMD: as many workgroups per CU as fit -- throughput grows with every resident
-// workgroup until vector issue saturates (luma, workgroups per CU -> tiles per 1000 cycles per CU:
-// 2 0.093, 3 0.130, 4 0.157, 5 0.171, 6 0.186; seven need 72 registers and spill).  The 12-pixel
-// row fits 80 registers since the class loops run on scalar registers: six waves per SIMD for luma
-// (18.6 KB of LDS) and, with 24-byte block records and tables of 352 blocks / 1792 items
-// (26.4 KB), for the 6-pixel-row kernels (chroma) too.
+// Waves per SIMD: as many workgroups per CU as fit.  r03 (luma, workgroups per CU by LDS padding ->
+// ms per 8 x 2160p luma launch): 2 0.278, 3 0.211, 4 0.180, 5 0.162, 6 0.153, 7 0.148 -- a saturating
+// curve: the launch is no longer waiting for anything in particular (compiled-out stages: everything
+// but the passes 0.056, the passes' arithmetic 0.044, their loads 0.047, the LDS atomics 0.009 ms).
+// The 12-pixel-row kernel takes 72 registers: seven waves per SIMD at 20.9 KB of LDS; the
+// 6-pixel-row kernels (chroma: 352 blocks of 40 bytes, 32 KB) run five workgroups per CU.
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
@@ -835,7 +934,10 @@ void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const ui
   obmc_row_body < 2, 2 > (jobs, njobs, order);
 }
 
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
+#ifndef SCHRO_ROW_WPE_31
+#define SCHRO_ROW_WPE_31 7
+#endif
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WPE_31, SCHRO_ROW_WPE_31)))
 void obmc_row_kernel_3_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   obmc_row_body < 3, 1 > (jobs, njobs, order);
