@@ -237,75 +237,116 @@ def quantised_handover(h, w, depth, stride, seed):
     return np.concatenate(blob).view(np.uint8), cbs
 
 
-def pcie_inclusive_quantised(wl, steps=3):
-    """pcie_inclusive with device-side dequantisation: the host sends quantised
-    values of the non-zero codeblocks (one byte each here) + the codeblock records instead of
-    dense s16 coefficient frames; schro_hip_dequant_batch rebuilds the frames on the device."""
-    c, b = wl.ctx, wl.sets[0]
+class HostSide:
+    """The host's side of one picture batch for the PCIe-inclusive figures: coefficient planes (dense
+    hand-over) or quantised values + codeblock tables (quantised hand-over), motion vectors and the
+    output pictures, all in PINNED host memory (schro_hip_host_alloc: what a decoder whose frames come
+    from schro_memory_domain_new_hip_host () hands over), plus the device buffers of the quantised form."""
+
+    def __init__(self, wl, b, quantised, seed):
+        c = wl.ctx
+        self.mv = []
+        for m in b.mv_np:
+            h = c.host_array((1, m.nbytes), np.uint8)
+            h[...] = np.ascontiguousarray(m).view(np.uint8).reshape(1, -1)
+            self.mv.append(h)
+        self.out = [[c.host_array((o.height, o.width), np.uint8) for o in of] for of in b.out]
+        self.h2d = sum(m.nbytes for m in self.mv)
+        self.d2h = sum(o.nbytes for of in self.out for o in of)
+        self.co, self.hand = [], []
+        if not quantised:
+            for cf in b.coeff_np:
+                planes = []
+                for co in cf:
+                    h = c.host_array(co.shape, np.int16)
+                    h[...] = co
+                    planes.append(h)
+                    self.h2d += h.nbytes
+                self.co.append(planes)
+            return
+        for f in range(wl.frames):
+            for k, (h, w) in enumerate(wl.dims):
+                dst = b.iwt_pairs[3 * f + k][0]
+                blob, cbs = quantised_handover(h, w, DEPTH, dst.stride, seed + 3 * f + k)
+                hb = c.host_array((1, blob.size), np.uint8)
+                hb[...] = blob.reshape(1, -1)
+                # the C table is built once per picture geometry, not per step
+                self.hand.append((dst, hb, c.plane(1, blob.size, np.uint8), c.codeblock_table(cbs)))
+                self.h2d += hb.nbytes + 24 * len(cbs)
+
+
+def pcie_pipeline(wl, quantised, steps=12, warmup=4):
+    """The step with the host hand-over in it, as a three-stage pipeline on the context's four queues
+    (include/schro_hip.h, asynchronous transfers): batch k + 1's coefficients (dense s16 frames, or
+    quantised values for schro_hip_dequant_batch) and vectors go up on the H2D queue while batch k's
+    kernels run on a kernel queue and batch k - 1's pictures come down on the D2H queue; marks carry
+    the dependencies, the host thread never waits inside the loop.  Two batches' buffers."""
+    c = wl.ctx
     c.select_queue(0)
     c.synchronize()
-    hand = []
-    for f in range(wl.frames):
-        for k, (h, w) in enumerate(wl.dims):
-            dst = b.iwt_pairs[3 * f + k][0]
-            blob, cbs = quantised_handover(h, w, DEPTH, dst.stride, 900 + 3 * f + k)
-            hand.append((dst, blob.reshape(1, -1), c.plane(1, blob.size, np.uint8), cbs))
-    h2d = sum(bl.nbytes + 24 * len(cbs) for _, bl, _, cbs in hand) + sum(m.nbytes for m in b.mv_np)
-    d2h = sum(o.nbytes for of in b.out for o in of)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        for dst, bl, dev, cbs in hand:
-            dev.upload(bl)
+    nb = len(wl.sets)
+    hs = [HostSide(wl, b, quantised, 900 + 100 * i) for i, b in enumerate(wl.sets)]
+
+    def step(k):
+        i = k % nb
+        b, h = wl.sets[i], hs[i]
+        c.select_queue(c.QUEUE_H2D)
+        c.queue_wait_mark(8 + i)                # the kernels that last read this batch's inputs
+        if quantised:
+            for dst, hb, dev, tab in h.hand:
+                dev.upload_async(hb)
+        else:
+            n = 0
+            for f in range(wl.frames):
+                for kk in range(3):
+                    b.iwt_pairs[n][0].upload_async(h.co[f][kk])
+                    n += 1
         for f in range(wl.frames):
-            b.mv_dev[f].upload(np.ascontiguousarray(b.mv_np[f]).view(np.uint8).reshape(1, -1))
-        c.dequant_batch([(dst, dev, cbs, False) for dst, _, dev, cbs in hand], 0)
+            b.mv_dev[f].upload_async(h.mv[f])
+        c.queue_mark(i)
+        c.select_queue(k % 2)
+        c.queue_wait_mark(i)
+        c.queue_wait_mark(12 + i)               # the download that last read this batch's pictures
+        if quantised:
+            c.dequant_batch([(dst, dev, tab, False) for dst, _, dev, tab in h.hand], 0)
         c.upsample_batch(b.up_pairs)
         c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
         c.obmc_batch(b.obmc_jobs)
-        for of in b.out:
-            for o in of:
-                o.download()
-    dt = (time.perf_counter() - t0) / steps
-    dense = sum(co.nbytes for cf in b.coeff_np for co in cf)
-    for _, _, dev, _ in hand:
-        dev.free()
-    return {"ms_per_step": round(dt * 1e3, 3), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
-            "h2d_MB": round(h2d / 1e6, 1), "d2h_MB": round(d2h / 1e6, 1),
-            "share_of_dense_coefficient_bytes": round((h2d - sum(m.nbytes for m in b.mv_np)) / dense, 3),
-            "note": "synthetic quantised hand-over: up to 8x8 codeblocks per sub-band, 35-75 % of the finer "
-                    "levels' codeblocks zero, Laplacian values one byte each; host-side table packing "
-                    "(Python) is inside this figure; overwrites batch 0's coefficient frames"}
+        c.queue_mark(8 + i)
+        c.queue_mark(4 + i)
+        c.select_queue(c.QUEUE_D2H)
+        c.queue_wait_mark(4 + i)
+        for f in range(wl.frames):
+            for kk in range(3):
+                b.out[f][kk].download_async(h.out[f][kk])
+        c.queue_mark(12 + i)
 
-
-def pcie_inclusive(wl, steps=3):
-    """The same step with the host hand-over in it: coefficient frames and motion vectors go up
-    (dense s16 coefficients: what a core-syntax decoder without device-side dequantisation
-    uploads), the u8 pictures come down; pageable host memory, one queue."""
-    c, b = wl.ctx, wl.sets[0]
+    for k in range(warmup):
+        step(k)
     c.select_queue(0)
     c.synchronize()
-    h2d = sum(co.nbytes for cf in b.coeff_np for co in cf) + sum(m.nbytes for m in b.mv_np)
-    d2h = sum(o.nbytes for of in b.out for o in of)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        n = 0
-        for f in range(wl.frames):
-            for k in range(3):
-                b.iwt_pairs[n][0].upload(b.coeff_np[f][k])
-                n += 1
-        for f in range(wl.frames):
-            b.mv_dev[f].upload(np.ascontiguousarray(b.mv_np[f]).view(np.uint8).reshape(1, -1))
-        c.upsample_batch(b.up_pairs)
-        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
-        c.obmc_batch(b.obmc_jobs)
-        for of in b.out:
-            for o in of:
-                o.download()
+    for k in range(warmup, warmup + steps):
+        step(k)
+    c.select_queue(0)
+    c.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(dt * 1e3, 3), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
-            "h2d_MB": round(h2d / 1e6, 1), "d2h_MB": round(d2h / 1e6, 1),
-            "host_GBs": round((h2d + d2h) / dt / 1e9, 1),
-            "note": "pageable host buffers, synchronous 2-D copies, one queue; never `value`"}
+    # the pictures that came down are the ones the device holds
+    ok = all(np.array_equal(hs[0].out[0][kk], wl.sets[0].out[0][kk].download()) for kk in range(3))
+    res = {"ms_per_step": round(dt * 1e3, 3), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
+           "h2d_MB": round(hs[0].h2d / 1e6, 1), "d2h_MB": round(hs[0].d2h / 1e6, 1),
+           "host_GBs": round((hs[0].h2d + hs[0].d2h) / dt / 1e9, 1), "downloaded_equals_device": bool(ok),
+           "note": "pinned host buffers, asynchronous copies on their own queues (H2D / D2H) beside the kernels, "
+                   "marks for the dependencies; %d steps in steady state; never `value`" % steps}
+    if quantised:
+        dense = sum(co.nbytes for cf in wl.sets[0].coeff_np for co in cf)
+        res["share_of_dense_coefficient_bytes"] = round((hs[0].h2d - sum(m.nbytes for m in hs[0].mv)) / dense, 3)
+        res["note"] += ("; synthetic quantised hand-over: up to 8x8 codeblocks per sub-band, 35-75 % of the finer "
+                        "levels' codeblocks zero, Laplacian values one byte each; C codeblock tables built once; "
+                        "overwrites the batches' coefficient frames")
+        for _, _, dev, _ in [x for h in hs for x in h.hand]:
+            dev.free()
+    return res
 
 
 def free_port():
@@ -336,7 +377,8 @@ def spawn_ranks(n, argv, popen=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= rank processes) of this node; default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
@@ -347,11 +389,13 @@ def main():
                     help="only the timed workload: no CPU baseline, no 1080p / PCIe-inclusive extras "
                          "(profiler runs: every launch in the trace is a launch of the headline step)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
-    ap.add_argument("--profile-every", type=int, default=10,
+    ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket the launches of every n-th timed step with HIP events; such a step "
                          "runs alone on the device (no other batch beside it), so a kernel's duration "
                          "is its own")
     args = ap.parse_args()
+    if args.gpus is None:           # under a launcher the world size is the number of GPUs
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.
@@ -487,7 +531,7 @@ def main():
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
             out["iiwt_1080p"] = iiwt_1080p(ctx)
-            out["pcie_inclusive"] = pcie_inclusive(wl)
+            out["pcie_inclusive"] = pcie_pipeline(wl, quantised=False)
             # one batch at a time on one queue, every step timed by itself: median
             wl.queues = 1
             ts = []
@@ -508,7 +552,8 @@ def main():
                                    "port, gcc -O3" % (10 * cores, cores)}
             out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
         if world == 1 and not args.headline_only:
-            out["pcie_inclusive_quantised"] = pcie_inclusive_quantised(wl)
+            wl.queues = 2
+            out["pcie_inclusive_quantised"] = pcie_pipeline(wl, quantised=True)
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):
             sys.exit(1)

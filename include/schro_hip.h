@@ -72,6 +72,13 @@ void schro_hip_context_free (SchroHipContext * ctx);
 int schro_hip_device_count (void);
 const char *schro_hip_last_error (void);
 void schro_hip_set_abort_on_error (int enable);
+/* schro_cuda_init (schrocuda.h:8) twin: looks at the devices (SCHRO_HIP_DEBUG prints them) */
+void schro_hip_init (void);
+/* The calling thread becomes the exec-domain thread of `ctx` (NULL: of none): the alloc / free table
+ * of a SchroMemoryDomain carries no domain argument (schrodomain.h:18-22), so it serves the domain the
+ * calling THREAD is bound to -- and fails loudly on a thread bound to none.  schro_hip_context_new
+ * binds the creating thread; the scheduler's threads bind theirs. */
+void schro_hip_thread_bind (SchroHipContext * ctx);
 
 /* SchroMemoryDomain.alloc / .free (schrodomain.h:18-22) */
 void *schro_hip_domain_alloc (SchroHipContext * ctx, size_t size);
@@ -87,12 +94,28 @@ int schro_hip_download_2d (SchroHipContext * ctx, void *dst, int dst_stride,
     const void *src, int src_stride, int row_bytes, int height);
 int schro_hip_memset (SchroHipContext * ctx, void *dst, int value,
     size_t bytes);
+/* r03 -- asynchronous transfers (TODO-CUDA:5-7; the synchronous pattern of schrogpuframe.c:480-609).
+ * Pinned host memory is what the DMA engines copy from / to at full rate without the host thread:
+ * schro_hip_host_alloc for blobs, schro_memory_domain_new_hip_host () for the reference's frames
+ * (schro_frame_new_and_alloc (domain, ...) then hands out pinned host frames: ordinary host memory to
+ * every CPU stage).  The _async copies are enqueued on the SELECTED queue and not waited for; by
+ * convention uploads go to SCHRO_HIP_QUEUE_H2D and downloads to SCHRO_HIP_QUEUE_D2H, so that picture
+ * k + 1's coefficients go up and picture k - 1's pixels come down beside picture k's kernels on
+ * queues 0 / 1; marks order them (upload -> mark -> the wavelet's queue waits for it; OBMC -> mark ->
+ * the download queue waits for it); schro_hip_queue_synchronize waits for one queue. */
+void *schro_hip_host_alloc (size_t size);
+void schro_hip_host_free (void *ptr);
+int schro_hip_upload_2d_async (SchroHipContext * ctx, void *dst, int dst_stride,
+    const void *src, int src_stride, int row_bytes, int height);
+int schro_hip_download_2d_async (SchroHipContext * ctx, void *dst, int dst_stride,
+    const void *src, int src_stride, int row_bytes, int height);
+int schro_hip_queue_synchronize (SchroHipContext * ctx, int queue);
 /* waits for everything enqueued on both queues */
 int schro_hip_synchronize (SchroHipContext * ctx);
 /* the selected queue's hipStream_t, for hosts that enqueue their own work or events */
 void *schro_hip_stream (SchroHipContext * ctx);
 
-/* Two in-order queues per context.  The reference's scheduler runs the stages of different
+/* In-order queues per context (r03: four; 0 and 1 carry the kernels, 2 and 3 the copies).  The reference's scheduler runs the stages of different
  * pictures on several worker threads at once (schroasync-pthread.c:320-390,
  * schro_decoder_async_schedule, schrodecoder.c:1546-1682); on this domain the same
  * concurrency is two queues: the inverse wavelet is HBM-bound, OBMC is issue-bound, so
@@ -101,7 +124,9 @@ void *schro_hip_stream (SchroHipContext * ctx);
  * the selected queue (0 after schro_hip_context_new); schro_hip_queue_wait makes the work
  * enqueued LATER on `waiter` start after everything enqueued SO FAR on `signaller` (the
  * render_ok / wavelet-done dependencies of schrodecoder.c:1589-1660). */
-#define SCHRO_HIP_QUEUES 2
+#define SCHRO_HIP_QUEUES 4
+#define SCHRO_HIP_QUEUE_H2D 2      /* by convention: host-to-device copies */
+#define SCHRO_HIP_QUEUE_D2H 3      /* device-to-host copies */
 int schro_hip_context_select_queue (SchroHipContext * ctx, int queue);
 int schro_hip_context_queue (SchroHipContext * ctx);
 int schro_hip_queue_wait (SchroHipContext * ctx, int waiter, int signaller);
@@ -429,6 +454,16 @@ typedef struct {
 int schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * planes, int nplanes,
     int bytes_per_sample, int arith);
 
+/* The geometry of every codeblock record of one component, in the decoder's order -- sub-band index
+ * 0 .. 3 * depth, in each its rows of codeblocks (schro_decoder_decode_subband, schrodecoder.c:3558-3577;
+ * counts per sub-band from params->horiz_codeblocks / vert_codeblocks [0 .. depth] as
+ * schro_decoder_setup_codeblocks picks them, :3280-3293; rectangles by schro_subband_get_frame_data,
+ * schroparams.c:319-352): dst_offset, dst_stride, width, height filled, src_offset -1 (zero codeblock).
+ * A host decoder builds the table once per picture geometry and fills src_offset / src_bytes /
+ * quant_index as it entropy-decodes.  Returns the number of records (write stops at `max`). */
+int schro_hip_codeblock_layout (int iwt_width, int iwt_height, int transform_depth, const int *horiz_codeblocks,
+    const int *vert_codeblocks, int stride, int bytes_per_sample, SchroHipCodeblock * out, int max);
+
 /* ---- frame layer: the reference's stage boundary ------------------------- */
 
 /* The structs of this layer are LAYOUT-IDENTICAL to the reference's (same members, same
@@ -473,6 +508,8 @@ typedef struct _SchroHipMemoryDomain {
  * for the plane-layer calls; schro_memory_domain_free_hip releases both. */
 SchroHipMemoryDomain *schro_memory_domain_new_hip (int device);
 void schro_memory_domain_free_hip (SchroHipMemoryDomain * domain);
+/* a domain of PINNED HOST memory (flags SCHRO_MEMORY_DOMAIN_CPU): see schro_hip_host_alloc; free it with free () */
+SchroHipMemoryDomain *schro_memory_domain_new_hip_host (void);
 SchroHipContext *schro_hip_domain_context (SchroHipMemoryDomain * domain);
 /* the domain of a context made with schro_hip_context_new */
 SchroHipMemoryDomain *schro_hip_context_domain (SchroHipContext * ctx);
@@ -662,6 +699,13 @@ void schro_hip_frame_unref (SchroHipFrame * frame);
  * whole-frame copies, all three components, synchronous on return. */
 int schro_frame_to_hip (SchroHipFrame * dest, SchroHipFrame * src);
 int schro_hipframe_to_cpu (SchroHipFrame * dest, SchroHipFrame * src);
+/* r03: the same, enqueued on the context's selected queue and NOT waited for (see the asynchronous
+ * transfers above: host frames in pinned memory, queues 2 / 3, marks, schro_hip_queue_synchronize) */
+int schro_frame_to_hip_async (SchroHipFrame * dest, SchroHipFrame * src);
+int schro_hipframe_to_cpu_async (SchroHipFrame * dest, SchroHipFrame * src);
+/* a copy of a device frame (plain or upsampled) on another context's device: one hipMemcpyPeerAsync per
+ * component on dst_ctx's selected queue, complete on return (the scheduler's reference migration) */
+SchroHipFrame *schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src);
 
 /* schro_frame_inverse_iwt_transform_cuda (schrocuda.h:13-14) replacement, same arguments:
  * upload transform_frame (host) or use it where it is (device), run the multi-level inverse
@@ -678,6 +722,9 @@ int schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame,
 /* schro_upsampled_gpuframe_upsample (schrogpuframe.h:27) replacement:
  * dest (device, is_upsampled) <- half-pel images of src (device u8). */
 int schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src);
+/* the reference's one-argument form (schrogpuframe.h:29): `frame` is the upsampled device frame, its
+ * integer-pel source the frame it keeps in virt_frame1 */
+int schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame);
 
 /* schro_motion_render (motion, dest, addframe, add, output_frame) (schromotion.h:100, as
  * x_render_motion calls it, schrodecoder.c:1905-1935) replacement, same arguments: add must
@@ -719,6 +766,9 @@ typedef int (*SchroHipPictureFunc) (SchroHipContext * ctx, int device_index, voi
  * NULL in the callbacks): the host logic under test on a machine without GPUs. */
 SchroHipScheduler *schro_hip_scheduler_new (int n_devices);
 SchroHipScheduler *schro_hip_scheduler_new_virtual (int n_devices);
+/* an explicit device list; a device may appear more than once (two exec-domain threads and contexts
+ * on one device: how a box with one GPU exercises the cross-device paths) */
+SchroHipScheduler *schro_hip_scheduler_new_on (const int *devices, int n_devices);
 /* waits for everything submitted, stops the threads, frees the contexts */
 void schro_hip_scheduler_free (SchroHipScheduler * sched);
 int schro_hip_scheduler_n_devices (SchroHipScheduler * sched);
@@ -727,8 +777,23 @@ SchroHipContext *schro_hip_scheduler_context (SchroHipScheduler * sched, int dev
  * predicts from (0 .. 2), each submitted earlier with is_ref != 0. */
 int schro_hip_scheduler_submit (SchroHipScheduler * sched, int picture_number, const int *refs, int n_refs,
     int is_ref, SchroHipPictureFunc func, void *priv, int *foreign_ref);
-/* a reference picture leaves the reference queue (schro_decoder_reference_retire) */
+/* A reference picture leaves the reference queue (schro_decoder_reference_retire,
+ * schrodecoder.c:1302 -- at PARSE time, possibly before pictures that predict from it, or the
+ * reference itself, have run): later submits no longer find the number; pictures already submitted
+ * keep what they resolved, and the reference's frames go when the last of them has finished. */
 int schro_hip_scheduler_retire (SchroHipScheduler * sched, int picture_number);
+/* r03 -- references move, not just wait.  The function of a reference picture publishes the device
+ * frame its dependents read (the upsampled frame when mv_precision > 0, else the plain one); the
+ * scheduler keeps a reference on it.  Before a picture with a reference on ANOTHER device runs, that
+ * frame is copied to the picture's device (schro_hip_frame_copy_to: one hipMemcpyPeerAsync per
+ * component; the owner's device work is complete by then) and cached there for later dependents;
+ * schro_hip_scheduler_reference_frame, called by a picture's function, gives the frame of one of ITS
+ * references on ITS device -- the published frame or the copy (NULL: nothing was published: the
+ * foreign_ref of submit names what the caller has to move itself).  On virtual devices the
+ * "frames" are opaque pointers that are handed through. */
+int schro_hip_scheduler_publish_reference (SchroHipScheduler * sched, int device_index, void *frame);
+void *schro_hip_scheduler_reference_frame (SchroHipScheduler * sched, int device_index, int picture_number);
+long schro_hip_scheduler_moves (SchroHipScheduler * sched);       /* frames copied between devices so far */
 /* waits until every submitted picture has run; returns the first non-zero result of a func */
 int schro_hip_scheduler_wait (SchroHipScheduler * sched);
 

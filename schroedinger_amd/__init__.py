@@ -58,6 +58,22 @@ class DevicePlane:
             self.width * self.dtype.itemsize, self.height))
         return out
 
+    def upload_async(self, a):
+        """Enqueue the copy of `a` (a pinned host array, Context.host_array) on the selected queue."""
+        assert a.shape == (self.height, self.width) and a.dtype == self.dtype, (a.shape, a.dtype)
+        check(self.ctx.lib.schro_hip_upload_2d_async(
+            self.ctx.h, self.ptr, self.stride, a.ctypes.data_as(C.c_void_p), a.strides[0],
+            self.width * self.dtype.itemsize, self.height))
+        return self
+
+    def download_async(self, out):
+        """Enqueue the copy into `out` (a pinned host array) on the selected queue; not waited for."""
+        assert out.shape == (self.height, self.width) and out.dtype == self.dtype
+        check(self.ctx.lib.schro_hip_download_2d_async(
+            self.ctx.h, out.ctypes.data_as(C.c_void_p), out.strides[0], self.ptr, self.stride,
+            self.width * self.dtype.itemsize, self.height))
+        return out
+
     def fill(self, byte):
         check(self.ctx.lib.schro_hip_memset(self.ctx.h, self.ptr, byte, self.nbytes))
         return self
@@ -135,6 +151,26 @@ class Context:
 
     def synchronize(self):
         check(self.lib.schro_hip_synchronize(self.h))
+
+    QUEUE_H2D, QUEUE_D2H = 2, 3
+
+    def queue_synchronize(self, q):
+        check(self.lib.schro_hip_queue_synchronize(self.h, q))
+
+    def host_array(self, shape, dtype):
+        """A numpy array in pinned host memory (schro_hip_host_alloc): what the asynchronous copies
+        read and write at full rate.  Freed with the array."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = self.lib.schro_hip_host_alloc(max(n, 1))
+        if not p:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        lib = self.lib
+        import weakref
+        weakref.finalize(buf, lib.schro_hip_host_free, p)
+        return a
 
     def select_queue(self, q):
         """Calls that follow are enqueued on in-order queue q (0 or 1)."""
@@ -295,17 +331,36 @@ class Context:
                 a.comp[k], a.stride[k] = planes[k].ptr, planes[k].stride
         check(self.lib.schro_hip_lowdelay_batch(self.h, arr, n, C.byref(self.lowdelay_params(P)), bpp))
 
+    @staticmethod
+    def codeblock_table(cbs):
+        """The C table (SchroHipCodeblock array) of a list of (dst_offset, dst_stride, width, height,
+        src_offset, src_bytes, quant_index): build it once per picture, not per call."""
+        tab = (_lib.Codeblock * len(cbs))()
+        for t, cb in zip(tab, cbs):
+            (t.dst_offset, t.dst_stride, t.width, t.height, t.src_offset, t.src_bytes, t.quant_index) = cb
+        return tab
+
+    def codeblock_layout(self, width, height, depth, horiz_codeblocks, vert_codeblocks, stride, itemsize):
+        """schro_hip_codeblock_layout: the geometry of every codeblock record of a component (C table)."""
+        hc = (C.c_int * (depth + 1))(*horiz_codeblocks)
+        vc = (C.c_int * (depth + 1))(*vert_codeblocks)
+        n = self.lib.schro_hip_codeblock_layout(width, height, depth, hc, vc, stride, itemsize, None, 0)
+        if n < 0:
+            raise SchroHipError(self.lib.schro_hip_last_error().decode())
+        tab = (_lib.Codeblock * n)()
+        check(min(0, self.lib.schro_hip_codeblock_layout(width, height, depth, hc, vc, stride, itemsize, tab, n)))
+        return tab
+
     def dequant_batch(self, jobs, arith=0):
-        """jobs: (dst DevicePlane (s16 / s32), values device blob (DevicePlane of bytes) or None,
-        codeblocks list of (dst_offset, dst_stride, width, height, src_offset, src_bytes,
-        quant_index), is_intra) per component."""
+        """jobs: (dst DevicePlane (s16 / s32), values device blob (DevicePlane of bytes, or an object
+        with .ptr) or None, codeblocks -- a C table from codeblock_table / codeblock_layout or a list
+        of (dst_offset, dst_stride, width, height, src_offset, src_bytes, quant_index) --,
+        is_intra) per component."""
         n = len(jobs)
         arr = (_lib.DequantPlane * n)()
         keep = []
         for a, (dst, values, cbs, intra) in zip(arr, jobs):
-            tab = (_lib.Codeblock * len(cbs))()
-            for t, cb in zip(tab, cbs):
-                (t.dst_offset, t.dst_stride, t.width, t.height, t.src_offset, t.src_bytes, t.quant_index) = cb
+            tab = cbs if isinstance(cbs, C.Array) else self.codeblock_table(cbs)
             keep.append(tab)
             a.dst, a.values = dst.ptr, values.ptr if values is not None else None
             a.codeblocks, a.ncodeblocks, a.is_intra = tab, len(cbs), 1 if intra else 0
@@ -367,9 +422,14 @@ class Scheduler:
     their references (include/schro_hip.h).  func(ctx, device_index) is the picture's pixel
     path; ctx is a Context of that device (None on virtual devices)."""
 
-    def __init__(self, n_devices=0, virtual=False):
+    def __init__(self, n_devices=0, virtual=False, devices=None):
         self.lib = _lib.load()
-        self.h = (self.lib.schro_hip_scheduler_new_virtual if virtual else self.lib.schro_hip_scheduler_new)(n_devices)
+        if devices is not None:         # an explicit list; a device may repeat (two contexts on one GPU)
+            arr = (C.c_int * len(devices))(*devices)
+            self.h = self.lib.schro_hip_scheduler_new_on(arr, len(devices))
+        else:
+            self.h = (self.lib.schro_hip_scheduler_new_virtual if virtual
+                      else self.lib.schro_hip_scheduler_new)(n_devices)
         if not self.h:
             raise SchroHipError(self.lib.schro_hip_last_error().decode())
         self.n_devices = self.lib.schro_hip_scheduler_n_devices(self.h)
@@ -404,6 +464,18 @@ class Scheduler:
 
     def retire(self, number):
         check(self.lib.schro_hip_scheduler_retire(self.h, number))
+
+    def publish_reference(self, device_index, frame_ptr):
+        """Called by a reference picture's function: the device frame (SchroHipFrame pointer; any
+        non-zero token on virtual devices) its dependents read."""
+        check(self.lib.schro_hip_scheduler_publish_reference(self.h, device_index, frame_ptr))
+
+    def reference_frame(self, device_index, number):
+        """Called by a picture's function: the frame of its reference `number` on this device."""
+        return self.lib.schro_hip_scheduler_reference_frame(self.h, device_index, number)
+
+    def moves(self):
+        return self.lib.schro_hip_scheduler_moves(self.h)
 
     def wait(self):
         r = self.lib.schro_hip_scheduler_wait(self.h)

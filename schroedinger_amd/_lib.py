@@ -13,7 +13,13 @@ LIB_PATH = os.environ.get("SCHRO_HIP_LIB") or os.path.join(_HERE, "libschro_hip.
 # every extern "C" symbol include/schro_hip.h declares
 EXPORTED_SYMBOLS = [
     "schro_hip_context_new", "schro_hip_context_free", "schro_hip_device_count",
-    "schro_hip_last_error", "schro_hip_set_abort_on_error",
+    "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind",
+    "schro_hip_host_alloc", "schro_hip_host_free", "schro_hip_upload_2d_async", "schro_hip_download_2d_async",
+    "schro_hip_queue_synchronize", "schro_memory_domain_new_hip_host", "schro_hip_codeblock_layout",
+    "schro_frame_to_hip_async", "schro_hipframe_to_cpu_async", "schro_hip_frame_copy_to",
+    "schro_upsampled_hipframe_upsample_inplace",
+    "schro_hip_scheduler_new_on", "schro_hip_scheduler_publish_reference", "schro_hip_scheduler_reference_frame",
+    "schro_hip_scheduler_moves",
     "schro_hip_domain_alloc", "schro_hip_domain_free", "schro_hip_domain_bytes",
     "schro_hip_upload_2d", "schro_hip_download_2d", "schro_hip_memset",
     "schro_hip_synchronize", "schro_hip_stream",
@@ -121,6 +127,14 @@ class FrameData(C.Structure):
                 ("h_shift", C.c_int), ("v_shift", C.c_int)]
 
 
+class MemoryDomain(C.Structure):
+    """The head of SchroHipMemoryDomain == SchroMemoryDomain (schrodomain.h:13-28): the alloc / free table."""
+    _fields_ = [("mutex", C.c_void_p), ("flags", C.c_uint),
+                ("alloc", C.CFUNCTYPE(C.c_void_p, C.c_int)),
+                ("alloc_2d", C.CFUNCTYPE(C.c_void_p, C.c_int, C.c_int, C.c_int)),
+                ("free", C.CFUNCTYPE(None, C.c_void_p, C.c_int))]
+
+
 class Frame(C.Structure):
     """SchroHipFrame == SchroFrame (schroframe.h:69-94), member for member."""
 
@@ -217,6 +231,40 @@ def load():
     L.schro_hip_domain_context.restype = vp
     L.schro_hip_context_domain.argtypes = [vp]
     L.schro_hip_context_domain.restype = vp
+    L.schro_hip_init.argtypes = []
+    L.schro_hip_init.restype = None
+    L.schro_hip_thread_bind.argtypes = [vp]
+    L.schro_hip_thread_bind.restype = None
+    L.schro_hip_host_alloc.argtypes = [C.c_size_t]
+    L.schro_hip_host_alloc.restype = vp
+    L.schro_hip_host_free.argtypes = [vp]
+    L.schro_hip_host_free.restype = None
+    L.schro_hip_upload_2d_async.argtypes = [vp, vp, i, vp, i, i, i]
+    L.schro_hip_upload_2d_async.restype = i
+    L.schro_hip_download_2d_async.argtypes = [vp, vp, i, vp, i, i, i]
+    L.schro_hip_download_2d_async.restype = i
+    L.schro_hip_queue_synchronize.argtypes = [vp, i]
+    L.schro_hip_queue_synchronize.restype = i
+    L.schro_memory_domain_new_hip_host.argtypes = []
+    L.schro_memory_domain_new_hip_host.restype = vp
+    L.schro_hip_codeblock_layout.argtypes = [i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int), i, i, C.POINTER(Codeblock), i]
+    L.schro_hip_codeblock_layout.restype = i
+    L.schro_frame_to_hip_async.argtypes = [vp, vp]
+    L.schro_frame_to_hip_async.restype = i
+    L.schro_hipframe_to_cpu_async.argtypes = [vp, vp]
+    L.schro_hipframe_to_cpu_async.restype = i
+    L.schro_hip_frame_copy_to.argtypes = [vp, vp]
+    L.schro_hip_frame_copy_to.restype = vp
+    L.schro_upsampled_hipframe_upsample_inplace.argtypes = [vp]
+    L.schro_upsampled_hipframe_upsample_inplace.restype = i
+    L.schro_hip_scheduler_new_on.argtypes = [C.POINTER(C.c_int), i]
+    L.schro_hip_scheduler_new_on.restype = vp
+    L.schro_hip_scheduler_publish_reference.argtypes = [vp, i, vp]
+    L.schro_hip_scheduler_publish_reference.restype = i
+    L.schro_hip_scheduler_reference_frame.argtypes = [vp, i, i]
+    L.schro_hip_scheduler_reference_frame.restype = vp
+    L.schro_hip_scheduler_moves.argtypes = [vp]
+    L.schro_hip_scheduler_moves.restype = C.c_long
     L.schro_hip_scheduler_new.argtypes = [i]
     L.schro_hip_scheduler_new.restype = vp
     L.schro_hip_scheduler_new_virtual.argtypes = [i]

@@ -131,6 +131,8 @@ ProfileScope::~ProfileScope ()
 
 using namespace schro;
 
+static_assert (sizeof (ObmcJob) * kMaxJobs <= SchroHipContext::kArgSlotBytes, "a launch group of kMaxJobs OBMC jobs fits a table slot");
+
 static inline int
 div_up (int a, int b)
 {
@@ -168,20 +170,34 @@ schro_hip_set_abort_on_error (int enable)
   g_abort_on_error = enable;
 }
 
+// schro_cuda_init (schrocuda.c:13-31): look at the devices; nothing else to set up
+void
+schro_hip_init (void)
+{
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess)
+    n = 0;
+  for (int i = 0; i < n; i++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties (&prop, i) == hipSuccess && getenv ("SCHRO_HIP_DEBUG"))
+      fprintf (stderr, "schro_hip: device %d: %s %s, %d CUs, %zu MB\n", i, prop.name, prop.gcnArchName,
+          prop.multiProcessorCount, prop.totalGlobalMem >> 20);
+  }
+}
+
 // ---- the SchroMemoryDomain-shaped handle -------------------------------------------------------
 // alloc / free of the reference's table carry no domain argument (schrodomain.h:18-22), so they
 // resolve the domain from the calling thread's current device, as the reference's CUDA table
 // resolves its device from the CUDA runtime's current-device state.
-static constexpr int kMaxDevices = 64;
-static SchroHipMemoryDomain *g_domain_of_device[kMaxDevices];
+// r03: "current" is per THREAD, set by schro_hip_thread_bind -- schro_hip_context_new binds the thread that
+// creates a context, the scheduler's exec-domain threads bind theirs -- and a thread that never bound
+// one gets an error instead of, silently, device 0's domain (the HIP runtime's per-thread default).
+static thread_local SchroHipContext *t_bound_ctx = nullptr;
 
 static SchroHipContext *
 current_device_context ()
 {
-  int dev = 0;
-  if (hipGetDevice (&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_domain_of_device[dev])
-    return nullptr;
-  return g_domain_of_device[dev]->ctx;
+  return t_bound_ctx;
 }
 
 static void *
@@ -189,9 +205,12 @@ domain_vt_alloc (int size)
 {
   SchroHipContext *ctx = current_device_context ();
   if (!ctx || size <= 0) {
-    set_error (SCHRO_HIP_EINVAL, "domain alloc (%d): no HIP domain on the current device", size);
+    set_error (SCHRO_HIP_EINVAL, "domain alloc (%d): this thread is not an exec-domain thread of a HIP domain "
+        "(schro_hip_thread_bind)", size);
+    fprintf (stderr, "schro_hip: %s\n", schro_hip_last_error ());
     return nullptr;
   }
+  (void) hipSetDevice (ctx->device);
   // plain allocation: the caller (schro_memory_domain_alloc, schrodomain.c:58-109) keeps its own
   // slot cache on top of this table
   void *p = nullptr;
@@ -218,6 +237,70 @@ domain_vt_free (void *ptr, int size)
   (void) size;
   if (ptr)
     (void) hipFree (ptr);
+}
+
+void
+schro_hip_thread_bind (SchroHipContext * ctx)
+{
+  t_bound_ctx = ctx;
+  if (ctx)
+    (void) hipSetDevice (ctx->device);
+}
+
+// ---- pinned host memory: what the DMA engines copy from / to at full rate and asynchronously ----
+void *
+schro_hip_host_alloc (size_t size)
+{
+  void *p = nullptr;
+  if (size == 0 || hipHostMalloc (&p, size, hipHostMallocDefault) != hipSuccess) {
+    set_error (SCHRO_HIP_ENOMEM, "host_alloc (%zu) failed", size);
+    return nullptr;
+  }
+  return p;
+}
+
+void
+schro_hip_host_free (void *ptr)
+{
+  if (ptr)
+    (void) hipHostFree (ptr);
+}
+
+static void *
+host_vt_alloc (int size)
+{
+  return size > 0 ? schro_hip_host_alloc ((size_t) size) : nullptr;
+}
+
+static void *
+host_vt_alloc_2d (int depth, int width, int height)
+{
+  if (depth <= 0 || width <= 0 || height <= 0)
+    return nullptr;
+  return host_vt_alloc (((depth + 7) / 8) * width * height);
+}
+
+static void
+host_vt_free (void *ptr, int size)
+{
+  (void) size;
+  schro_hip_host_free (ptr);
+}
+
+// A SchroMemoryDomain whose blocks are pinned HOST memory (flags: SCHRO_MEMORY_DOMAIN_CPU): frames the
+// reference allocates in it (schro_frame_new_and_alloc (domain, ...): the transform frames the
+// arithmetic decoder writes, the output pictures) are ordinary host frames to every CPU stage and the
+// source / destination of asynchronous copies for this library.
+SchroHipMemoryDomain *
+schro_memory_domain_new_hip_host (void)
+{
+  SchroHipMemoryDomain *d = (SchroHipMemoryDomain *) calloc (1, sizeof (SchroHipMemoryDomain));
+  d->flags = 0x0001;            // SCHRO_MEMORY_DOMAIN_CPU, schrodomain.h:34
+  d->alloc = host_vt_alloc;
+  d->alloc_2d = host_vt_alloc_2d;
+  d->free = host_vt_free;
+  d->ctx = nullptr;
+  return d;
 }
 
 static SchroHipContext *
@@ -282,8 +365,7 @@ schro_hip_context_new (int device)
     delete ctx;
     return nullptr;
   }
-  if (device >= 0 && device < kMaxDevices && !g_domain_of_device[device])
-    g_domain_of_device[device] = ctx->domain;   // the table's alloc / free on this device
+  t_bound_ctx = ctx;            // the creating thread is the context's exec-domain thread until told otherwise
   return ctx;
 }
 
@@ -348,8 +430,8 @@ schro_hip_context_free (SchroHipContext * ctx)
   }
   (void) hipEventDestroy (ctx->ev_begin);
   (void) hipEventDestroy (ctx->ev_end);
-  if (ctx->device >= 0 && ctx->device < kMaxDevices && g_domain_of_device[ctx->device] == ctx->domain)
-    g_domain_of_device[ctx->device] = nullptr;
+  if (t_bound_ctx == ctx)
+    t_bound_ctx = nullptr;
   free (ctx->domain);
   for (int m = 0; m < SchroHipContext::kMarks; m++)
     if (ctx->marks[m])
@@ -430,6 +512,46 @@ schro_hip_download_2d (SchroHipContext * ctx, void *dst, int dst_stride, const v
   SCHRO_HIP_CHECK (hipMemcpy2DAsync (dst, dst_stride, src, src_stride, row_bytes, height,
           hipMemcpyDeviceToHost, ctx->stream));
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+// The asynchronous forms: enqueued on the SELECTED queue (by convention SCHRO_HIP_QUEUE_H2D / _D2H), no
+// wait.  With pinned host memory (schro_hip_host_alloc, schro_memory_domain_new_hip_host) the copy runs
+// on a DMA engine beside the kernels of the other queues; order it with marks.  Rows that are
+// contiguous on both sides go as ONE linear copy (the rectangle form is slower on the DMA engines).
+static int
+copy_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src, int src_stride, int row_bytes,
+    int height, hipMemcpyKind kind)
+{
+  (void) hipSetDevice (ctx->device);
+  if (dst_stride == row_bytes && src_stride == row_bytes)
+    SCHRO_HIP_CHECK (hipMemcpyAsync (dst, src, (size_t) row_bytes * height, kind, ctx->stream));
+  else
+    SCHRO_HIP_CHECK (hipMemcpy2DAsync (dst, dst_stride, src, src_stride, row_bytes, height, kind, ctx->stream));
+  return 0;
+}
+
+int
+schro_hip_upload_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src,
+    int src_stride, int row_bytes, int height)
+{
+  SCHRO_HIP_REQUIRE (ctx && dst && src && row_bytes > 0 && height > 0, "upload_2d_async: bad arguments");
+  return copy_2d_async (ctx, dst, dst_stride, src, src_stride, row_bytes, height, hipMemcpyHostToDevice);
+}
+
+int
+schro_hip_download_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src,
+    int src_stride, int row_bytes, int height)
+{
+  SCHRO_HIP_REQUIRE (ctx && dst && src && row_bytes > 0 && height > 0, "download_2d_async: bad arguments");
+  return copy_2d_async (ctx, dst, dst_stride, src, src_stride, row_bytes, height, hipMemcpyDeviceToHost);
+}
+
+int
+schro_hip_queue_synchronize (SchroHipContext * ctx, int queue)
+{
+  SCHRO_HIP_REQUIRE (ctx && queue >= 0 && queue < SchroHipContext::kQueues, "queue_synchronize: queue %d out of range", queue);
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[queue]));
   return 0;
 }
 
@@ -1118,6 +1240,59 @@ schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * pla
   return flush ();
 }
 
+// The codeblock records of one component in the decoder's order: sub-band index 0 .. 3 * depth
+// (position by schro_subband_get_position, schroparams.c:355-368; rectangle by
+// schro_subband_get_frame_data, :319-352), in each the rows of codeblocks of
+// schro_decoder_decode_subband (schrodecoder.c:3558-3577; their counts by
+// schro_decoder_setup_codeblocks, :3280-3293).  Geometry only: src_offset -1 (zero codeblock),
+// src_bytes 0, quant_index 0 -- what the entropy decoder fills in as it goes.
+int
+schro_hip_codeblock_layout (int iwt_width, int iwt_height, int transform_depth, const int *horiz_codeblocks,
+    const int *vert_codeblocks, int stride, int bytes_per_sample, SchroHipCodeblock * out, int max)
+{
+  SCHRO_HIP_REQUIRE (iwt_width > 0 && iwt_height > 0 && transform_depth >= 0 && transform_depth <= 6 && horiz_codeblocks
+      && vert_codeblocks && stride > 0 && (bytes_per_sample == 2 || bytes_per_sample == 4) && (out || max == 0),
+      "codeblock_layout: bad arguments");
+  int n = 0;
+  for (int index = 0; index < 1 + 3 * transform_depth; index++) {
+    const int position = index == 0 ? 0 : (((index - 1) / 3) << 2) | ((index - 1) % 3 + 1);
+    const int level = position >> 2;                    // SCHRO_SUBBAND_SHIFT
+    const int shift = transform_depth - level;
+    const int bw = iwt_width >> shift, bh = iwt_height >> shift;
+    const int bstride = stride << shift;
+    const int base = ((position & 2) ? bstride >> 1 : 0) + ((position & 1) ? bw * bytes_per_sample : 0);
+    const int hc = horiz_codeblocks[position == 0 ? 0 : level + 1], vc = vert_codeblocks[position == 0 ? 0 : level + 1];
+    SCHRO_HIP_REQUIRE (hc > 0 && vc > 0, "codeblock_layout: sub-band %d has %d x %d codeblocks", index, hc, vc);
+    for (int y = 0; y < vc; y++) {
+      const int ymin = (bh * y) / vc, ymax = (bh * (y + 1)) / vc;
+      int xmin = 0, acc = 0;
+      const int cw = bw / hc, inc = bw - hc * cw;
+      for (int x = 0; x < hc; x++) {
+        const int x0 = xmin;
+        xmin += cw;
+        acc += inc;
+        if (acc >= hc) {
+          acc -= hc;
+          xmin++;
+        }
+        if (n < max) {
+          SchroHipCodeblock & cb = out[n];
+          cb.dst_offset = base + ymin * bstride + x0 * bytes_per_sample;
+          cb.dst_stride = bstride;
+          cb.width = xmin - x0;
+          cb.height = ymax - ymin;
+          cb.src_offset = -1;
+          cb.src_bytes = 0;
+          cb.quant_index = 0;
+          cb.pad[0] = cb.pad[1] = 0;
+        }
+        n++;
+      }
+    }
+  }
+  return n;
+}
+
 int
 schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture * pictures, int npictures,
     const SchroHipLowDelayParams * params, int bytes_per_sample)
@@ -1387,18 +1562,30 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
       lru = &o;
   }
   if (!slot) {
+    // r03: the sort unit is a SUPERTILE of 8 x 4 tiles (1024 x 128 pixels), not a row of tiles.  An
+    // XCD has up to 32 x 7 = 224 tiles in flight: one supertile of all 8 pictures between two anchors.
+    // Their sample windows cover (1024 + 32) x (128 + 44) pixels of each reference, 1.4 MB of the four
+    // half-pel planes -- both references fit the XCD's 4 MiB L2 beside the streamed residual.  As rows
+    // of tiles (r02) the tiles in flight spanned the picture's width: 2.3 MB per reference with the
+    // r03 planes, and the L2 missed 7.1 M lines per step (915 MB) for 205 MB of reference planes.
     struct Key {
-      uint32_t row;             // vertical position, 1/64 of the plane
+      uint32_t row;             // supertile, in raster order over the plane (by relative position: planes of different sizes align)
       uint32_t ref;
       uint32_t entry;
     };
     std::vector < Key > keys;
     keys.reserve ((size_t) total);
-    for (size_t j = 0; j < jobs.size (); j++)
+    static const int sup_x = getenv ("SCHRO_HIP_OBMC_SUPER_X") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_X"))) : 8;
+    static const int sup_y = getenv ("SCHRO_HIP_OBMC_SUPER_Y") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_Y"))) : 4;
+    for (size_t j = 0; j < jobs.size (); j++) {
+      // (a U + V pair reads two planes of each reference: half the width)
+      const int sx = jobs[j].nplanes == 2 ? std::max (1, sup_x / 2) : sup_x;
+      const int nsx = div_up (jobs[j].tiles_x, sx);
       for (int ty = 0; ty < tiles_y[j]; ty++)
         for (int tx = 0; tx < jobs[j].tiles_x; tx++)
-          keys.push_back (Key { (uint32_t) (ty * 64 / tiles_y[j]), ref_class[j],
+          keys.push_back (Key { (uint32_t) ((ty / sup_y) * nsx + tx / sx), ref_class[j],
               (uint32_t) (j << 16) | (uint32_t) (ty * jobs[j].tiles_x + tx) });
+    }
     if (keys.size () != (size_t) total)
       return set_error (SCHRO_HIP_EINVAL, "obmc tile order: %zu tiles, %d expected", keys.size (), total);
     std::stable_sort (keys.begin (), keys.end (),[](const Key & a, const Key & b) {
@@ -1756,13 +1943,12 @@ schro_hip_frame_unref (SchroHipFrame * frame)
   free (frame);
 }
 
+// all components of a frame, host <-> device or device -> device, on the selected queue; no wait
 static int
-copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src,
-    hipMemcpyKind kind)
+copy_frame_async (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src, hipMemcpyKind kind)
 {
   if ((src->format & 0x100) || (dest->format & 0x100)) {
     SCHRO_HIP_REQUIRE (src->format == dest->format, "frame copy: packed format mismatch");
-    (void) hipSetDevice (ctx->device);
     const SchroHipFrameData *s = &src->components[0];
     SchroHipFrameData *d = &dest->components[0];
     int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
@@ -1771,22 +1957,30 @@ copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * s
         : f == SCHRO_HIP_FORMAT_AY64 ? (size_t) w * 8 : f == SCHRO_HIP_FORMAT_v216 ? (size_t) (w / 2) * 8
         : f == SCHRO_HIP_FORMAT_v210 ? (size_t) 16 * div_up (w, 6) : (size_t) (w / 2) * 4;
     if (row && h > 0)
-      SCHRO_HIP_CHECK (hipMemcpy2DAsync (d->data, d->stride, s->data, s->stride, row, h, kind, ctx->stream));
-    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+      return copy_2d_async (ctx, d->data, d->stride, s->data, s->stride, (int) row, h, kind);
     return 0;
   }
   int bpp = format_bpp (src->format);
   SCHRO_HIP_REQUIRE (bpp && format_bpp (dest->format) == bpp, "frame copy: depth mismatch");
-  (void) hipSetDevice (ctx->device);
   for (int k = 0; k < 3; k++) {
     const SchroHipFrameData *s = &src->components[k];
     SchroHipFrameData *d = &dest->components[k];
     int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
     if (w <= 0 || h <= 0)
       continue;
-    SCHRO_HIP_CHECK (hipMemcpy2DAsync (d->data, d->stride, s->data, s->stride, (size_t) w * bpp, h,
-            kind, ctx->stream));
+    int r = copy_2d_async (ctx, d->data, d->stride, s->data, s->stride, w * bpp, h, kind);
+    if (r)
+      return r;
   }
+  return 0;
+}
+
+static int
+copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src, hipMemcpyKind kind)
+{
+  int r = copy_frame_async (ctx, dest, src, kind);
+  if (r)
+    return r;
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
   return 0;
 }
@@ -1805,6 +1999,63 @@ schro_hipframe_to_cpu (SchroHipFrame * dest, SchroHipFrame * src)
   SCHRO_HIP_REQUIRE (dest && src && frame_ctx (src) && !frame_ctx (dest),
       "hipframe_to_cpu: src must be a device frame and dest a host frame");
   return copy_frame (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
+}
+
+// r03 -- the asynchronous twins (TODO-CUDA:5-7 "make gpu stuff completely asynchronous"; the
+// synchronous pattern they replace: schrogpuframe.c:480-609): enqueued on the context's selected
+// queue -- SCHRO_HIP_QUEUE_H2D / _D2H by convention -- and not waited for.  The host frame should live in
+// pinned memory (schro_memory_domain_new_hip_host): then picture k's copies run on the DMA engines
+// beside picture k - 1's kernels; order them against the stages with marks and end with
+// schro_hip_queue_synchronize.
+int
+schro_frame_to_hip_async (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && !frame_ctx (src),
+      "frame_to_hip_async: dest must be a device frame and src a host frame");
+  (void) hipSetDevice (frame_ctx (dest)->device);
+  return copy_frame_async (frame_ctx (dest), dest, src, hipMemcpyHostToDevice);
+}
+
+int
+schro_hipframe_to_cpu_async (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (src) && !frame_ctx (dest),
+      "hipframe_to_cpu_async: src must be a device frame and dest a host frame");
+  (void) hipSetDevice (frame_ctx (src)->device);
+  return copy_frame_async (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
+}
+
+// A copy of a device frame on another context's device (the scheduler moves a reference across two
+// chains with it): same format, size and layout -- plain or upsampled --, one
+// hipMemcpyPeerAsync per component on the destination context's queue, complete on return.
+SchroHipFrame *
+schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src)
+{
+  SchroHipContext *src_ctx = frame_ctx (src);
+  if (!dst_ctx || !src_ctx) {
+    set_error (SCHRO_HIP_EINVAL, "frame_copy_to: needs a destination context and a device frame");
+    return nullptr;
+  }
+  SchroHipFrame *dst = schro_hip_frame_new_and_alloc (dst_ctx, src->format, src->width, src->height, src->is_upsampled);
+  if (!dst)
+    return nullptr;
+  (void) hipSetDevice (dst_ctx->device);
+  const int ncomp = (src->format & 0x100) ? 1 : 3;
+  bool ok = true;
+  for (int k = 0; ok && k < ncomp; k++) {
+    const SchroHipFrameData *s = &src->components[k];
+    SchroHipFrameData *d = &dst->components[k];
+    ok = d->length == s->length && d->stride == s->stride
+        && hipMemcpyPeerAsync (d->data, dst_ctx->device, s->data, src_ctx->device, (size_t) s->length, dst_ctx->stream) == hipSuccess;
+  }
+  ok = ok && hipStreamSynchronize (dst_ctx->stream) == hipSuccess;
+  if (!ok) {
+    set_error (SCHRO_HIP_EDEVICE, "frame_copy_to: peer copy device %d -> %d failed", src_ctx->device, dst_ctx->device);
+    schro_hip_frame_unref (dst);
+    return nullptr;
+  }
+  dst->upsample_done = src->upsample_done;
+  return dst;
 }
 
 int
@@ -1919,6 +2170,16 @@ schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
   if (!r)
     dest->upsample_done = 1;
   return r;
+}
+
+// schro_upsampled_gpuframe_upsample (SchroFrame *) (schrogpuframe.h:29): one argument, the upsampled
+// frame, whose integer-pel source is the frame it keeps in virt_frame1
+int
+schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame)
+{
+  SCHRO_HIP_REQUIRE (frame && frame->is_upsampled && frame->virt_frame1,
+      "upsampled_hipframe_upsample_inplace: needs an upsampled frame with its source frame in virt_frame1");
+  return schro_upsampled_hipframe_upsample (frame, frame->virt_frame1);
 }
 
 int

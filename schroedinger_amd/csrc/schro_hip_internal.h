@@ -355,7 +355,10 @@ struct SchroHipContext {
   // go to the selected queue; `stream` is always streams[cur].  Job-table slots, tile-order
   // slots and the wavelet's scratch are per queue, so a launch on one queue never has its
   // tables rewritten by a copy enqueued on the other.
-  static constexpr int kQueues = 2;
+  // r03: four queues -- 0 and 1 for kernels as before, 2 and 3 by convention the host-to-device and
+  // the device-to-host copy queue (SCHRO_HIP_QUEUE_H2D / _D2H): copies from / to pinned host memory
+  // enqueued there run on the DMA engines beside the kernels of the other queues, ordered by marks.
+  static constexpr int kQueues = 4;
   hipStream_t streams[kQueues];
   hipEvent_t queue_ev[kQueues];
   static constexpr int kMarks = 16;
@@ -385,8 +388,8 @@ struct SchroHipContext {
     hipEvent_t copied;          // the slot's last host -> device copy
     bool copy_pending;
   };
-  static constexpr int kArgSlots = 64;
-  static constexpr size_t kArgSlotBytes = 48u << 10;
+  static constexpr int kArgSlots = 128;        // kArgSlots / kQueues per queue
+  static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in api.cpp)
   char *h_args;                 // kArgSlots pinned mirrors
   char *d_args;
   ArgSlot arg_slots[kArgSlots];
@@ -412,7 +415,7 @@ struct SchroHipContext {
     hipEvent_t copied;          // the slot's last upload
     bool copy_pending;
   };
-  static constexpr int kOrderSlots = 8;         // kOrderSlots / kQueues per queue
+  static constexpr int kOrderSlots = 16;        // kOrderSlots / kQueues per queue
   OrderSlot order_slots[kOrderSlots];
 
   // grow-only scratch for intermediate LL bands, one per queue

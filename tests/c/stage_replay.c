@@ -73,6 +73,54 @@ host_frame (SchroHipFrame * f, int format, int bpp, int w, int h, int cw, int ch
   }
 }
 
+/* schro_frame_new_and_alloc (domain, format, width, height) as the REFERENCE does it
+ * (schro_frame_new_and_alloc_full, schroframe.c:60-191, extension 0, not upsampled): strides
+ * ROUND_UP_16 (width * bytes), the three components back to back in ONE block from the domain's
+ * alloc table -- the frames a patched decoder hands to the stage calls come from here, not from
+ * schro_hip_frame_new_and_alloc */
+static SchroHipFrame *
+domain_frame (SchroHipMemoryDomain * domain, int format, int bpp, int w, int h)
+{
+  SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+  const int hs = SCHRO_HIP_FORMAT_H_SHIFT (format), vs = SCHRO_HIP_FORMAT_V_SHIFT (format);
+  const int cw = (w + (1 << hs) - 1) >> hs, ch = (h + (1 << vs) - 1) >> vs;
+  int total = 0;
+  f->refcount = 1;
+  f->domain = domain;
+  f->format = format;
+  f->width = w;
+  f->height = h;
+  for (int k = 0; k < 3; k++) {
+    SchroHipFrameData *c = &f->components[k];
+    c->format = format;
+    c->width = k ? cw : w;
+    c->height = k ? ch : h;
+    c->stride = ((c->width * bpp) + 15) & ~15;
+    c->length = c->stride * c->height;
+    c->h_shift = k ? hs : 0;
+    c->v_shift = k ? vs : 0;
+    total += c->length;
+  }
+  f->regions[0] = domain->alloc (total);
+  if (!f->regions[0]) {
+    fprintf (stderr, "domain->alloc (%d) failed: %s\n", total, schro_hip_last_error ());
+    exit (1);
+  }
+  char *p = (char *) f->regions[0];
+  for (int k = 0; k < 3; k++) {
+    f->components[k].data = p;
+    p += f->components[k].length;
+  }
+  return f;
+}
+
+static void
+domain_frame_free (SchroHipFrame * f)
+{
+  f->domain->free (f->regions[0], f->components[0].length + f->components[1].length + f->components[2].length);
+  free (f);
+}
+
 int
 main (int argc, char **argv)
 {
@@ -106,7 +154,8 @@ main (int argc, char **argv)
   const size_t iwt_samples = (size_t) params.iwt_luma_width * params.iwt_luma_height
       + 2 * (size_t) params.iwt_chroma_width * params.iwt_chroma_height;
 
-  /* decoder->cuda_domain = schro_memory_domain_new_cuda () (schrodecoder.c:167-169) */
+  /* schro_cuda_init (); decoder->cuda_domain = schro_memory_domain_new_cuda () (schrodecoder.c:167-169) */
+  schro_hip_init ();
   SchroHipMemoryDomain *domain = schro_memory_domain_new_hip (0);
   if (!domain) {
     fprintf (stderr, "no HIP domain: %s\n", schro_hip_last_error ());
@@ -131,9 +180,7 @@ main (int argc, char **argv)
       params.iwt_chroma_height, read_file (dir, "coeffs.bin", 2 * iwt_samples));
 
   /* x_wavelet_transform: picture->frame in the device domain, inverse transform into it */
-  SchroHipFrame *frame = schro_hip_frame_new_and_alloc (ctx, fmt16, params.iwt_luma_width, params.iwt_luma_height, 0);
-  if (!frame)
-    return 1;
+  SchroHipFrame *frame = domain_frame (domain, fmt16, 2, params.iwt_luma_width, params.iwt_luma_height);
   CHECK (schro_frame_inverse_iwt_transform_hip (frame, &transform_frame, &params));
 
   /* the two reference pictures (device), x_upsample when mv_precision > 0 */
@@ -141,16 +188,16 @@ main (int argc, char **argv)
   for (int r = 0; r < 2; r++) {
     SchroHipFrame hostref;
     host_frame (&hostref, fmt8, 1, w, h, cw, ch, read_file (dir, r ? "ref1.bin" : "ref0.bin", pic_bytes));
-    ref[r] = schro_hip_frame_new_and_alloc (ctx, fmt8, w, h, 0);
-    if (!ref[r])
-      return 1;
+    ref[r] = domain_frame (domain, fmt8, 1, w, h);
     CHECK (schro_frame_to_hip (ref[r], &hostref));
     src[r] = ref[r];
     if (params.mv_precision > 0) {
+      /* (the half-pel planes have this library's tiled layout: its own allocator) */
       src[r] = schro_hip_frame_new_and_alloc (ctx, fmt8, w, h, 1);
       if (!src[r])
         return 1;
-      CHECK (schro_upsampled_hipframe_upsample (src[r], ref[r]));
+      src[r]->virt_frame1 = ref[r];
+      CHECK (schro_upsampled_hipframe_upsample_inplace (src[r]));     /* schrogpuframe.h:29's one-argument form */
     }
     free (hostref.components[0].data);
   }
@@ -162,15 +209,11 @@ main (int argc, char **argv)
   motion.src2 = src[1];
   motion.motion_vectors = read_file (dir, "mvs.bin", (size_t) 20 * params.x_num_blocks * params.y_num_blocks);
   motion.params = &params;
-  SchroHipFrame *output = schro_hip_frame_new_and_alloc (ctx, fmt8, w, h, 0);
-  if (!output)
-    return 1;
+  SchroHipFrame *output = domain_frame (domain, fmt8, 1, w, h);
   CHECK (schro_motion_render_hip (&motion, NULL, frame, 1, output));
 
   /* x_combine: the output picture (u8 -> u8 copy), then to the host */
-  SchroHipFrame *outpic = schro_hip_frame_new_and_alloc (ctx, fmt8, w, h, 0);
-  if (!outpic)
-    return 1;
+  SchroHipFrame *outpic = domain_frame (domain, fmt8, 1, w, h);
   CHECK (schro_hipframe_convert (outpic, output));
   SchroHipFrame hostout, hostres;
   void *out_bytes = malloc (pic_bytes), *res_bytes = malloc (2 * iwt_samples);
@@ -185,11 +228,11 @@ main (int argc, char **argv)
   for (int r = 0; r < 2; r++) {
     if (src[r] != ref[r])
       schro_hip_frame_unref (src[r]);
-    schro_hip_frame_unref (ref[r]);
+    domain_frame_free (ref[r]);
   }
-  schro_hip_frame_unref (frame);
-  schro_hip_frame_unref (output);
-  schro_hip_frame_unref (outpic);
+  domain_frame_free (frame);
+  domain_frame_free (output);
+  domain_frame_free (outpic);
   schro_memory_domain_free_hip (domain);
   printf ("stage_replay: ok\n");
   return 0;

@@ -1,0 +1,233 @@
+"""GPU: round-3 boundary pieces.
+
+* asynchronous transfers (TODO-CUDA:5-7; schrogpuframe.c:480-609 is the synchronous pattern they
+  replace): pictures whose coefficients go up from pinned host memory on the H2D queue, are decoded
+  on the kernel queues and come down on the D2H queue -- three pictures in flight, ordered by marks
+  only -- equal the oracle's; the frame-layer twins schro_frame_to_hip_async / _to_cpu_async;
+* references that MOVE between devices: two exec-domain threads and contexts on the one
+  device of this box (schro_hip_scheduler_new_on ({0, 0})), a B picture whose references live on
+  different "devices": the foreign one reaches it through schro_hip_frame_copy_to (a peer copy of the
+  upsampled frame) and the picture equals the oracle's;
+* the memory-domain table off an exec-domain thread fails loudly; schro_hip_init;
+  schro_upsampled_hipframe_upsample_inplace; schro_hip_codeblock_layout against a Python model."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import synth
+from schroedinger_amd import _lib, frames
+
+pytestmark = pytest.mark.gpu
+
+W, H, DEPTH, FILT = 320, 192, 3, 0
+
+
+def picture_inputs(seed):
+    P = synth.motion_params(W, H, 12, 8, 2, (1, 1, 1), (1, 1))
+    dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    resid = [synth.image_s(h, w, np.int16, seed=seed + k) for k, (h, w) in enumerate(dims)]
+    coeffs = [O.forward_iwt(r, DEPTH, FILT) for r in resid]
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 40, seed=seed + 7)
+    return P, dims, coeffs, mv
+
+
+def test_pictures_through_the_copy_queues(ctx):
+    lib = ctx.lib
+    P, dims, _, _ = picture_inputs(0)
+    refs_np = [[synth.picture_u8(h, w, seed=300 + 10 * r + k) for k, (h, w) in enumerate(dims)] for r in range(2)]
+    ups = [[O.UpComp(p) for p in comps] for comps in refs_np]
+    hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
+    ctx.upsample_batch([(ctx.upload(refs_np[r][k]), hp[r][k]) for r in range(2) for k in range(3)])
+    ctx.synchronize()
+    npic, slots = 6, 3
+    # a slot = one picture in flight: pinned host coefficient planes / MV blob / output planes, device twins
+    slot = []
+    for s in range(slots):
+        slot.append(dict(
+            h_co=[ctx.host_array(d, np.int16) for d in dims], h_out=[ctx.host_array(d, np.uint8) for d in dims],
+            h_mv=ctx.host_array((1, 20 * P["x_num_blocks"] * P["y_num_blocks"]), np.uint8),
+            d_co=[ctx.plane(h, w, np.int16) for (h, w) in dims], d_res=[ctx.plane(h, w, np.int16) for (h, w) in dims],
+            d_out=[ctx.plane(h, w, np.uint8) for (h, w) in dims]))
+        slot[s]["d_mv"] = ctx.plane(1, slot[s]["h_mv"].shape[1], np.uint8)
+    wants, got = [], []
+    for n in range(npic + 1):
+        if n < npic:
+            s = slot[n % slots]
+            # the slot's previous picture has come down (its pinned planes are free again)
+            if n >= slots:
+                ctx.queue_synchronize(ctx.QUEUE_D2H)
+                got.append([o.copy() for o in slot[n % slots]["h_out"]])
+            _, _, coeffs, mv = picture_inputs(10 * n)
+            for k in range(3):
+                s["h_co"][k][...] = coeffs[k]
+            s["h_mv"][...] = np.ascontiguousarray(mv).view(np.uint8).reshape(1, -1)
+            wants.append([O.motion_render(mv, O.MotionParams(**P), k, ups[0][k], ups[1][k],
+                                          O.inverse_iwt(coeffs[k], DEPTH, FILT), dims[k][1], dims[k][0]) for k in range(3)])
+            ctx.select_queue(ctx.QUEUE_H2D)
+            ctx.queue_wait_mark(8 + n % slots)          # the kernels that last read this slot's device planes
+            for k in range(3):
+                s["d_co"][k].upload_async(s["h_co"][k])
+            s["d_mv"].upload_async(s["h_mv"])
+            ctx.queue_mark(n % slots)
+            ctx.select_queue(n % 2)                      # kernels alternate between the two kernel queues
+            ctx.queue_wait_mark(n % slots)
+            ctx.queue_wait_mark(12 + n % slots)         # the download that last read this slot's output planes
+            ctx.iiwt_batch(list(zip(s["d_co"], s["d_res"])), DEPTH, FILT)
+            ctx.obmc_batch([sa.obmc_plane(s["d_mv"], P, k, hp[0][k], hp[1][k], s["d_res"][k], s["d_out"][k])
+                            for k in range(3)])
+            ctx.queue_mark(8 + n % slots)
+            ctx.queue_mark(4 + n % slots)
+            ctx.select_queue(ctx.QUEUE_D2H)
+            ctx.queue_wait_mark(4 + n % slots)
+            for k in range(3):
+                s["d_out"][k].download_async(s["h_out"][k])
+            ctx.queue_mark(12 + n % slots)
+    ctx.select_queue(0)
+    ctx.synchronize()
+    for n in range(npic - slots, npic):
+        got.append([o.copy() for o in slot[n % slots]["h_out"]])
+    assert len(got) == npic
+    for n in range(npic):
+        for k in range(3):
+            assert np.array_equal(got[n][k], wants[n][k]), (n, k)
+
+
+def test_frame_layer_async_twins(ctx):
+    lib = ctx.lib
+    dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    src = [ctx.host_array(d, np.int16) for d in dims]
+    dst = [ctx.host_array(d, np.int16) for d in dims]
+    for k, a in enumerate(src):
+        a[...] = synth.image_s(a.shape[0], a.shape[1], np.int16, seed=60 + k)
+    fmt = frames.frame_format(np.int16, 1, 1)
+    dev = frames.DeviceFrame(ctx, fmt, W, H)
+    hsrc, hdst = frames.HostFrame.__new__(frames.HostFrame), None
+    hsrc = frames.HostFrame(src, 1, 1)
+    # HostFrame copies non-contiguous planes only: the pinned arrays are used as they are
+    assert all(p.ctypes.data == a.ctypes.data for p, a in zip(hsrc.planes, src))
+    hdst = frames.HostFrame(dst, 1, 1)
+    ctx.select_queue(ctx.QUEUE_H2D)
+    sa.check(lib.schro_frame_to_hip_async(dev.ptr(), hsrc.ptr()))
+    ctx.queue_mark(1)
+    ctx.select_queue(ctx.QUEUE_D2H)
+    ctx.queue_wait_mark(1)
+    sa.check(lib.schro_hipframe_to_cpu_async(hdst.ptr(), dev.ptr()))
+    ctx.queue_synchronize(ctx.QUEUE_D2H)
+    ctx.select_queue(0)
+    for k in range(3):
+        assert np.array_equal(dst[k], src[k])
+    dev.unref()
+
+
+def test_reference_moves_between_two_contexts_on_this_device():
+    sched = sa.Scheduler(devices=[0, 0])
+    assert sched.n_devices == 2
+    lib = sched.lib
+    P, dims, coeffs, mv = picture_inputs(500)
+    fmt8 = frames.frame_format(np.uint8, 1, 1)
+    refs_np = {n: [synth.picture_u8(h, w, seed=n + k) for k, (h, w) in enumerate(dims)] for n in (0, 10)}
+    keep, result = {}, {}
+
+    def reference(number):
+        def run(ctx, dev):
+            plain = frames.DeviceFrame(ctx, fmt8, W, H).upload(frames.HostFrame(refs_np[number], 1, 1))
+            up = frames.DeviceFrame(ctx, fmt8, W, H, upsampled=True)
+            up.c.virt_frame1 = plain.p                     # schrogpuframe.h:29: the one-argument form
+            sa.check(lib.schro_upsampled_hipframe_upsample_inplace(up.ptr()))
+            sched.publish_reference(dev, up.ptr())
+            keep[number] = (plain, up)
+            return 0
+        return run
+
+    def bipred(ctx, dev):
+        f = [C.cast(sched.reference_frame(dev, n), C.POINTER(_lib.Frame)) for n in (10, 0)]
+        assert f[0] and f[1]
+        d_mv = ctx.upload_bytes(mv)
+        res, out = [], []
+        for k, (h, w) in enumerate(dims):
+            co = ctx.upload(coeffs[k])
+            r = ctx.plane(h, w, np.int16)
+            ctx.iiwt_batch([(co, r)], DEPTH, FILT)
+            res.append(r)
+            out.append(ctx.plane(h, w, np.uint8))
+        planes = []
+        for k in range(3):
+            class V:        # a view of the moved frame's component: pointer + band pitch
+                pass
+            views = []
+            for fr in f:
+                v = V()
+                v.ptr, v.stride = fr.contents.components[k].data, fr.contents.components[k].stride
+                views.append(v)
+            planes.append(sa.obmc_plane(d_mv, P, k, views[0], views[1], res[k], out[k]))
+        ctx.obmc_batch(planes)
+        result["B"] = [o.download() for o in out]
+        return 0
+
+    d0, _ = sched.submit(0, [], True, reference(0))
+    d1, _ = sched.submit(10, [], True, reference(10))
+    assert d0 != d1
+    dev, foreign = sched.submit(11, [10, 0], False, bipred)
+    assert dev == d1 and foreign == 0
+    sched.retire(0)                 # retired while the dependent may still be queued
+    sched.retire(10)
+    assert sched.wait() == 0
+    assert sched.moves() == 1
+    ups = {n: [O.UpComp(p) for p in refs_np[n]] for n in (0, 10)}
+    for k, (h, w) in enumerate(dims):
+        want = O.motion_render(mv, O.MotionParams(**P), k, ups[10][k], ups[0][k], O.inverse_iwt(coeffs[k], DEPTH, FILT), w, h)
+        assert np.array_equal(result["B"][k], want), k
+    sched.close()
+
+
+def test_domain_table_off_the_exec_domain_thread(ctx):
+    lib = ctx.lib
+    lib.schro_hip_init()
+    dom = C.cast(lib.schro_hip_context_domain(ctx.h), C.POINTER(_lib.MemoryDomain)).contents
+    lib.schro_hip_thread_bind(ctx.h)
+    p = dom.alloc(4096)
+    assert p
+    dom.free(p, 4096)
+    out = {}
+
+    def other():                     # a thread that never bound a domain: no silent device 0
+        out["p"] = dom.alloc(4096)
+        out["err"] = lib.schro_hip_last_error().decode()
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert not out["p"] and "exec-domain thread" in out["err"]
+
+
+def test_codeblock_layout_matches_the_decoders_geometry(ctx):
+    w, h, depth, stride = 360, 208, 3, 768
+    hc, vc = [1, 3, 4, 5], [1, 2, 3, 4]
+    tab = ctx.codeblock_layout(w, h, depth, hc, vc, stride, 2)
+    want = []
+    for index in range(1 + 3 * depth):
+        position = 0 if index == 0 else (((index - 1) // 3) << 2) | ((index - 1) % 3 + 1)
+        level = position >> 2
+        shift = depth - level
+        bw, bh, bstride = w >> shift, h >> shift, stride << shift
+        base = (bstride >> 1 if position & 2 else 0) + (bw * 2 if position & 1 else 0)
+        nh, nv = (hc[0], vc[0]) if position == 0 else (hc[level + 1], vc[level + 1])
+        for y in range(nv):
+            y0, y1 = bh * y // nv, bh * (y + 1) // nv
+            # schrodecoder.c:3565-3577: widths by an error accumulator
+            xmin, acc, cw = 0, 0, bw // nh
+            inc = bw - nh * cw
+            for x in range(nh):
+                x0 = xmin
+                xmin += cw
+                acc += inc
+                if acc >= nh:
+                    acc -= nh
+                    xmin += 1
+                want.append((base + y0 * bstride + 2 * x0, bstride, xmin - x0, y1 - y0, -1))
+    assert len(tab) == len(want)
+    for t, wv in zip(tab, want):
+        assert (t.dst_offset, t.dst_stride, t.width, t.height, t.src_offset) == wv

@@ -60,7 +60,7 @@ def test_pipelined_batches_equal_the_oracle(ctx):
 
 def test_queue_arguments_are_checked(ctx):
     with pytest.raises(sa.SchroHipError):
-        ctx.select_queue(2)
+        ctx.select_queue(4)         # queues 0, 1 (kernels), 2, 3 (copies)
     with pytest.raises(sa.SchroHipError):
         ctx.queue_mark(16)
     ctx.queue_wait_mark(7)      # never recorded: no-op

@@ -105,3 +105,91 @@ def test_errors_and_retirement():
     s.close()
     with pytest.raises(sa.SchroHipError):
         sa.Scheduler(0, virtual=False) if sa.device_count() == 0 else (_ for _ in ()).throw(sa.SchroHipError("skip"))
+
+
+def test_retire_before_the_dependent_runs():
+    """schro_decoder_reference_retire runs at PARSE time (schrodecoder.c:1302): references are retired
+    while pictures that predict from them -- on another device, so they wait -- are still queued, or
+    while the reference itself is.  Round 2 deadlocked here: completion was looked up by
+    number, and retire had erased the number."""
+    s = sa.Scheduler(2, virtual=True)
+    gate = threading.Event()
+    order, lock = [], threading.Lock()
+
+    def f(name, wait=False):
+        def g(ctx, index):
+            if wait:
+                gate.wait(5)
+            with lock:
+                order.append(name)
+            return 0
+        return g
+    d0, _ = s.submit(0, [], True, f("I0", wait=True))       # held back
+    d1, _ = s.submit(10, [], True, f("I10"))
+    assert d0 != d1
+    dev, foreign = s.submit(12, [10, 0], False, f("B12"))    # waits for picture 0 on the other device
+    assert dev == d1 and foreign == 0
+    s.retire(0)                                              # ... which is retired before it has even run
+    s.retire(10)
+    with pytest.raises(sa.SchroHipError):
+        s.submit(13, [0], False, f("late"))                  # retired: new pictures cannot predict from it
+    done = threading.Event()
+    result = []
+
+    def waiter():
+        result.append(s.wait())
+        done.set()
+    threading.Thread(target=waiter, daemon=True).start()
+    time.sleep(0.05)
+    assert not done.is_set()                                 # B12 still waits for I0
+    gate.set()
+    assert done.wait(5), "scheduler_wait hangs after retire (the round-2 deadlock)"
+    assert result == [0]
+    assert order.index("I0") < order.index("B12") and order.index("I10") < order.index("B12")
+    s.close()
+
+
+def test_references_move_to_the_dependents_device():
+    """A prediction across two chains: the foreign reference's published frame is brought to the
+    picture's device before its function runs, once per device, and handed out by number."""
+    s = sa.Scheduler(2, virtual=True)
+    seen = {}
+
+    def ref(token):
+        def g(ctx, index):
+            s.publish_reference(index, token)
+            return 0
+        return g
+
+    def dep(name, numbers):
+        def g(ctx, index):
+            seen[name] = (index, [s.reference_frame(index, n) for n in numbers])
+            return 0
+        return g
+    d0, _ = s.submit(0, [], True, ref(0x1000))
+    d1, _ = s.submit(10, [], True, ref(0x2000))
+    assert d0 != d1
+    dev, foreign = s.submit(11, [10, 0], False, dep("B11", [10, 0]))
+    assert (dev, foreign) == (d1, 0)
+    dev2, _ = s.submit(12, [10, 0], False, dep("B12", [10, 0]))          # the copy is there already
+    dev3, foreign3 = s.submit(1, [0, 10], False, dep("B1", [0, 10]))       # and the other way round
+    assert dev3 == d0 and foreign3 == 10
+    s.retire(0)
+    s.retire(10)
+    assert s.wait() == 0
+    assert seen["B11"] == (d1, [0x2000, 0x1000]) and seen["B12"] == (d1, [0x2000, 0x1000])
+    assert seen["B1"] == (d0, [0x1000, 0x2000])
+    assert s.moves() == 2                                    # picture 0 -> d1 once, picture 10 -> d0 once
+    s.close()
+
+
+def test_a_reused_picture_number_is_a_new_reference():
+    s = sa.Scheduler(1, virtual=True)
+    got = []
+    s.submit(5, [], True, lambda c, i: s.publish_reference(i, 0x51) or 0)
+    s.submit(6, [5], False, lambda c, i: got.append(s.reference_frame(i, 5)) or 0)
+    s.submit(5, [], True, lambda c, i: s.publish_reference(i, 0x52) or 0)       # the number comes round again
+    s.submit(7, [5], False, lambda c, i: got.append(s.reference_frame(i, 5)) or 0)
+    assert s.wait() == 0
+    assert got == [0x51, 0x52]
+    s.close()
