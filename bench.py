@@ -48,7 +48,9 @@ def coeff_plane(h, w, seed):
 
 class BatchSet:
     """One picture batch in flight: its references' half-pel images, coefficient frames,
-    motion fields, residual frames and output pictures -- all resident in HBM."""
+    motion fields, residual frames and output pictures -- all resident in HBM.  Coefficient frames,
+    motion fields and output pictures each live in ONE device block per batch (an arena), so that a
+    batch crosses the host boundary as one copy per kind (the PCIe-inclusive figures)."""
 
     def __init__(self, wl, seed):
         import schroedinger_amd as sa
@@ -57,10 +59,14 @@ class BatchSet:
         self.up_pairs = [(wl.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
         self.iwt_pairs, self.obmc_jobs = [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
+        nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
+        self.co_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * wl.frames))
+        self.out_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.uint8) for d in dims] * wl.frames))
+        self.mv_arena = sa.Arena(ctx, sa.Arena.size_of([((1, nmv), np.uint8)] * wl.frames))
         base = {}
         for f in range(wl.frames):
             mv = synth.motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 64, seed=seed + 2 + f)
-            d_mv = ctx.upload_bytes(mv)
+            d_mv = self.mv_arena.plane(1, nmv, np.uint8).upload(np.ascontiguousarray(mv).view(np.uint8).reshape(1, -1))
             self.mv_np.append(mv)
             self.mv_dev.append(d_mv)
             co_f, out_f = [], []
@@ -69,9 +75,9 @@ class BatchSet:
                 if key not in base:
                     base[key] = coeff_plane(h, w, seed + 7 * f + k)
                 co = base[key]
-                d_co = ctx.upload(co)
+                d_co = self.co_arena.plane(h, w, np.int16).upload(co)
                 d_res = ctx.plane(h, w, np.int16)
-                out = ctx.plane(h, w, np.uint8)
+                out = self.out_arena.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
                 self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[0][k], self.hp[1][k], d_res, out))
                 co_f.append(co)
@@ -238,41 +244,48 @@ def quantised_handover(h, w, depth, stride, seed):
 
 
 class HostSide:
-    """The host's side of one picture batch for the PCIe-inclusive figures: coefficient planes (dense
-    hand-over) or quantised values + codeblock tables (quantised hand-over), motion vectors and the
-    output pictures, all in PINNED host memory (schro_hip_host_alloc: what a decoder whose frames come
-    from schro_memory_domain_new_hip_host () hands over), plus the device buffers of the quantised form."""
+    """The host's side of one picture batch for the PCIe-inclusive figures, in PINNED host memory
+    (schro_hip_host_alloc: what a decoder whose frames come from schro_memory_domain_new_hip_host ()
+    hands over): ONE block each for the coefficient frames (dense hand-over) or the quantised values
+    of the non-zero codeblocks (quantised hand-over; their C tables built once), the motion vectors
+    and the output pictures -- mirrors of the batch's device arenas, one copy per kind and step."""
 
     def __init__(self, wl, b, quantised, seed):
         c = wl.ctx
-        self.mv = []
-        for m in b.mv_np:
-            h = c.host_array((1, m.nbytes), np.uint8)
-            h[...] = np.ascontiguousarray(m).view(np.uint8).reshape(1, -1)
-            self.mv.append(h)
-        self.out = [[c.host_array((o.height, o.width), np.uint8) for o in of] for of in b.out]
-        self.h2d = sum(m.nbytes for m in self.mv)
-        self.d2h = sum(o.nbytes for of in self.out for o in of)
-        self.co, self.hand = [], []
+        self.mv = c.host_array((1, b.mv_arena.nbytes), np.uint8)
+        self.mv[...] = b.mv_arena.block.download()
+        self.out = c.host_array((1, b.out_arena.nbytes), np.uint8)
+        self.h2d, self.d2h = b.mv_arena.used, b.out_arena.used
+        self.co = self.blob = self.d_blob = None
+        self.hand = []
         if not quantised:
-            for cf in b.coeff_np:
-                planes = []
-                for co in cf:
-                    h = c.host_array(co.shape, np.int16)
-                    h[...] = co
-                    planes.append(h)
-                    self.h2d += h.nbytes
-                self.co.append(planes)
+            self.co = c.host_array((1, b.co_arena.nbytes), np.uint8)
+            self.co[...] = b.co_arena.block.download()
+            self.h2d += b.co_arena.used
             return
+        import schroedinger_amd as sa
+        parts, off = [], 0
         for f in range(wl.frames):
             for k, (h, w) in enumerate(wl.dims):
                 dst = b.iwt_pairs[3 * f + k][0]
                 blob, cbs = quantised_handover(h, w, DEPTH, dst.stride, seed + 3 * f + k)
-                hb = c.host_array((1, blob.size), np.uint8)
-                hb[...] = blob.reshape(1, -1)
-                # the C table is built once per picture geometry, not per step
-                self.hand.append((dst, hb, c.plane(1, blob.size, np.uint8), c.codeblock_table(cbs)))
-                self.h2d += hb.nbytes + 24 * len(cbs)
+                parts.append((off, blob, dst, cbs))
+                off += (blob.size + 255) // 256 * 256
+        self.blob = c.host_array((1, off), np.uint8)
+        self.d_blob = sa.Arena(c, off)
+        for o, blob, dst, cbs in parts:
+            self.blob[0, o:o + blob.size] = blob
+            dev = self.d_blob.plane(1, blob.size, np.uint8)
+            assert dev.ptr == self.d_blob.ptr + o
+            # the C table is built once per picture geometry, not per step
+            self.hand.append((dst, dev, c.codeblock_table(cbs)))
+            self.h2d += blob.size + 24 * len(cbs)
+
+    def view(self, b, f, k):
+        """Output plane (f, k) of the batch as it came down."""
+        p = b.out[f][k]
+        o = p.ptr - b.out_arena.ptr
+        return self.out[0, o:o + p.nbytes].reshape(p.height, p.stride)[:, :p.width]
 
 
 def pcie_pipeline(wl, quantised, steps=12, warmup=4):
@@ -280,7 +293,8 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
     (include/schro_hip.h, asynchronous transfers): batch k + 1's coefficients (dense s16 frames, or
     quantised values for schro_hip_dequant_batch) and vectors go up on the H2D queue while batch k's
     kernels run on a kernel queue and batch k - 1's pictures come down on the D2H queue; marks carry
-    the dependencies, the host thread never waits inside the loop.  Two batches' buffers."""
+    the dependencies, the host thread never waits inside the loop.  Two batches' buffers; a batch's
+    planes of one kind are one block on either side: one copy per kind and step."""
     c = wl.ctx
     c.select_queue(0)
     c.synchronize()
@@ -293,22 +307,16 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
         c.select_queue(c.QUEUE_H2D)
         c.queue_wait_mark(8 + i)                # the kernels that last read this batch's inputs
         if quantised:
-            for dst, hb, dev, tab in h.hand:
-                dev.upload_async(hb)
+            h.d_blob.block.upload_async(h.blob)
         else:
-            n = 0
-            for f in range(wl.frames):
-                for kk in range(3):
-                    b.iwt_pairs[n][0].upload_async(h.co[f][kk])
-                    n += 1
-        for f in range(wl.frames):
-            b.mv_dev[f].upload_async(h.mv[f])
+            b.co_arena.block.upload_async(h.co)
+        b.mv_arena.block.upload_async(h.mv)
         c.queue_mark(i)
         c.select_queue(k % 2)
         c.queue_wait_mark(i)
         c.queue_wait_mark(12 + i)               # the download that last read this batch's pictures
         if quantised:
-            c.dequant_batch([(dst, dev, tab, False) for dst, _, dev, tab in h.hand], 0)
+            c.dequant_batch([(dst, dev, tab, False) for dst, dev, tab in h.hand], 0)
         c.upsample_batch(b.up_pairs)
         c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
         c.obmc_batch(b.obmc_jobs)
@@ -316,9 +324,7 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
         c.queue_mark(4 + i)
         c.select_queue(c.QUEUE_D2H)
         c.queue_wait_mark(4 + i)
-        for f in range(wl.frames):
-            for kk in range(3):
-                b.out[f][kk].download_async(h.out[f][kk])
+        b.out_arena.block.download_async(h.out)
         c.queue_mark(12 + i)
 
     for k in range(warmup):
@@ -328,24 +334,24 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
         step(k)
+    t_host = time.perf_counter() - t0
     c.select_queue(0)
     c.synchronize()
     dt = (time.perf_counter() - t0) / steps
     # the pictures that came down are the ones the device holds
-    ok = all(np.array_equal(hs[0].out[0][kk], wl.sets[0].out[0][kk].download()) for kk in range(3))
+    ok = all(np.array_equal(hs[0].view(wl.sets[0], 0, kk), wl.sets[0].out[0][kk].download()) for kk in range(3))
     res = {"ms_per_step": round(dt * 1e3, 3), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
            "h2d_MB": round(hs[0].h2d / 1e6, 1), "d2h_MB": round(hs[0].d2h / 1e6, 1),
-           "host_GBs": round((hs[0].h2d + hs[0].d2h) / dt / 1e9, 1), "downloaded_equals_device": bool(ok),
-           "note": "pinned host buffers, asynchronous copies on their own queues (H2D / D2H) beside the kernels, "
-                   "marks for the dependencies; %d steps in steady state; never `value`" % steps}
+           "host_GBs": round((hs[0].h2d + hs[0].d2h) / dt / 1e9, 1), "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3),
+           "downloaded_equals_device": bool(ok),
+           "note": "pinned host buffers, asynchronous copies on their own queues (H2D / D2H) beside the kernels, one copy "
+                   "per kind and step, marks for the dependencies; %d steps in steady state; never `value`" % steps}
     if quantised:
         dense = sum(co.nbytes for cf in wl.sets[0].coeff_np for co in cf)
-        res["share_of_dense_coefficient_bytes"] = round((hs[0].h2d - sum(m.nbytes for m in hs[0].mv)) / dense, 3)
+        res["share_of_dense_coefficient_bytes"] = round((hs[0].h2d - wl.sets[0].mv_arena.used) / dense, 3)
         res["note"] += ("; synthetic quantised hand-over: up to 8x8 codeblocks per sub-band, 35-75 % of the finer "
                         "levels' codeblocks zero, Laplacian values one byte each; C codeblock tables built once; "
                         "overwrites the batches' coefficient frames")
-        for _, _, dev, _ in [x for h in hs for x in h.hand]:
-            dev.free()
     return res
 
 

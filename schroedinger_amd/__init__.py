@@ -110,6 +110,41 @@ class HpPlane(DevicePlane):
         return out
 
 
+class ArenaPlane(DevicePlane):
+    """A height x width plane carved out of a larger device allocation (an arena: all planes of a
+    picture batch in ONE block, so that they cross the host boundary as one copy); owns nothing."""
+
+    def __init__(self, arena, offset, height, width, dtype, stride=None):
+        self.ctx = arena.ctx
+        self.dtype = np.dtype(dtype)
+        self.height, self.width = int(height), int(width)
+        row = self.width * self.dtype.itemsize
+        self.stride = int(stride) if stride else (row + 63) // 64 * 64
+        self.nbytes = self.stride * self.height
+        assert offset % 256 == 0 and offset + self.nbytes <= arena.nbytes
+        self.ptr = arena.ptr + offset
+
+    def free(self):
+        self.ptr = None
+
+
+class Arena:
+    """One device block handed out in 256-byte aligned pieces (ArenaPlane)."""
+
+    def __init__(self, ctx, nbytes):
+        self.block = DevicePlane(ctx, 1, int(nbytes), np.uint8)
+        self.ctx, self.ptr, self.nbytes, self.used = ctx, self.block.ptr, self.block.nbytes, 0
+
+    @staticmethod
+    def size_of(shapes_dtypes):
+        return sum(((w * np.dtype(d).itemsize + 63) // 64 * 64 * h + 255) // 256 * 256 for (h, w), d in shapes_dtypes)
+
+    def plane(self, height, width, dtype):
+        p = ArenaPlane(self, self.used, height, width, dtype)
+        self.used += (p.nbytes + 255) // 256 * 256
+        return p
+
+
 class SubPlane:
     """A strided view into a DevicePlane (e.g. the LL band of a coefficient frame in the
     in-place sub-band layout: rows 2^depth apart, stride << depth); owns nothing."""

@@ -524,7 +524,7 @@ copy_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src
     int height, hipMemcpyKind kind)
 {
   (void) hipSetDevice (ctx->device);
-  if (dst_stride == row_bytes && src_stride == row_bytes)
+  if (height == 1 || (dst_stride == row_bytes && src_stride == row_bytes))
     SCHRO_HIP_CHECK (hipMemcpyAsync (dst, src, (size_t) row_bytes * height, kind, ctx->stream));
   else
     SCHRO_HIP_CHECK (hipMemcpy2DAsync (dst, dst_stride, src, src_stride, row_bytes, height, kind, ctx->stream));
