@@ -355,6 +355,133 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
     return res
 
 
+def lowdelay_8k(ctx, npic=4, steps=8):
+    """BASELINE config 5: VC-2 low-delay 10-bit 4:2:2 7680x4320 -- s32 coefficients, slices of 32x8
+    luma samples in 155 bytes, 3-level Haar (no shift).  Per picture: slice decode + dequantisation,
+    DC prediction of the LL bands, inverse wavelet; batches of `npic` pictures alternate between the
+    two kernel queues (the DC prediction is a dependency chain on a few CUs: it runs beside the other
+    batch's slices / wavelet).  Slices come from tests/synth.py's writer (not from oracle/); a sample
+    of slices is checked against that writer's values here, the whole path against the oracle in
+    tests/test_gpu_lowdelay.py."""
+    import schroedinger_amd as sa
+    Wl, Hl, depth, filt = 7680, 4320, 3, 3
+    P = synth.lowdelay_params(Wl, Hl, (1, 0), depth, 32, 8, 155, 1)
+    data, kind, made = synth.lowdelay_picture(P, 3)
+    tables = json.load(open(os.path.join(ROOT, "tests", "golden", "quant_tables.json")))
+    dims = [(P["iwt_luma_height"], P["iwt_luma_width"])] + [(P["iwt_chroma_height"], P["iwt_chroma_width"])] * 2
+
+    def batch():
+        pics = []
+        for _ in range(npic):
+            pics.append((ctx.upload_bytes(data), [ctx.plane(h, w, np.int32) for (h, w) in dims],
+                         [ctx.plane(h, w, np.int32) for (h, w) in dims]))
+        return pics, [(sl, co) for sl, co, _ in pics], [(c, p) for _, co, px in pics for c, p in zip(co, px)]
+    sets = [batch() for _ in range(2)]
+    pics, jobs, pairs = sets[0]
+    ctx.select_queue(0)
+    ctx.lowdelay_batch(jobs, P)
+    ctx.synchronize()
+    # a sample of slices against what the writer put in: every sub-band but the (DC-predicted) LL band
+    ok, nx, ny = True, P["n_horiz_slices"], P["n_vert_slices"]
+    for (sy, sx) in ((0, 0), (ny // 2, nx // 3), (ny - 1, nx - 1)):
+        base, vals = made[int(kind[sy, sx])]
+        for comp, (h, w) in enumerate(dims):
+            rows = pics[-1][1][comp].download()
+            for index in range(1, 1 + 3 * depth):
+                _, c0, r0, step, bw, bh = synth.subband_geometry(w, h, depth, index)
+                x0, x1, y0, y1 = bw * sx // nx, bw * (sx + 1) // nx, bh * sy // ny, bh * (sy + 1) // ny
+                got = rows[r0 + step * y0:r0 + step * y1:step, c0 + x0:c0 + x1]
+                ok = ok and np.array_equal(got, synth.lowdelay_expected_band(P, comp, index, base, vals, tables))
+    for _ in range(2):
+        ctx.lowdelay_batch(jobs, P)
+        ctx.iiwt_batch(pairs, depth, filt)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(steps):
+        ctx.lowdelay_batch(jobs, P)
+        ctx.iiwt_batch(pairs, depth, filt)
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    def step(k):
+        _, jobs_q, pairs_q = sets[k % 2]
+        ctx.select_queue(k % 2)
+        ctx.lowdelay_batch(jobs_q, P)
+        ctx.iiwt_batch(pairs_q, depth, filt)
+    for k in range(4):
+        step(k)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2 * steps):
+        step(k)
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / (2 * steps)
+    ctx.select_queue(0)
+    for pics_q, _, _ in sets:
+        for sl, co, px in pics_q:
+            sl.free()
+            [p.free() for p in co + px]
+    samples = sum(h * w for h, w in dims)
+    per = {k: ms / steps / npic for k, (ms, n) in prof.items() if n}
+    iiwt = per.get("iiwt_finest", 0) + per.get("iiwt_coarse", 0)
+    # algorithmic bytes per picture: compressed slices in, 4 B per coefficient out; DC prediction: the LL bands
+    # read and written; wavelet: 8 B per sample per level (4 read + 4 written), levels 1 + 1/4 + 1/16
+    return {"workload": "7680x4320 4:2:2 s32 low-delay, 32x8 slices of 155 bytes, 3-level Haar, %d pictures per launch, "
+                        "two batches alternating between the kernel queues" % npic,
+            "ms_per_picture": round(wall / npic, 4), "Mpix_per_s": round(Wl * Hl * npic / wall / 1e3, 1),
+            "kernels_ms_per_picture": {"slices": round(per.get("slices", 0), 4), "dc_predict": round(per.get("dc_predict", 0), 4),
+                                       "iiwt_3_levels": round(iiwt, 4)},
+            "alg_GBs": {"slices": round((4 * samples + data.size) / (per.get("slices", 1) * 1e-3) / 1e9, 1),
+                        "iiwt_3_levels": round(8 * samples * (1 + 0.25 + 0.0625) / (max(iiwt, 1e-9) * 1e-3) / 1e9, 1)},
+            "compressed_MB_per_picture": round(data.size / 1e6, 1), "coefficient_MB_per_picture": round(4 * samples / 1e6, 1),
+            "sample_slices_vs_writer": "bit-exact" if ok else "MISMATCH"}
+
+
+def extra_kernels(wl):
+    """The remaining kernel classes of the path on the headline's pictures, one profiled launch set each:
+    core-syntax dequantisation (schro_hip_dequant_batch), intra convert s16 -> u8, packed copy-out (UYVY)."""
+    c, b = wl.ctx, wl.sets[0]
+    c.select_queue(0)
+    c.synchronize()
+    hand = []
+    for f in range(wl.frames):
+        for k, (h, w) in enumerate(wl.dims):
+            dst = b.iwt_pairs[3 * f + k][0]
+            blob, cbs = quantised_handover(h, w, DEPTH, dst.stride, 700 + 3 * f + k)
+            hand.append((dst, c.upload(blob.reshape(1, -1)), c.codeblock_table(cbs), blob.size))
+    conv = [(b.iwt_pairs[n][1], b.out[n // 3][n % 3]) for n in range(3 * wl.frames)]
+    packed = [c.plane(H, 2 * W, np.uint8) for _ in range(wl.frames)]
+    packs = [(b.out[f], 1, 1, packed[f], W, H, 0x101) for f in range(wl.frames)]
+    res = {}
+    samples = wl.frames * (W * H * 3 // 2)
+    for name, fn, alg in (("dequant", lambda: c.dequant_batch([(d, v, t, False) for d, v, t, _ in hand], 0),
+                           2 * samples + sum(n for _, _, _, n in hand)),
+                          ("convert", lambda: c.convert_u8_batch(conv), 3 * samples),
+                          ("pack_uyvy", lambda: c.pack_u8_batch(packs), samples + 2 * wl.frames * W * H)):
+        for _ in range(2):
+            fn()
+        ts = []
+        for _ in range(5):
+            c.timer_begin()
+            fn()
+            ts.append(c.timer_end())
+        ms = float(np.median(ts))
+        res[name] = {"ms_per_step": round(ms, 4), "alg_GBs": round(alg / (ms * 1e-3) / 1e9, 1)}
+    for _, v, _, _ in hand:
+        v.free()
+    [p.free() for p in packed]
+    # (the dequantisation overwrote batch 0's coefficient frames and the conversion its pictures: restore)
+    for n, (d_co, _) in enumerate(b.iwt_pairs):
+        d_co.upload(b.coeff_np[n // 3][n % 3])
+    wl.queues_saved = wl.queues
+    wl.queues = 1
+    wl.step()
+    wl.queues = wl.queues_saved
+    c.synchronize()
+    return res
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -537,6 +664,7 @@ def main():
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
             out["iiwt_1080p"] = iiwt_1080p(ctx)
+            out["kernels"].update(extra_kernels(wl))
             out["pcie_inclusive"] = pcie_pipeline(wl, quantised=False)
             # one batch at a time on one queue, every step timed by itself: median
             wl.queues = 1
@@ -560,6 +688,7 @@ def main():
         if world == 1 and not args.headline_only:
             wl.queues = 2
             out["pcie_inclusive_quantised"] = pcie_pipeline(wl, quantised=True)
+            out["lowdelay_8k"] = lowdelay_8k(ctx)
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):
             sys.exit(1)

@@ -124,3 +124,104 @@ def quantised_planes(P, seed=1, scale=3.0, big_every=0, big_range=1 << 31):
 def lowdelay_base_index(P, seed=1, lo=0, hi=40):
     n = P["n_horiz_slices"] * P["n_vert_slices"]
     return (lo + lcg(n, seed + 99) % (hi - lo + 1)).astype(np.uint8)
+
+
+# ---- VC-2 low-delay slices without the oracle (bench.py's lowdelay_8k key) ------------------------
+# The slice syntax as the reference READS it (schro_decoder_decode_slice_slow(_s32),
+# schrolowdelay.c:110-270; schro_unpack_decode_uint / _sint, schrounpack.c:214-245): 7 bits base
+# index, ilog2up (8 * slice_bytes) bits luma length, the luma codes of sub-bands 0 .. 3 * depth (each
+# the slice's rectangle, row-major), then the U / V codes interleaved sample by sample; a code is the
+# interleaved exp-Golomb form of |v| (value + 1 in binary: a 0 and the next bit per bit below the
+# leading one, then a 1) followed by a sign bit when v != 0.
+
+def _ilog2up(x):
+    n = 0
+    while (1 << n) < x:
+        n += 1
+    return n
+
+
+def _sint_bits(v):
+    m = abs(int(v)) + 1
+    bits = []
+    for b in range(m.bit_length() - 2, -1, -1):
+        bits += [0, (m >> b) & 1]
+    bits.append(1)
+    if v:
+        bits.append(1 if v < 0 else 0)
+    return bits
+
+
+def subband_geometry(w, h, depth, index):
+    """(position, column 0, row 0, row step, width, height) of sub-band `index` inside the
+    interleaved coefficient plane (schro_subband_get_frame_data, schroparams.c:319-352)."""
+    position = 0 if index == 0 else (((index - 1) // 3) << 2) | ((index - 1) % 3 + 1)
+    shift = depth - (position >> 2)
+    bw, bh = w >> shift, h >> shift
+    return position, (bw if position & 1 else 0), ((1 << shift) >> 1 if position & 2 else 0), 1 << shift, bw, bh
+
+
+def lowdelay_slice_values(P, seed, scale=0.9):
+    """Quantised values of ONE slice: (luma, u, v), each a list of 1 + 3 * depth row-major arrays."""
+    rng = np.random.default_rng(seed)
+    depth = P["transform_depth"]
+    out = []
+    for k in range(3):
+        w = (P["iwt_chroma_width"] if k else P["iwt_luma_width"]) // P["n_horiz_slices"]
+        h = (P["iwt_chroma_height"] if k else P["iwt_luma_height"]) // P["n_vert_slices"]
+        bands = []
+        for index in range(1 + 3 * depth):
+            _, _, _, _, bw, bh = subband_geometry(w, h, depth, index)
+            mag = np.floor(rng.exponential(scale, (bh, bw))).astype(np.int64)
+            bands.append(np.where(rng.integers(0, 2, (bh, bw)) == 1, -mag, mag))
+        out.append(bands)
+    return out
+
+
+def lowdelay_write_slice(P, base_index, values):
+    """One slice of slice_bytes_num bytes (slice_bytes_denom must be 1): bytes, or None when the
+    codes do not fit."""
+    assert P["slice_bytes_denom"] == 1
+    nbytes = P["slice_bytes_num"]
+    bits = [(base_index >> b) & 1 for b in range(6, -1, -1)]
+    luma = [b for band in values[0] for v in band.reshape(-1) for b in _sint_bits(v)]
+    nlen = _ilog2up(8 * nbytes)
+    bits += [(len(luma) >> b) & 1 for b in range(nlen - 1, -1, -1)] + luma
+    for bu, bv in zip(values[1], values[2]):
+        for a, b in zip(bu.reshape(-1), bv.reshape(-1)):
+            bits += _sint_bits(a) + _sint_bits(b)
+    if len(bits) > 8 * nbytes:
+        return None
+    bits += [1] * (8 * nbytes - len(bits))         # (the reader sees ones past the end: value 0 codes)
+    return np.packbits(np.array(bits, np.uint8))
+
+
+def lowdelay_picture(P, seed=1, kinds=16):
+    """The slice bytes of a whole picture from `kinds` different slices dealt out pseudo-randomly,
+    and what went into them: (bytes, kind of every slice [ny, nx], [(base_index, values)] per kind)."""
+    made = []
+    s = seed
+    while len(made) < kinds:
+        base = 4 + (s * 7) % 25
+        vals = lowdelay_slice_values(P, s)
+        data = lowdelay_write_slice(P, base, vals)
+        s += 1
+        if data is not None:
+            made.append((base, vals, data))
+    ny, nx = P["n_vert_slices"], P["n_horiz_slices"]
+    kind = (lcg(ny * nx, seed + 5) % kinds).reshape(ny, nx)
+    table = np.stack([m[2] for m in made])
+    return table[kind.reshape(-1)].reshape(-1), kind, [(m[0], m[1]) for m in made]
+
+
+def lowdelay_dequantise(q, quant_index, tables):
+    """schro_dequantise (schroutils.c:180-189) with schro_table_quant / schro_table_offset_1_2."""
+    f, o = tables["schro_table_quant"][quant_index], tables["schro_table_offset_1_2"][quant_index]
+    a = (np.abs(q) * f + o + 2) >> 2
+    return np.where(q == 0, 0, np.where(q < 0, -a, a)).astype(np.int64)
+
+
+def lowdelay_expected_band(P, comp, index, base_index, values, tables):
+    """Dequantised coefficients of sub-band `index` of one slice (the slice's rectangle of the band)."""
+    qi = min(max(base_index - P["quant_matrix"][index], 0), 60)
+    return lowdelay_dequantise(values[comp][index], qi, tables)

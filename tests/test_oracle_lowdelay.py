@@ -242,3 +242,26 @@ def test_slice_codes_read_by_the_stream_validated_reader():
                             assert b.sint() == band[y, x]
             if k == 0:
                 assert b.p - start == ylen
+
+
+def test_synth_slice_writer_against_the_oracle_decoder():
+    """bench.py's lowdelay_8k key makes its slices with tests/synth.py's writer (no oracle/ in bench.py's
+    product legs): what it writes must be what the oracle's decoder -- the restated reference reader --
+    reads, for every sub-band but the DC-predicted LL band, and the LL band before prediction."""
+    import json
+    P = synth.lowdelay_params(256, 64, (1, 0), 3, 32, 8, 155, 1)
+    data, kind, made = synth.lowdelay_picture(P, seed=11, kinds=5)
+    tables = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "quant_tables.json")))
+    dims = [(P["iwt_luma_height"], P["iwt_luma_width"])] + [(P["iwt_chroma_height"], P["iwt_chroma_width"])] * 2
+    got = [np.zeros(d, np.int32) for d in dims]
+    O.lowdelay_decode(data, got, P)
+    nx, ny, depth = P["n_horiz_slices"], P["n_vert_slices"], P["transform_depth"]
+    for sy in range(ny):
+        for sx in range(nx):
+            base, vals = made[int(kind[sy, sx])]
+            for comp, (h, w) in enumerate(dims):
+                for index in range(1, 1 + 3 * depth):
+                    _, c0, r0, step, bw, bh = synth.subband_geometry(w, h, depth, index)
+                    x0, x1, y0, y1 = bw * sx // nx, bw * (sx + 1) // nx, bh * sy // ny, bh * (sy + 1) // ny
+                    want = synth.lowdelay_expected_band(P, comp, index, base, vals, tables)
+                    assert np.array_equal(got[comp][r0 + step * y0:r0 + step * y1:step, c0 + x0:c0 + x1], want), (sy, sx, comp, index)
