@@ -109,14 +109,33 @@ class Workload:
 
     def step(self, alone=False):
         """alone: this step's launches share the device with no other step's (the steps whose
-        launches bench.py brackets with events, so that a kernel's duration is its own)."""
+        launches bench.py brackets with events, so that a kernel's duration is its own).
+        Order inside a batch (r03): the inverse wavelet first, then each reference plane set is
+        upsampled RIGHT BEFORE the OBMC launch that gathers from it -- luma planes, luma OBMC, chroma
+        planes, chroma OBMC -- so the half-pel planes (205 MB per batch, written once, gathered from at
+        random) are still in the 256 MB Infinity Cache when they are read, instead of having been
+        pushed out by the wavelet's 460 MB of streaming in between (SCHRO_BENCH_ORDER=0: the r02 order)."""
         c, k = self.ctx, self.k
         self.k += 1
+        order = int(os.environ.get("SCHRO_BENCH_ORDER", "2"))
+
+        def obmc_side(b):
+            if order == 0:
+                c.obmc_batch(b.obmc_jobs)
+            elif order == 1:
+                c.upsample_batch(b.up_pairs)
+                c.obmc_batch(b.obmc_jobs)
+            else:
+                c.upsample_batch([p for n, p in enumerate(b.up_pairs) if n % 3 == 0])
+                c.obmc_batch([j for n, j in enumerate(b.obmc_jobs) if n % 3 == 0])
+                c.upsample_batch([p for n, p in enumerate(b.up_pairs) if n % 3])
+                c.obmc_batch([j for n, j in enumerate(b.obmc_jobs) if n % 3])
         if self.queues == 1:
             b = self.sets[0]
-            c.upsample_batch(b.up_pairs)
+            if order == 0:
+                c.upsample_batch(b.up_pairs)
             c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
-            c.obmc_batch(b.obmc_jobs)
+            obmc_side(b)
             return
         s = k % self.queues
         b = self.sets[s]
@@ -125,12 +144,13 @@ class Workload:
             c.queue_wait(0, 1)              # the previous batch's OBMC has finished
         self.prev_alone = alone
         c.queue_wait_mark(8 + s)            # the OBMC that last read this batch's frames
-        c.upsample_batch(b.up_pairs)
+        if order == 0:
+            c.upsample_batch(b.up_pairs)
         c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
         c.queue_mark(s)
         c.select_queue(1)
         c.queue_wait_mark(s)
-        c.obmc_batch(b.obmc_jobs)
+        obmc_side(b)
         c.queue_mark(8 + s)
         c.select_queue(0)
 
@@ -522,10 +542,12 @@ def main():
                     help="only the timed workload: no CPU baseline, no 1080p / PCIe-inclusive extras "
                          "(profiler runs: every launch in the trace is a launch of the headline step)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
-    ap.add_argument("--profile-every", type=int, default=4,
-                    help="bracket the launches of every n-th timed step with HIP events; such a step "
-                         "runs alone on the device (no other batch beside it), so a kernel's duration "
-                         "is its own")
+    ap.add_argument("--profile-steps", type=int, default=-1,
+                    help="bracket the launches of the LAST n timed steps with HIP events (default: max (5, steps / 8)); "
+                         "such a step runs alone on the device (no other batch beside it), so a kernel's duration "
+                         "is its own; as one block at the end the two-queue pipeline drains once, not per sample")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="(r02 form) bracket every n-th timed step instead; n > steps: no samples")
     args = ap.parse_args()
     if args.gpus is None:           # under a launcher the world size is the number of GPUs
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -572,8 +594,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     profiled_steps = 0
+    n_samp = max(1, min(args.steps, args.profile_steps if args.profile_steps >= 0 else max(5, args.steps // 8)))
     for i in range(args.steps):
-        sample = i % max(args.profile_every, 1) == 0
+        sample = (i % args.profile_every == 0) if args.profile_every > 0 else i >= args.steps - n_samp
         ctx.profile_enable(sample)
         profiled_steps += sample
         wl.step(alone=sample)
