@@ -206,27 +206,60 @@ def iiwt_1080p(ctx, frames=8, steps=30):
     """BASELINE config 2: 3-level DD(9,7) inverse wavelet of 1920x1080 s16 pictures (4:2:0; the
     chroma coefficient frames are 960x544, padded to a multiple of 2^depth as the reference
     does, schroparams.c:75-92).  Median of `steps` batches of `frames` pictures, HIP events."""
+    import schroedinger_amd as sa
     dims = [(1080, 1920), (544, 960), (544, 960)]
     pairs = []
+    # the planes of all pictures in two blocks (coefficients, residuals), as a decoder's frame pool is
+    # (planes allocated one by one measure the same: SCHRO_BENCH_1080P_ARENA=0)
+    arena = os.environ.get("SCHRO_BENCH_1080P_ARENA", "1") != "0"
+    a_co = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * frames)) if arena else None
+    a_res = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * frames)) if arena else None
     for f in range(frames):
         for k, (h, w) in enumerate(dims):
-            pairs.append((ctx.upload(coeff_plane(h, w, 300 + 3 * f + k)), ctx.plane(h, w, np.int16)))
+            co = coeff_plane(h, w, 300 + 3 * f + k)
+            if arena:
+                pairs.append((a_co.plane(h, w, np.int16).upload(co), a_res.plane(h, w, np.int16)))
+            else:
+                pairs.append((ctx.upload(co), ctx.plane(h, w, np.int16)))
     for _ in range(5):
         ctx.iiwt_batch(pairs, DEPTH, FILTER)
+    # groups of 8 launch sets between one event pair: the host runs ahead of the device, as in a decoder
+    # whose queue is never empty (one launch set per event pair also times the host's table building:
+    # 0.051 against 0.039 ms for 8 pictures)
     ts = []
-    for _ in range(steps):
+    for _ in range(max(steps // 8, 3)):
         ctx.timer_begin()
-        ctx.iiwt_batch(pairs, DEPTH, FILTER)
-        ts.append(ctx.timer_end())
-    for a, b in pairs:
+        for _ in range(8):
+            ctx.iiwt_batch(pairs, DEPTH, FILTER)
+        ts.append(ctx.timer_end() / 8)
+    # two batches in flight, alternating between the kernel queues: the coarse levels of one (two launches
+    # of latency, 8 us each) run beside the finest level of the other
+    pairs2 = [(ctx.upload(a.download()), ctx.plane(b.height, b.width, np.int16)) for a, b in pairs]
+    for k in range(4):
+        ctx.select_queue(k % 2)
+        ctx.iiwt_batch(pairs2 if k % 2 else pairs, DEPTH, FILTER)
+    ctx.select_queue(0)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(32):
+        ctx.select_queue(k % 2)
+        ctx.iiwt_batch(pairs2 if k % 2 else pairs, DEPTH, FILTER)
+    ctx.select_queue(0)
+    ctx.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3 / 32
+    for a, b in pairs + pairs2:
         a.free()
         b.free()
+    if arena:
+        a_co.block.free()
+        a_res.block.free()
     ms = float(np.median(ts))
     samples = frames * sum(h * w for h, w in dims)
     return {"workload": "3-level DD(9,7) IIWT, %d x 1920x1080 4:2:0 s16 per launch set" % frames,
             "median_ms": round(ms, 4), "Mpix_per_s": round(frames * 1920 * 1080 / ms / 1e3, 1),
             "alg_GBs": round(4 * samples / (ms * 1e-3) / 1e9, 1),
-            "frac_of_8TBs": round(4 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            "frac_of_8TBs": round(4 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "two_batches_in_flight": {"ms": round(ms2, 4), "frac_of_8TBs": round(4 * samples / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
 def quantised_handover(h, w, depth, stride, seed):
