@@ -139,6 +139,17 @@ class Workload:
             return
         s = k % self.queues
         b = self.sets[s]
+        if os.environ.get("SCHRO_BENCH_PIPE", "whole") == "whole":
+            # each batch runs all its stages on ONE queue, the two batches in flight on different queues:
+            # no cross-queue dependency at all in the steady state
+            c.select_queue(s)
+            if alone or self.prev_alone:
+                c.queue_wait(s, 1 - s)
+            self.prev_alone = alone
+            c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
+            obmc_side(b)
+            c.select_queue(0)
+            return
         c.select_queue(0)
         if alone or self.prev_alone:
             c.queue_wait(0, 1)              # the previous batch's OBMC has finished
