@@ -823,6 +823,41 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   if (use_haar)
     iiwt_haar_geometry (&hcols, &hrows);
 
+  // r03: a depth-3 s32 Haar transform (the low-delay 10-bit configurations) is ONE pass over the
+  // coefficient frame when every plane allows it (iiwt_haar.hip, iiwt_haar3_s32_kernel);
+  // SCHRO_HIP_IIWT_HAAR3=0 keeps a launch per level
+  if (use_haar && depth == 3 && !nl && !(getenv ("SCHRO_HIP_IIWT_HAAR3") && atoi (getenv ("SCHRO_HIP_IIWT_HAAR3")) == 0)) {
+    bool all_ok = true;
+    for (int p = 0; p < nplanes && all_ok; p++)
+      all_ok = iiwt_haar3_job_ok (planes[p].src, planes[p].src_stride, planes[p].dst, planes[p].dst_stride, planes[p].width,
+          planes[p].height);
+    if (all_ok) {
+      int bxs, bys;
+      iiwt_haar3_geometry (&bxs, &bys);
+      std::vector < IwtJob > j3 (nplanes);
+      int tile_base = 0;
+      for (int p = 0; p < nplanes; p++) {
+        IwtJob & j = j3[p];
+        memset (&j, 0, sizeof (j));
+        j.sb[0] = planes[p].src;
+        j.sb_stride[0] = planes[p].src_stride;
+        j.dst = planes[p].dst;
+        j.dst_stride = planes[p].dst_stride;
+        j.w = planes[p].width;
+        j.h = planes[p].height;
+        j.tiles_x = div_up (j.w / 8, bxs);
+        j.tile_base = tile_base;
+        tile_base += j.tiles_x * div_up (j.h / 8, bys);
+      }
+      void *d_j3;
+      int r = push_args (ctx, j3.data (), sizeof (IwtJob) * j3.size (), &d_j3);
+      if (r)
+        return r;
+      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
+      return launch_iiwt_haar3 (ctx->stream, (const IwtJob *) d_j3, nplanes, tile_base, filter);
+    }
+  }
+
   std::vector < IwtJob > jobs, rjobs, hjobs;
   for (int level = depth - 1; level >= 0; level--) {
     if (nl && level >= fb && level < fb + nl) {

@@ -82,7 +82,122 @@ void iiwt_haar_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)
   gstore < u32x4 > (d1 + 16, (u32x4) { odd[4], odd[5], odd[6], odd[7] });
 }
 
+// ---- r03: all three levels of a depth-3 Haar transform in one pass ------------------------------
+// Without halos the whole synthesis is local: an 8x8 block of output samples depends on one LL2
+// coefficient, one of each level-2 detail band, 2x2 of each level-1 band and 4x4 of each finest band --
+// 64 coefficients, all in the 8 frame rows of the block (the in-place layout interleaves the levels'
+// ROWS: level l's view is {w >> l, h >> l, stride << l}; its columns are split low | high).  A lane
+// owns one block: 22 loads (4 dwords, 6 x 8 bytes, 12 x 16 bytes; adjacent lanes = adjacent blocks, so
+// every load instruction reads contiguous runs), three levels of haar_pair in registers, 16 stores of
+// 16 bytes.  The coefficient frame is read once and the pixels written once: 8 B per sample instead
+// of the per-level launches' 10.5 (levels 1 and 2 went through the intermediate LL planes).
+constexpr int kHaar3Rows = kHaarThreads / 64;    // rows of blocks per workgroup (64 blocks wide)
+
+template < int SHIFT >
+__device__ __forceinline__ void
+haar_quad (uint32_t ll, uint32_t hl, uint32_t lh, uint32_t hh, uint32_t * o00, uint32_t * o01, uint32_t * o10, uint32_t * o11)
+{
+  haar_pair (ll, lh);
+  haar_pair (hl, hh);
+  haar_pair (ll, hl);
+  haar_pair (lh, hh);
+  if constexpr (SHIFT) {
+    ll = avgs0 (ll);
+    hl = avgs0 (hl);
+    lh = avgs0 (lh);
+    hh = avgs0 (hh);
+  }
+  *o00 = ll;
+  *o01 = hl;
+  *o10 = lh;
+  *o11 = hh;
+}
+
+template < int SHIFT >
+__global__ __launch_bounds__ (kHaarThreads)
+void iiwt_haar3_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)
+{
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const IwtJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int ty = t / job.tiles_x, tx = t - ty * job.tiles_x;
+  const int w = job.w, nbx = w / 8, nby = job.h / 8;
+  const int bx = tx * 64 + (int) (threadIdx.x & 63), by = ty * kHaar3Rows + (int) (threadIdx.x >> 6);
+  if (bx >= nbx || by >= nby)
+    return;
+  const char *base = (const char *) job.sb[0] + (size_t) (8 * by) * job.sb_stride[0];
+  const size_t S = (size_t) job.sb_stride[0];
+  // level 2 (the coarsest): one coefficient per band; LL2 / HL2 in frame row 8 by, LH2 / HH2 in row 8 by + 4
+  const uint32_t ll2 = gload < uint32_t > (base + (size_t) bx * 4), hl2 = gload < uint32_t > (base + (size_t) (w / 8 + bx) * 4);
+  const uint32_t lh2 = gload < uint32_t > (base + 4 * S + (size_t) bx * 4), hh2 = gload < uint32_t > (base + 4 * S + (size_t) (w / 8 + bx) * 4);
+  // level 1: 2 x 2 per band; HL1 in rows 8 by + 4 i, LH1 / HH1 in rows 8 by + 4 i + 2
+  u32x2 hl1[2], lh1[2], hh1[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    hl1[i] = gload < u32x2 > (base + (size_t) (4 * i) * S + (size_t) (w / 4 + 2 * bx) * 4);
+    lh1[i] = gload < u32x2 > (base + (size_t) (4 * i + 2) * S + (size_t) (2 * bx) * 4);
+    hh1[i] = gload < u32x2 > (base + (size_t) (4 * i + 2) * S + (size_t) (w / 4 + 2 * bx) * 4);
+  }
+  // level 0: 4 x 4 per band; HL0 in rows 8 by + 2 i, LH0 / HH0 in rows 8 by + 2 i + 1
+  u32x4 hl0[4], lh0[4], hh0[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    hl0[i] = gload < u32x4 > (base + (size_t) (2 * i) * S + (size_t) (w / 2 + 4 * bx) * 4);
+    lh0[i] = gload < u32x4 > (base + (size_t) (2 * i + 1) * S + (size_t) (4 * bx) * 4);
+    hh0[i] = gload < u32x4 > (base + (size_t) (2 * i + 1) * S + (size_t) (w / 2 + 4 * bx) * 4);
+  }
+  uint32_t l1[2][2], l0[4][4], px[8][8];
+  haar_quad < SHIFT > (ll2, hl2, lh2, hh2, &l1[0][0], &l1[0][1], &l1[1][0], &l1[1][1]);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      haar_quad < SHIFT > (l1[i][j], hl1[i][j], lh1[i][j], hh1[i][j], &l0[2 * i][2 * j], &l0[2 * i][2 * j + 1],
+          &l0[2 * i + 1][2 * j], &l0[2 * i + 1][2 * j + 1]);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      haar_quad < SHIFT > (l0[i][j], hl0[i][j], lh0[i][j], hh0[i][j], &px[2 * i][2 * j], &px[2 * i][2 * j + 1],
+          &px[2 * i + 1][2 * j], &px[2 * i + 1][2 * j + 1]);
+  char *d = (char *) job.dst + (size_t) (8 * by) * job.dst_stride + (size_t) (8 * bx) * 4;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    gstore < u32x4 > (d + (size_t) r * job.dst_stride, (u32x4) { px[r][0], px[r][1], px[r][2], px[r][3] });
+    gstore < u32x4 > (d + (size_t) r * job.dst_stride + 16, (u32x4) { px[r][4], px[r][5], px[r][6], px[r][7] });
+  }
+}
+
 }                               // namespace
+
+// the three-level form: a depth-3 s32 Haar transform of a plane whose rows and band origins are 16-byte
+// aligned (job.sb[0] / sb_stride[0]: the coefficient plane; w, h: the plane's size)
+bool
+iiwt_haar3_job_ok (const void *src, int src_stride, const void *dst, int dst_stride, int w, int h)
+{
+  return ((((uintptr_t) src | (uintptr_t) src_stride | (uintptr_t) dst | (uintptr_t) dst_stride) & 15) == 0) && w % 32 == 0
+      && h % 8 == 0 && w >= 32 && h >= 8;
+}
+
+void
+iiwt_haar3_geometry (int *blocks_x, int *blocks_y)
+{
+  *blocks_x = 64;
+  *blocks_y = kHaar3Rows;
+}
+
+int
+launch_iiwt_haar3 (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter)
+{
+  if (filter == 3)
+    hipLaunchKernelGGL ((iiwt_haar3_s32_kernel < 0 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+  else
+    hipLaunchKernelGGL ((iiwt_haar3_s32_kernel < 1 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "iiwt (Haar s32, three levels) launch: %s", hipGetErrorString (e));
+  return 0;
+}
 
 // which levels this form takes: s32, Haar, every sub-band row and the destination 16-byte aligned,
 // whole groups of four columns

@@ -308,6 +308,10 @@ bool iiwt_haar_supported (int filter, int bpp);
 bool iiwt_haar_job_ok (const IwtJob & j);
 void iiwt_haar_geometry (int *cols, int *rows);
 int launch_iiwt_haar (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter);
+// ... all three levels of a depth-3 transform in one pass (r03)
+bool iiwt_haar3_job_ok (const void *src, int src_stride, const void *dst, int dst_stride, int w, int h);
+void iiwt_haar3_geometry (int *blocks_x, int *blocks_y);
+int launch_iiwt_haar3 (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter);
 // register form of one level (iiwt_reg.hip): s16, filters with a small lifting halo
 bool iiwt_reg_supported (int filter, int bpp);
 void iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pairs,

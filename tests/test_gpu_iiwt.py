@@ -149,3 +149,18 @@ def test_argument_errors(ctx):
         ctx.iiwt_batch([(a, a)], 1, 0)          # in-place is refused, not silently wrong
     a.free()
     b.free()
+
+
+@pytest.mark.parametrize("filt", [3, 4])
+def test_three_level_haar_in_one_pass(ctx, filt, monkeypatch):
+    # r03: a depth-3 s32 Haar transform is one launch (iiwt_haar3_s32_kernel) where every plane allows it
+    # (width a multiple of 32, 16-byte aligned rows); the per-level form (SCHRO_HIP_IIWT_HAAR3=0) and the
+    # oracle must agree with it, also on full-range values (32-bit wrap) and where it does not apply
+    for (h, w) in [(8, 32), (72, 96), (264, 480), (48, 40)]:
+        for arr in (O.forward_iwt(synth.image_s(h, w, np.int32, seed=h + w) * 4, 3, filt), synth.full_range(h, w, np.int32, seed=3 * h)):
+            want = O.inverse_iwt(arr, 3, filt)
+            monkeypatch.delenv("SCHRO_HIP_IIWT_HAAR3", raising=False)
+            assert np.array_equal(gpu_iiwt(ctx, arr, 3, filt), want), (filt, h, w, "one pass")
+            monkeypatch.setenv("SCHRO_HIP_IIWT_HAAR3", "0")
+            assert np.array_equal(gpu_iiwt(ctx, arr, 3, filt), want), (filt, h, w, "per level")
+    monkeypatch.delenv("SCHRO_HIP_IIWT_HAAR3", raising=False)
