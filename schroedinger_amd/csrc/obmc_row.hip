@@ -52,7 +52,8 @@ constexpr int kRAccW = 85;
 template < int ND > struct RowCaps {
   static constexpr int kBlk = ND <= 2 ? 352 : 128, kItem = ND <= 2 ? 1792 : 1024;
 };
-constexpr int kRWCap = 32 * 8;          // (row, pixel pair) weight words: 2 * ND per row, zero beyond the block
+// (row, pixel pair) weight words: 2 * ND per row (zero beyond the block), 32 rows
+template < int ND > constexpr int kRWCapOf = 32 * 2 * ND;
 // Item classes (one straight-line pass body each): both references / the first / the second / DC /
 // edge (windows clamped vertically and / or folded weights, any mode: still a row per lane) / rim (DC
 // values outside 8 bits, geometries beyond the weight table: per sample).  Inside the reference
@@ -362,7 +363,7 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     // weights folded at the picture's rim (schromotion8.c:673-693): 1-D tables per edge type behind
     // the plain products -- (left | right << 1) pairs of x weights, (top | bottom << 1) y weights
     const uint32_t fb = ((uint32_t) hb.flags >> 2) & 15u;
-    const uint32_t *wxf = s_wp + kRWCap + 8 * (fb >> 2), *wyf = s_wp + kRWCap + 32 + 32 * (fb & 3u);
+    const uint32_t *wxf = s_wp + kRWCapOf < ND > + 8 * (fb >> 2), *wyf = s_wp + kRWCapOf < ND > + 32 + 32 * (fb & 3u);
     const uint32_t wy2 = wyf[row] * 0x00010001u;
 #pragma unroll
     for (int k = 0; k < 2 * ND; k++)
@@ -597,13 +598,13 @@ __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * kRAccW];
-  __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
+  __shared__ int s_wx[16], s_wy[32];    // (obmc_row_nd: blocks up to 16 x 32)
   constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
   __shared__ uint16_t s_meta[kRBlkCap];         // slot | first item within the slot << 5
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
-  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCap + 32 + 128];      // + folded x pairs, folded y (edge class)
+  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCapOf < ND > + 32 + 128];      // + folded x pairs, folded y (edge class)
   __shared__ int s_icnt[kRSlots];               // items of each slot
   __shared__ int s_nrim, s_wide;
 
@@ -662,7 +663,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     __syncthreads ();           // ramps, counters
     // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
     // 2 * ND words, zero beyond the block's width
-    for (int i = tid; i < yblen * 2 * ND && i < kRWCap; i += kRThreads) {
+    for (int i = tid; i < yblen * 2 * ND && i < kRWCapOf < ND >; i += kRThreads) {
       const int r = i / (2 * ND), pr = i - r * (2 * ND);
       s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
     }
@@ -682,11 +683,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       };
       if (tid < 32) {
         const int type = tid >> 3, pr = tid & 7;
-        s_wp[kRWCap + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
+        s_wp[kRWCapOf < ND > + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
             | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
       } else {
         const int type = (tid - 32) >> 5, r = (tid - 32) & 31;
-        s_wp[kRWCap + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
+        s_wp[kRWCapOf < ND > + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
       }
     }
     RSTAMP (1);
@@ -754,7 +755,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       if (wide_dc)
         s_wide = 1;
       int key;
-      if (off_h || wide_dc || yblen * 2 * ND > kRWCap || xblen > 16) {
+      if (off_h || wide_dc || yblen * 2 * ND > kRWCapOf < ND > || xblen > 16) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
         // (16 bits each: obmc_row_nd keeps planes whose origins do not fit away from this kernel)
