@@ -625,10 +625,17 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   static_assert ((TH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
   for (int it = tid; it < TH * kRAccW / 4; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
+#ifdef SCHRO_ROW_DBG_NOWT      // (scratch builds, wrong results: the set-up without its weight tables)
+  if (tid < 16)
+    s_wx[tid] = 8;
+  if (tid >= 64 && tid < 96)
+    s_wy[tid - 64] = 8;
+#else
   if (tid < job.xblen)
     s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
   if (tid >= 64 && tid - 64 < job.yblen)
     s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
+#endif
   if (tid >= 128 && tid < 128 + kRSlots)
     s_icnt[tid - 128] = 0;
   if (tid == 192) {
@@ -663,6 +670,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     __syncthreads ();           // ramps, counters
     // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
     // 2 * ND words, zero beyond the block's width
+#ifdef SCHRO_ROW_DBG_NOWT
+    if (tid < kRWCapOf < ND >)
+      s_wp[tid] = 0x00400040u;
+    if (0)
+#endif
     for (int i = tid; i < yblen * 2 * ND && i < kRWCapOf < ND >; i += kRThreads) {
       const int r = i / (2 * ND), pr = i - r * (2 * ND);
       s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
