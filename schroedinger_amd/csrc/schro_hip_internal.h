@@ -392,7 +392,7 @@ struct SchroHipContext {
     hipEvent_t copied;          // the slot's last host -> device copy
     bool copy_pending;
   };
-  static constexpr int kArgSlots = 128;        // kArgSlots / kQueues per queue
+  static constexpr int kArgSlots = 256;        // kArgSlots / kQueues per queue
   static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in api.cpp)
   char *h_args;                 // kArgSlots pinned mirrors
   char *d_args;
