@@ -593,7 +593,7 @@ def main():
                          "(profiler runs: every launch in the trace is a launch of the headline step)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads for the CPU baseline (0: auto)")
     ap.add_argument("--profile-steps", type=int, default=-1,
-                    help="bracket the launches of the LAST n timed steps with HIP events (default: max (5, steps / 8)); "
+                    help="time the launches of the LAST n timed steps with HIP events (default: max (3, steps / 8)); "
                          "such a step runs alone on the device (no other batch beside it), so a kernel's duration "
                          "is its own; as one block at the end the two-queue pipeline drains once, not per sample")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -644,7 +644,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     profiled_steps = 0
-    n_samp = max(1, min(args.steps, args.profile_steps if args.profile_steps >= 0 else max(5, args.steps // 8)))
+    n_samp = max(1, min(args.steps, args.profile_steps if args.profile_steps >= 0 else max(3, args.steps // 8)))
     for i in range(args.steps):
         sample = (i % args.profile_every == 0) if args.profile_every > 0 else i >= args.steps - n_samp
         ctx.profile_enable(sample)

@@ -145,9 +145,10 @@ int schro_hip_timer_begin (SchroHipContext * ctx);
 float schro_hip_timer_end (SchroHipContext * ctx);
 
 /* Per-kernel HIP-event profiling.  When enabled, every kernel launch of the
- * plane layer is bracketed by an event pair on the context stream;
- * schro_hip_profile_read synchronises and returns the summed elapsed time and
- * the number of launches of one kernel class since the last reset.  bench.py
+ * plane layer carries a start / stop event pair of its own (hipExtLaunchKernelGGL:
+ * the kernel's begin and end as the dispatch records them, nothing extra on the
+ * queue); schro_hip_profile_read synchronises and returns the summed elapsed time
+ * and the number of launches of one kernel class since the last reset.  bench.py
  * uses this for the roofline figure of the dominant kernel. */
 #define SCHRO_HIP_KERNEL_IIWT_FINEST 0  /* level-0 launch of the inverse wavelet */
 #define SCHRO_HIP_KERNEL_IIWT_COARSE 1  /* levels >= 1 */

@@ -100,31 +100,43 @@ ensure_scratch (SchroHipContext * ctx, size_t bytes)
   return 0;
 }
 
-ProfileScope::ProfileScope (SchroHipContext * c, int cls):ctx (c), idx (-1)
+static thread_local SchroHipContext *t_prof_ctx = nullptr;
+static thread_local int t_prof_cls = 0;
+
+ProfileScope::ProfileScope (SchroHipContext * c, int cls)
 {
-  if (!c->profile)
-    return;
-  if (c->ev_used == c->ev_pool.size ()) {
-    if (c->ev_pool.size () >= 16384)
-      return;                   // pool exhausted: stop sampling, keep running
-    SchroHipContext::EvPair p;
-    if (hipEventCreate (&p.a) != hipSuccess)
-      return;
-    if (hipEventCreate (&p.b) != hipSuccess) {
-      (void) hipEventDestroy (p.a);
-      return;
-    }
-    c->ev_pool.push_back (p);
-  }
-  idx = (int) c->ev_used++;
-  c->ev_pool[idx].cls = cls;
-  (void) hipEventRecord (c->ev_pool[idx].a, c->stream);
+  t_prof_ctx = c->profile ? c : nullptr;
+  t_prof_cls = cls;
 }
 
 ProfileScope::~ProfileScope ()
 {
-  if (idx >= 0)
-    (void) hipEventRecord (ctx->ev_pool[idx].b, ctx->stream);
+  t_prof_ctx = nullptr;
+}
+
+bool
+profile_launch_events (hipEvent_t * start, hipEvent_t * stop)
+{
+  SchroHipContext *c = t_prof_ctx;
+  if (!c)
+    return false;
+  if (c->ev_used == c->ev_pool.size ()) {
+    if (c->ev_pool.size () >= 16384)
+      return false;             // pool exhausted: stop sampling, keep running
+    SchroHipContext::EvPair p;
+    if (hipEventCreate (&p.a) != hipSuccess)
+      return false;
+    if (hipEventCreate (&p.b) != hipSuccess) {
+      (void) hipEventDestroy (p.a);
+      return false;
+    }
+    c->ev_pool.push_back (p);
+  }
+  const size_t idx = c->ev_used++;
+  c->ev_pool[idx].cls = t_prof_cls;
+  *start = c->ev_pool[idx].a;
+  *stop = c->ev_pool[idx].b;
+  return true;
 }
 
 }                               // namespace schro

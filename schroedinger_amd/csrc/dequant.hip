@@ -146,11 +146,11 @@ int
 launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith)
 {
   if (bpp == 2 && arith == 1)
-    hipLaunchKernelGGL ((dequant_kernel < int16_t, 1 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((dequant_kernel < int16_t, 1 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
   else if (bpp == 2)
-    hipLaunchKernelGGL ((dequant_kernel < int16_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((dequant_kernel < int16_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
   else
-    hipLaunchKernelGGL ((dequant_kernel < int32_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((dequant_kernel < int32_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "dequant launch: %s", hipGetErrorString (e));

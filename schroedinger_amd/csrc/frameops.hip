@@ -580,10 +580,10 @@ int
 launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp, int shift)
 {
   if (bpp == 2)
-    hipLaunchKernelGGL ((shift_right_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
+    SCHRO_LAUNCH ((shift_right_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
         njobs, shift);
   else
-    hipLaunchKernelGGL ((shift_right_kernel < int32_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
+    SCHRO_LAUNCH ((shift_right_kernel < int32_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
         njobs, shift);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
@@ -601,7 +601,7 @@ pack_tile_geometry (int *groups_x, int *rows)
 int
 launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int total_tiles)
 {
-  hipLaunchKernelGGL (pack_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs, njobs);
+  SCHRO_LAUNCH (pack_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "pack launch: %s", hipGetErrorString (e));
@@ -619,10 +619,10 @@ int
 launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp)
 {
   if (bpp == 2)
-    hipLaunchKernelGGL ((convert_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0,
+    SCHRO_LAUNCH ((convert_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0,
         stream, d_jobs, njobs);
   else
-    hipLaunchKernelGGL ((convert_kernel < int32_t >), dim3 (total_tiles), dim3 (kThreads), 0,
+    SCHRO_LAUNCH ((convert_kernel < int32_t >), dim3 (total_tiles), dim3 (kThreads), 0,
         stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
@@ -640,7 +640,7 @@ upsample_tile_geometry (int *tw, int *th)
 int
 launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs, int njobs, int total_tiles)
 {
-  hipLaunchKernelGGL (upsample_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
+  SCHRO_LAUNCH (upsample_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
       njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)

@@ -667,7 +667,7 @@ template < typename T, int F >
 int
 launch_one (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles)
 {
-  hipLaunchKernelGGL ((iiwt_level_kernel < T, F >), dim3 (total_tiles), dim3 (kThreads), 0,
+  SCHRO_LAUNCH ((iiwt_level_kernel < T, F >), dim3 (total_tiles), dim3 (kThreads), 0,
       stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
@@ -710,14 +710,14 @@ launch_fused_one (hipStream_t stream, const void *d_jobs, int njobs, int total_t
   bool launched = false;
   if constexpr (MAXL >= 3) {
     if (nl == 3) {
-      hipLaunchKernelGGL ((iiwt_fused_kernel < T, F, 3 >), dim3 (total_tiles), dim3 (kThreads), 0,
+      SCHRO_LAUNCH ((iiwt_fused_kernel < T, F, 3 >), dim3 (total_tiles), dim3 (kThreads), 0,
           stream, (const IwtFusedJob *) d_jobs, njobs);
       launched = true;
     }
   }
   if constexpr (MAXL >= 2) {
     if (nl == 2) {
-      hipLaunchKernelGGL ((iiwt_fused_kernel < T, F, 2 >), dim3 (total_tiles), dim3 (kThreads), 0,
+      SCHRO_LAUNCH ((iiwt_fused_kernel < T, F, 2 >), dim3 (total_tiles), dim3 (kThreads), 0,
           stream, (const IwtFusedJob *) d_jobs, njobs);
       launched = true;
     }

@@ -190,9 +190,9 @@ int
 launch_iiwt_haar3 (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter)
 {
   if (filter == 3)
-    hipLaunchKernelGGL ((iiwt_haar3_s32_kernel < 0 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((iiwt_haar3_s32_kernel < 0 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
   else
-    hipLaunchKernelGGL ((iiwt_haar3_s32_kernel < 1 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((iiwt_haar3_s32_kernel < 1 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "iiwt (Haar s32, three levels) launch: %s", hipGetErrorString (e));
@@ -227,9 +227,9 @@ int
 launch_iiwt_haar (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter)
 {
   if (filter == 3)
-    hipLaunchKernelGGL ((iiwt_haar_s32_kernel < 0 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((iiwt_haar_s32_kernel < 0 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
   else
-    hipLaunchKernelGGL ((iiwt_haar_s32_kernel < 1 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
+    SCHRO_LAUNCH ((iiwt_haar_s32_kernel < 1 >), dim3 (total_tiles), dim3 (kHaarThreads), 0, stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "iiwt (Haar s32) launch: %s", hipGetErrorString (e));

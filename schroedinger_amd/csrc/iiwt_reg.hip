@@ -386,10 +386,10 @@ launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tile
 {
   const int wgs = (total_tiles + kRegThreads / 64 - 1) / (kRegThreads / 64);
   if (small)
-    hipLaunchKernelGGL ((iiwt_reg_kernel < F, small_rp (F) >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, small_rp (F) >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
         d_jobs, njobs, total_tiles);
   else
-    hipLaunchKernelGGL ((iiwt_reg_kernel < F, kRegRP >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, kRegRP >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
         njobs, total_tiles);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)

@@ -610,11 +610,11 @@ launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const Sli
   static const bool split = !getenv ("SCHRO_HIP_SLICE_SPLIT") || atoi (getenv ("SCHRO_HIP_SLICE_SPLIT")) != 0;
   const dim3 grid ((unsigned) ((P.nh * P.nv + 63) / 64), (unsigned) njobs, split ? 2u : 1u);
   if (bpp == 4)
-    hipLaunchKernelGGL ((slice_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), 0, stream, d_jobs, P);
+    SCHRO_LAUNCH ((slice_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), 0, stream, d_jobs, P);
   else if (arith == SCHRO_HIP_LOWDELAY_FAST16)
-    hipLaunchKernelGGL ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_FAST16 >), grid, dim3 (64), 0, stream, d_jobs, P);
+    SCHRO_LAUNCH ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_FAST16 >), grid, dim3 (64), 0, stream, d_jobs, P);
   else
-    hipLaunchKernelGGL ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_SLOW16 >), grid, dim3 (64), 0, stream, d_jobs, P);
+    SCHRO_LAUNCH ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_SLOW16 >), grid, dim3 (64), 0, stream, d_jobs, P);
   const hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "slice kernel launch: %s", hipGetErrorString (e));
@@ -627,9 +627,9 @@ launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_
   // whole waves; a band taller than kDcRows is walked in slabs
   const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);
   if (bpp == 4)
-    hipLaunchKernelGGL ((dc_predict_kernel < int32_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+    SCHRO_LAUNCH ((dc_predict_kernel < int32_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
   else
-    hipLaunchKernelGGL ((dc_predict_kernel < int16_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+    SCHRO_LAUNCH ((dc_predict_kernel < int16_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
   const hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "dc_predict kernel launch: %s", hipGetErrorString (e));

@@ -853,10 +853,10 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
   // five that fit, to leave registers for a kernel on the other queue (experiments)
   static const int lds_pad = getenv ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (getenv ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
   if (variant == 1)
-    hipLaunchKernelGGL ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), lds_pad, stream,
+    SCHRO_LAUNCH ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), lds_pad, stream,
         d_jobs, njobs, d_order);
   else
-    hipLaunchKernelGGL ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,
+    SCHRO_LAUNCH ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,
         stream, d_jobs, njobs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstddef>
 #include <vector>
@@ -24,6 +25,22 @@ int set_error (int code, const char *fmt, ...);
   do {                                                                         \
     if (!(cond))                                                               \
       return schro::set_error (SCHRO_HIP_EINVAL, __VA_ARGS__);                 \
+  } while (0)
+
+// Every kernel launch of the library goes through SCHRO_LAUNCH.  While a ProfileScope of a
+// profiling context is open (schro_hip_profile_enable), the launch carries a start / stop event pair
+// (hipExtLaunchKernelGGL): the events take the kernel's own begin and end from the dispatch's completion
+// signal -- the duration rocprofv3 reports -- and put nothing else on the queue.  (r02 bracketed every
+// launch with two hipEventRecord: 8 us of barrier packets per launch, 0.12 ms per profiled bench step.)
+bool profile_launch_events (hipEvent_t * start, hipEvent_t * stop);
+
+#define SCHRO_LAUNCH(kernel, grid, block, shmem, stream, ...)                                      \
+  do {                                                                                             \
+    hipEvent_t pa_, pb_;                                                                           \
+    if (schro::profile_launch_events (&pa_, &pb_))                                                 \
+      hipExtLaunchKernelGGL (kernel, grid, block, shmem, stream, pa_, pb_, 0, __VA_ARGS__);       \
+    else                                                                                           \
+      hipLaunchKernelGGL (kernel, grid, block, shmem, stream, __VA_ARGS__);                        \
   } while (0)
 
 // ---- job tables handed to the kernels (device memory, one per launch) ------
@@ -435,10 +452,8 @@ namespace schro {
 int push_args (SchroHipContext * ctx, const void *host, size_t bytes,
     void **dev);
 int ensure_scratch (SchroHipContext * ctx, size_t bytes);
-// bracket one launch with an event pair when profiling is on
+// the launches made while a scope is open are timed under its kernel class (when profiling is on)
 struct ProfileScope {
-  SchroHipContext *ctx;
-  int idx;
   ProfileScope (SchroHipContext * c, int cls);
   ~ProfileScope ();
 };
