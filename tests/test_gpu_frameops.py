@@ -3,10 +3,13 @@
 Upsample follows testsuite/upsample.c's design (sizes 1..20 squared, all
 planes) with the oracle's exact restatement of schroframe.c as the reference.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
+import schroedinger_amd as sa
 import synth
 
 pytestmark = pytest.mark.gpu
@@ -89,3 +92,38 @@ def test_convert_picture_size(ctx):
     assert np.array_equal(dst.download(), O.convert_u8(src_np, 1920, 1080))
     src.free()
     dst.free()
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (5, 7), (16, 16), (33, 47), (64, 130), (135, 240), (270, 481)])
+def test_half_pel_planes_every_home_and_the_aprons(ctx, h, w):
+    """The r03 half-pel buffer byte by byte (include/schro_hip.h): every column of every plane sits in
+    TWO chunks (byte xp & 15 of chunk xp >> 4 and byte 16 + (xp & 15) of the chunk before), and 32
+    columns either side plus everything up to the end of the last chunk repeat the edge sample of plane 0
+    (planes 0, 1) / plane 2 (planes 2, 3) -- schro_frame_mc_edgeextend_horiz's sources in
+    schro_upsampled_frame_upsample (schroframe.c:2012-2029).  schro_hip_upsampled_download reads one home
+    only; the OBMC kernels read both and the aprons."""
+    pic = synth.picture_u8(h, w, seed=h * 31 + w)
+    src, dst = ctx.upload(pic), ctx.hp_plane(h, w).fill(0xa5)
+    ctx.upsample_batch([(src, dst)])
+    up = O.UpComp(pic)
+    planes = [up.plane(i) for i in range(4)]
+    raw = np.empty((1, dst.nbytes), np.uint8)
+    sa.check(ctx.lib.schro_hip_download_2d(ctx.h, raw.ctypes.data_as(C.c_void_p), dst.nbytes, dst.ptr, dst.nbytes,
+                                          dst.nbytes, 1))
+    raw = raw.reshape(-1)
+    stride = dst.stride
+    nch = stride // 512
+    assert nch == (w + 64 + 15) // 16 + 1
+    for p in range(4):
+        edge_src = planes[0] if p < 2 else planes[2]
+        for y in range(h):
+            # expected padded row: 32 apron columns, the plane's row, aprons to the end of the last chunk
+            cols = 16 * nch + 16
+            want = np.empty(cols, np.uint8)
+            want[:32] = edge_src[y, 0]
+            want[32:32 + w] = planes[p][y]
+            want[32 + w:] = edge_src[y, w - 1]
+            base = (y >> 2) * stride + p * 128 + (y & 3) * 32
+            for c in range(nch):
+                got = raw[base + c * 512: base + c * 512 + 32]
+                assert np.array_equal(got, want[16 * c:16 * c + 32]), (p, y, c)
