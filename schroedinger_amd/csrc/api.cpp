@@ -1384,6 +1384,7 @@ schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture *
 
   std::vector < SliceJob > jobs (npictures);
   std::vector < DcJob > dc (3 * (size_t) npictures);
+  bool aligned16 = true;
   for (int p = 0; p < npictures; p++) {
     const SchroHipLowDelayPicture & pic = pictures[p];
     SCHRO_HIP_REQUIRE (pic.slices && (int64_t) pic.slices_bytes >= need && pic.slices_bytes < ((size_t) 1 << 28),
@@ -1398,6 +1399,7 @@ schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture *
           && (uintptr_t) pic.comp[k] % bytes_per_sample == 0, "lowdelay_batch: picture %d component %d invalid", p, k);
       j.comp[k] = pic.comp[k];
       j.stride[k] = pic.stride[k];
+      aligned16 = aligned16 && (((uintptr_t) pic.comp[k] | (uintptr_t) pic.stride[k]) & 15) == 0;
       DcJob & d = dc[3 * (size_t) p + k];
       d.data = pic.comp[k];             // the LL band: sub-band 0 of schro_subband_get_frame_data
       d.stride = pic.stride[k] << depth;
@@ -1412,7 +1414,7 @@ schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture *
     return r;
   {
     ProfileScope ps (ctx, SCHRO_HIP_KERNEL_SLICES);
-    r = launch_slices (ctx->stream, (const SliceJob *) d_jobs, npictures, P, bytes_per_sample, arith);
+    r = launch_slices (ctx->stream, (const SliceJob *) d_jobs, npictures, P, bytes_per_sample, arith, aligned16);
     if (r)
       return r;
   }

@@ -65,6 +65,9 @@ struct BitReader {
     if ((j >> 2) != pidx) {
       res = nxt;
       pidx++;
+      // (keeps the load below the copy: scheduled above it, its result needs registers of its own
+      // and the move into nxt -- with a wait for the load -- comes right behind it)
+      asm volatile ("" : "+v" (res) : : "memory");
       nxt = fetch_piece (pidx + 1);
     }
     return pick (res, j & 3u);
@@ -339,6 +342,319 @@ void slice_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
   }
 }
 
+// ---- r03: slice_run_kernel -- the same slices, a step per NON-ZERO value --------------------
+// slice_kernel is bound by vector issue (rocprofv3: 75 VALU instructions per code and lane, the
+// SIMDs issuing 80 % of the time), and most codes of a low-delay slice are the single bit "1" =
+// value 0 (a 32x8 slice of config 5 has 2.4 bits per value to spend).  Here a lane's step is: count
+// the leading ones of its 32-bit window (= that many zeros, which are already in the staging:
+// it is zero-filled and every copy-out puts zeros back), then decode the code behind them out of
+// the SAME window when it ends inside it.  A wave takes as many steps per staging turn as its
+// busiest lane has non-zero values (+ one per 32 zeros in a row), not as many as there are values.
+// A staging turn = as many whole rows of a sub-band's slice rectangle as fit kRunCap words per lane
+// (U and V interleaved as they come); the copy-out is slice_kernel's (one contiguous run per slice
+// row, 16 bytes per lane), rectangles narrower than 16 bytes go out value by value.
+// The host takes this kernel when every sub-band divides evenly into the slices, a rectangle row
+// fits the staging and the planes are 16-byte aligned (launch_slices); slice_kernel stays for the rest.
+// Words per lane: the smallest of 16 / 32 / 64 that holds a rectangle row (16: 4.3 KB of LDS per
+// wave; with 62 VGPRs 6 waves per SIMD are resident -- measured on config 5: 16 words 0.082 ms per
+// picture, 32 words 0.090, 64 words 0.113: occupancy is worth more than longer turns).
+constexpr int kRunCapMin = 16, kRunCapMax = 64;
+
+// MSB-first reader whose dwords get their guard ones (bits at or beyond `end` read as 1) when they
+// are fetched, not at every peek; between two peeks the position moves by at most 32 bits.
+struct RunReader {
+  const uint32_t *base;
+  uint32_t pos, end, last_piece;
+  uint32_t w0, w1, widx;
+  u32x4 res, nxt;
+  uint32_t pidx;
+
+  __device__ __forceinline__ u32x4 fetch_piece (uint32_t pi) const
+  {
+    return gload < u32x4 > (base + 4u * min (pi, last_piece));
+  }
+  __device__ __forceinline__ uint32_t guarded (uint32_t w, uint32_t j) const
+  {
+    const uint32_t first = 32u * j;
+    const uint32_t left = end > first ? end - first : 0u;      // bits of dword j before `end`
+    return left < 32u ? w | (0xffffffffu >> left) : w;
+  }
+  __device__ __forceinline__ uint32_t take (uint32_t j)
+  {
+    if ((j >> 2) != pidx) {
+      res = nxt;
+      pidx++;
+      // (the load must not be scheduled above the copy: its result would then need registers of
+      // its own, and the move into nxt -- with a wait for the load -- would come right behind it)
+      asm volatile ("" : "+v" (res) : : "memory");
+      nxt = fetch_piece (pidx + 1);
+    }
+    return guarded (BitReader::pick (res, j & 3u), j);
+  }
+  __device__ __forceinline__ void start (const BitReader & b, uint32_t p, uint32_t e)
+  {
+    base = b.base;
+    last_piece = b.last_piece;
+    pos = p;
+    end = e;
+    widx = p >> 5;
+    pidx = widx >> 2;
+    res = fetch_piece (pidx);
+    nxt = fetch_piece (pidx + 1);
+    w0 = guarded (BitReader::pick (res, widx & 3u), widx);
+    w1 = take (widx + 1);
+  }
+  __device__ __forceinline__ uint32_t peek ()
+  {
+    const uint32_t wi = pos >> 5;
+    if (wi != widx) {
+      w0 = w1;
+      w1 = take (wi + 1);
+      widx = wi;
+    }
+    return (uint32_t) (((((uint64_t) w0) << 32 | w1) << (pos & 31u)) >> 32);
+  }
+  __device__ __forceinline__ uint32_t bit ()
+  {
+    const uint32_t v = peek () >> 31;
+    pos++;
+    return v;
+  }
+  // any code (BitReader::sint)
+  __device__ __forceinline__ int32_t sint ()
+  {
+    const uint32_t v = peek ();
+    const uint32_t stop = v & 0xaaaaaaaau;
+    const int k = __clz ((int) stop);
+    if (k <= 30) {
+      const int c = k >> 1;
+      if (c == 0) {
+        pos += 1;
+        return 0;
+      }
+      const uint32_t mag = (1u << c) - 1u + even_bits (v >> (32 - k));
+      const uint32_t neg = (v >> (30 - k)) & 1u;
+      pos += k + 2;
+      return neg ? -(int32_t) mag : (int32_t) mag;
+    }
+    uint32_t count = 0, value = 0;
+    while (!bit ()) {
+      count++;
+      value = (value << 1) | bit ();
+    }
+    value += (count < 32u ? 1u << count : 0u) - 1u;
+    if (value && bit ())
+      value = 0u - value;
+    return (int32_t) value;
+  }
+  // bits 0, 2, 4 ... 30 of t packed into bits 0 ... 15
+  static __device__ __forceinline__ uint32_t even_bits (uint32_t t)
+  {
+    t &= 0x55555555u;
+    t = (t | (t >> 1)) & 0x33333333u;
+    t = (t | (t >> 2)) & 0x0f0f0f0fu;
+    t = (t | (t >> 4)) & 0x00ff00ffu;
+    return (t | (t >> 8)) & 0x0000ffffu;
+  }
+};
+
+__device__ __forceinline__ void
+wave_sync ()
+{
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier ();
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one staging turn of a lane: values 0 .. n - 1 of its string, the non-zero ones into mine[]
+template < int ARITH >
+__device__ __forceinline__ void
+run_turn (RunReader & r, int32_t * mine, int n, uint32_t qf, uint32_t qo)
+{
+  int i = 0;
+  while (i < n) {
+    const uint32_t v = r.peek ();
+    const uint32_t ones = (uint32_t) __clz ((int) ~v);          // 32 when the window is all ones
+    const uint32_t z = min (ones, (uint32_t) (n - i));
+    i += (int) z;
+    r.pos += z;
+    if (i < n) {                // (then z == ones: the bit behind the zeros is a 0, or z == 32)
+      const uint32_t u = v << (z & 31u);
+      const uint32_t k = (uint32_t) __clz ((int) (u & 0xaaaaaaaau));    // 2 * data bits, >= 2 when z < 32
+      int32_t d;
+      if (__builtin_expect (z + k <= 30u, 1)) { // the code ends inside this window
+        const uint32_t mag = (1u << (k >> 1)) - 1u + RunReader::even_bits (u >> (32u - k));      // never 0
+        const bool neg = (u >> (30u - k)) & 1u;
+        r.pos += k + 2u;
+        if constexpr (ARITH == SCHRO_HIP_LOWDELAY_FAST16) {
+          d = dequant_s16 (neg ? -(int32_t) mag : (int32_t) mag, qf, qo);
+        } else {
+          // dequant_int of a magnitude below 2^16 (factor < 2^18): a 24-bit multiply, modulo 2^32
+          uint32_t a_u;
+          asm ("v_mad_u32_u24 %0, %1, %2, %3" : "=v" (a_u) : "v" (mag), "v" (qf), "v" (qo + 2u));
+          const int32_t a = (int32_t) a_u >> 2;
+          d = neg ? -a : a;
+        }
+      } else {
+        const int32_t q = r.sint ();
+        d = ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? dequant_s16 (q, qf, qo) : dequant_int (q, qf, qo);
+      }
+      mine[i] = d;
+      i++;
+    }
+  }
+}
+
+// one component string (K = 0: luma; K = 1: U and V interleaved) of the wave's slices
+template < typename T, int ARITH, int K >
+__device__ __forceinline__ void
+run_string (RunReader & r, const SliceJob & job, const SliceParams & P, int32_t * stage, uint64_t (*rowbase)[64],
+    int lane, int sx, int sy, int nvalid, bool active, int base_index)
+{
+  const int kRunCap = P.run_cap, kRunPitch = kRunCap + 1;
+  constexpr int E = 16 / (int) sizeof (T);
+  constexpr int C = K + 1;
+  const int iwt_w = K ? P.iwt_cw : P.iwt_lw, iwt_h = K ? P.iwt_ch : P.iwt_lh;
+  uint8_t *const plane[2] = { (uint8_t *) (K ? job.comp[1] : job.comp[0]), (uint8_t *) job.comp[2] };
+  const int plane_stride[2] = { K ? job.stride[1] : job.stride[0], job.stride[2] };
+  const int nsub = 1 + 3 * P.depth;
+  int32_t *mine = stage + lane * kRunPitch;
+#pragma unroll 1
+  for (int i = 0; i < nsub; i++) {
+    const int qi = min (max (base_index - P.quant_matrix[i], 0), 60);
+    const uint32_t qf = kQuant.factor[qi], qo = kQuant.offset[qi];
+    const int position = subband_position (i);
+    const int shift = P.depth - (position >> 2);
+    const int w = iwt_w >> shift, h = iwt_h >> shift;
+    const int ebw = w / P.nh, ebh = h / P.nv;           // (the host checked: no remainders)
+    size_t pitch[2];
+    uint8_t *dst[2];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      pitch[c] = (size_t) plane_stride[c] << shift;
+      dst[c] = plane[c] + ((position & 2) ? pitch[c] >> 1 : 0) + ((position & 1) ? (size_t) w * sizeof (T) : 0)
+          + (size_t) (ebh * sy) * pitch[c] + (size_t) (ebw * sx) * sizeof (T);
+    }
+    const bool rows_out = ebw % E == 0;
+    if (rows_out) {
+#pragma unroll
+      for (int c = 0; c < C; c++)
+        rowbase[c][lane] = (uint64_t) (uintptr_t) dst[c];
+    }
+    const int rows_turn = min (ebh, kRunCap / (C * ebw));
+    const int cpl = ebw / E;
+    const uint32_t m_cpl = div_magic (max (cpl, 1));
+    const int nchunk = nvalid * cpl;
+#pragma unroll 1
+    for (int y0 = 0; y0 < ebh; y0 += rows_turn) {
+      const int rows = min (rows_turn, ebh - y0);
+      run_turn < ARITH > (r, mine, C * rows * ebw, qf, qo);
+      wave_sync ();
+      if (rows_out) {
+#pragma unroll 1
+        for (int y = 0; y < rows; y++) {
+#pragma unroll
+          for (int c = 0; c < C; c++) {
+#pragma unroll 1
+            for (int ch = lane; ch < nchunk; ch += 64) {
+              const int src = mdiv (ch, cpl, m_cpl), xc = ch - src * cpl;
+              int32_t *from = stage + src * kRunPitch + C * (y * ebw + xc * E) + c;
+              uint32_t e[E];
+#pragma unroll
+              for (int j = 0; j < E; j++)
+                e[j] = (uint32_t) from[C * j];
+#pragma unroll
+              for (int j = 0; j < E; j++)
+                from[C * j] = 0;
+              u32x4 o;
+              if constexpr (E == 4)
+                o = u32x4 { e[0], e[1], e[2], e[3] };
+              else
+                o = u32x4 { (e[0] & 0xffffu) | (e[1] << 16), (e[2] & 0xffffu) | (e[3] << 16),
+                  (e[4] & 0xffffu) | (e[5] << 16), (e[6] & 0xffffu) | (e[7] << 16) };
+              uint8_t *to = (uint8_t *) (uintptr_t) rowbase[c][src] + (size_t) (y0 + y) * pitch[c] + (size_t) xc * 16;
+              __builtin_nontemporal_store (o, (SCHRO_GLOBAL u32x4 *) to);
+            }
+          }
+        }
+      } else {
+        // a rectangle narrower than 16 bytes: each lane its own values
+#pragma unroll 1
+        for (int y = 0; y < rows; y++) {
+#pragma unroll 1
+          for (int x = 0; x < ebw; x++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+              int32_t *from = mine + C * (y * ebw + x) + c;
+              const int32_t d = *from;
+              *from = 0;
+              if (active)
+                gstore < T > ((T *) (dst[c] + (size_t) (y0 + y) * pitch[c]) + x, (T) d);
+            }
+          }
+        }
+      }
+      wave_sync ();             // the next turn writes the staging
+    }
+  }
+}
+
+#ifndef SCHRO_RUN_WAVES
+#define SCHRO_RUN_WAVES 6
+#endif
+template < typename T, int ARITH >
+__global__ __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (SCHRO_RUN_WAVES, SCHRO_RUN_WAVES)))
+void slice_run_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
+{
+  extern __shared__ int32_t stage[];    // 64 * (P.run_cap + 1) words
+  __shared__ uint64_t rowbase[2][64];
+  const SliceJob job = jobs[blockIdx.y];
+  const int lane = (int) threadIdx.x;
+  const int nslices = P.nh * P.nv;
+  const int s0 = blockIdx.x * 64, s = s0 + lane;
+  const bool active = s < nslices;
+  const int nvalid = min (64, nslices - s0);
+  const int sc = active ? s : nslices - 1;
+  const int sy = sc / P.nh, sx = sc - sy * P.nh;
+  const uint32_t wraps = (uint32_t) (((uint64_t) sc * (uint32_t) P.remainder) / (uint32_t) P.denom);
+  const uint32_t wraps1 = (uint32_t) (((uint64_t) (sc + 1) * (uint32_t) P.remainder) / (uint32_t) P.denom);
+  const uint32_t offset = (uint32_t) sc * (uint32_t) P.n_bytes + wraps;
+  const uint32_t slice_bytes = (uint32_t) P.n_bytes + (wraps1 - wraps);
+
+  for (int j = lane; j < 64 * (P.run_cap + 1); j += 64)
+    stage[j] = 0;
+
+  // the slice header, with slice_kernel's reader
+  const uintptr_t addr = (uintptr_t) job.data;
+  BitReader hb;
+  hb.base = (const uint32_t *) (addr & ~(uintptr_t) 15);
+  const uint32_t lead = 8u * (uint32_t) (addr & 15);
+  const uint32_t buffer_end = lead + 8u * job.data_bytes;
+  hb.last_piece = (buffer_end - 1u) >> 7;
+  const uint32_t slice_end = active ? lead + 8u * (offset + slice_bytes) : 0u;
+  hb.end = slice_end;
+  hb.start (lead + 8u * offset);
+  const int base_index = (int) hb.bits (7);
+  const uint32_t field = 8u * (ARITH == SCHRO_HIP_LOWDELAY_FAST16 ? (uint32_t) P.n_bytes : slice_bytes);
+  const int length_bits = field ? 32 - __clz ((int) field) : 0;
+  const uint32_t slice_y_length = hb.bits (length_bits);
+  const uint32_t y_pos = hb.pos;
+  const uint32_t y_end = active ? min (y_pos + slice_y_length, buffer_end) : 0u;
+  const uint32_t uv_pos = y_pos + slice_y_length;
+  wave_sync ();
+
+  const int k_first = gridDim.z == 2 ? (int) blockIdx.z : 0, k_last = gridDim.z == 2 ? (int) blockIdx.z : 1;
+  RunReader r;
+  if (k_first == 0) {
+    r.start (hb, y_pos, y_end);
+    run_string < T, ARITH, 0 > (r, job, P, stage, rowbase, lane, sx, sy, nvalid, active, base_index);
+  }
+  if (k_last == 1) {
+    r.start (hb, uv_pos, slice_end);
+    run_string < T, ARITH, 1 > (r, job, P, stage, rowbase, lane, sx, sy, nvalid, active, base_index);
+  }
+}
+
 // ---- DC prediction ---------------------------------------------------------------------
 // x[j][i] += pred (x[j][i-1], x[j-1][i], x[j-1][i-1]): serial along rows AND columns, only
 // the anti-diagonals are independent.  One workgroup per band; thread r owns row band0 + r
@@ -603,13 +919,48 @@ void dc_predict_kernel (const DcJob * __restrict__ jobs)
   }
 }
 
-int
-launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith)
+// slice_run_kernel's conditions: every sub-band divides evenly into the slices and a row of a
+// slice rectangle (U and V together) fits a staging turn; the words per lane it then takes, or 0
+static int
+slice_run_cap (const SliceParams & P)
 {
-  // (SCHRO_HIP_SLICE_SPLIT=0: one workgroup decodes both strings of its slices)
+  int widest = 0;
+  for (int k = 0; k < 2; k++) {
+    for (int level = 0; level <= P.depth; level++) {
+      const int shift = level == 0 ? P.depth : P.depth - level + 1;     // LL and level 1 have the same size
+      const int w = (k ? P.iwt_cw : P.iwt_lw) >> shift, h = (k ? P.iwt_ch : P.iwt_lh) >> shift;
+      if (w <= 0 || h <= 0 || w % P.nh || h % P.nv)
+        return 0;
+      widest = std::max (widest, (k + 1) * (w / P.nh));
+    }
+  }
+  for (int cap = kRunCapMin; cap <= kRunCapMax; cap *= 2)
+    if (widest <= cap)
+      return cap;
+  return 0;
+}
+
+int
+launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P0, int bpp, int arith,
+    bool aligned16)
+{
+  SliceParams P = P0;
+  // (SCHRO_HIP_SLICE_SPLIT=0: one workgroup decodes both strings of its slices;
+  //  SCHRO_HIP_SLICE_RUNS=0: slice_kernel -- a step per value -- for every geometry)
   static const bool split = !getenv ("SCHRO_HIP_SLICE_SPLIT") || atoi (getenv ("SCHRO_HIP_SLICE_SPLIT")) != 0;
+  const char *env = getenv ("SCHRO_HIP_SLICE_RUNS");
+  P.run_cap = aligned16 && !(env && atoi (env) == 0) ? slice_run_cap (P) : 0;
+  const bool runs = P.run_cap != 0;
+  const size_t lds = 64 * (size_t) (P.run_cap + 1) * sizeof (int32_t);
   const dim3 grid ((unsigned) ((P.nh * P.nv + 63) / 64), (unsigned) njobs, split ? 2u : 1u);
-  if (bpp == 4)
+  if (runs) {
+    if (bpp == 4)
+      SCHRO_LAUNCH ((slice_run_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), lds, stream, d_jobs, P);
+    else if (arith == SCHRO_HIP_LOWDELAY_FAST16)
+      SCHRO_LAUNCH ((slice_run_kernel < int16_t, SCHRO_HIP_LOWDELAY_FAST16 >), grid, dim3 (64), lds, stream, d_jobs, P);
+    else
+      SCHRO_LAUNCH ((slice_run_kernel < int16_t, SCHRO_HIP_LOWDELAY_SLOW16 >), grid, dim3 (64), lds, stream, d_jobs, P);
+  } else if (bpp == 4)
     SCHRO_LAUNCH ((slice_kernel < int32_t, SCHRO_HIP_LOWDELAY_S32 >), grid, dim3 (64), 0, stream, d_jobs, P);
   else if (arith == SCHRO_HIP_LOWDELAY_FAST16)
     SCHRO_LAUNCH ((slice_kernel < int16_t, SCHRO_HIP_LOWDELAY_FAST16 >), grid, dim3 (64), 0, stream, d_jobs, P);

@@ -143,6 +143,7 @@ struct SliceParams {
   int nh, nv;
   int n_bytes, remainder, denom;        // slice_bytes_num / _denom split, schrolowdelay.c:601-602
   int quant_matrix[SCHRO_HIP_LIMIT_SUBBANDS];
+  int run_cap;                          // slice_run_kernel: staging words per lane (launch_slices sets it)
 };
 
 struct DcJob {
@@ -346,8 +347,8 @@ void pack_tile_geometry (int *groups_x, int *rows);
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);
 void upsample_tile_geometry (int *tw, int *th);
-int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P,
-    int bpp, int arith);
+int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith,
+    bool aligned16);
 int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 void dequant_tile_geometry (int *tw, int *th);

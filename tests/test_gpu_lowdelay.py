@@ -69,12 +69,24 @@ GEOMETRIES = [
     (16, 16, (1, 1), 0, 8, 8, 150, 1, None),            # depth 0
     (200, 24, (1, 1), 1, 8, 8, 90, 1, (25, 3)),         # more slices per row than a wave has lanes... of 3 rows
     (1040, 16, (1, 0), 1, 16, 16, 255, 2, None),        # 65 slices in a row: two waves, field width changes (255/2)
+    (256, 32, (1, 0), 2, 64, 8, 300, 1, None),          # rectangle rows of 32 values: 32 staging words per lane
+    (512, 32, (1, 0), 1, 128, 8, 1201, 2, None),        # rows of 64 values: 64 words
+    (512, 16, (0, 0), 1, 128, 8, 900, 1, None),         # U and V rows of 128 values together: slice_kernel takes it
 ]
+
+
+@pytest.fixture(params=["runs", "values"])
+def slice_kernel(request, monkeypatch):
+    """Both slice kernels: slice_run_kernel (a step per non-zero value) where the geometry allows it,
+    and slice_kernel (a step per value) for everything."""
+    if request.param == "values":
+        monkeypatch.setenv("SCHRO_HIP_SLICE_RUNS", "0")
+    return request.param
 
 
 @pytest.mark.parametrize("bpp", [2, 4])
 @pytest.mark.parametrize("geo", GEOMETRIES)
-def test_legal_streams(ctx, geo, bpp):
+def test_legal_streams(ctx, geo, bpp, slice_kernel):
     w, h, chroma, depth, sw, sh, num, den, override = geo
     P = synth.lowdelay_params(w, h, chroma, depth, sw, sh, num, den)
     if override:
@@ -91,7 +103,7 @@ def test_legal_streams(ctx, geo, bpp):
 
 
 @pytest.mark.parametrize("bpp", [2, 4])
-def test_long_codes_wrap_and_quantiser_range(ctx, bpp):
+def test_long_codes_wrap_and_quantiser_range(ctx, bpp, slice_kernel):
     # values beyond the 32-bit decode window (|v| >= 65535), products that wrap in 16 / 32 bits,
     # base indices up to 127 (quantiser index clamps at 60; schrolowdelay.c:140)
     for override in (None, (5, 3)):
@@ -107,7 +119,7 @@ def test_long_codes_wrap_and_quantiser_range(ctx, bpp):
 
 
 @pytest.mark.parametrize("bpp", [2, 4])
-def test_short_slices_and_corrupt_lengths(ctx, bpp):
+def test_short_slices_and_corrupt_lengths(ctx, bpp, slice_kernel):
     # codes cut off by the end of the slice (guard bits), slice_y_length fields that point
     # short of / beyond the luma codes and beyond the slice (the reference then reads the next
     # slice's bytes; at the end of the buffer it would read out of bounds, we read guard bits)
