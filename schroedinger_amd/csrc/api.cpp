@@ -100,6 +100,40 @@ ensure_scratch (SchroHipContext * ctx, size_t bytes)
   return 0;
 }
 
+int
+dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned long long **edge, int *edge_pitch,
+    uint32_t * epoch)
+{
+  void *&buf = ctx->dc_edge_q[ctx->cur];
+  size_t & size = ctx->dc_edge_size_q[ctx->cur];
+  const int strips = (max_rows + 63) / 64;
+  const size_t bytes = (size_t) njobs * strips * max_w * sizeof (unsigned long long);
+  if (bytes > size) {
+    if (buf) {
+      SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+      SCHRO_HIP_CHECK (hipFree (buf));
+      buf = nullptr;
+      size = 0;
+    }
+    SCHRO_HIP_CHECK (hipMalloc (&buf, bytes));
+    size = bytes;
+    // tag 0 = "never written": epochs start at 1
+    SCHRO_HIP_CHECK (hipMemsetAsync (buf, 0, bytes, ctx->stream));
+  }
+  if (++ctx->dc_epoch == 0) {   // the counter wrapped: old tags must not look new
+    for (int q = 0; q < SchroHipContext::kQueues; q++)
+      if (ctx->dc_edge_q[q]) {
+        SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[q]));
+        SCHRO_HIP_CHECK (hipMemset (ctx->dc_edge_q[q], 0, ctx->dc_edge_size_q[q]));
+      }
+    ctx->dc_epoch = 1;
+  }
+  *edge = (unsigned long long *) buf;
+  *edge_pitch = max_w;
+  *epoch = ctx->dc_epoch;
+  return 0;
+}
+
 static thread_local SchroHipContext *t_prof_ctx = nullptr;
 static thread_local int t_prof_cls = 0;
 
@@ -341,7 +375,10 @@ schro_hip_context_new (int device)
   ctx->domain_bytes = 0;
   for (int q = 0; q < SchroHipContext::kQueues; q++) {
     ctx->scratch_q[q] = nullptr;
+    ctx->dc_edge_q[q] = nullptr;
+    ctx->dc_edge_size_q[q] = 0;
     ctx->scratch_size_q[q] = 0;
+    ctx->dc_epoch = 0;
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
   }
@@ -418,9 +455,12 @@ schro_hip_context_free (SchroHipContext * ctx)
       (void) hipStreamSynchronize (ctx->streams[q]);
   for (auto & s : ctx->slots)
     (void) hipFree (s.ptr);
-  for (int q = 0; q < SchroHipContext::kQueues; q++)
+  for (int q = 0; q < SchroHipContext::kQueues; q++) {
     if (ctx->scratch_q[q])
       (void) hipFree (ctx->scratch_q[q]);
+    if (ctx->dc_edge_q[q])
+      (void) hipFree (ctx->dc_edge_q[q]);
+  }
   for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
     if (ctx->order_slots[k].d)
       (void) hipFree (ctx->order_slots[k].d);
@@ -1197,7 +1237,7 @@ schro_hip_dc_predict_batch (SchroHipContext * ctx, const SchroHipDcPlane * plane
   SCHRO_HIP_REQUIRE (bytes_per_sample == 2 || bytes_per_sample == 4, "dc_predict_batch: bytes_per_sample must be 2 or 4");
   (void) hipSetDevice (ctx->device);
   std::vector < DcJob > jobs (nplanes);
-  int max_rows = 1;
+  int max_rows = 1, max_w = 1;
   for (int p = 0; p < nplanes; p++) {
     const SchroHipDcPlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.data && pl.width > 0 && pl.height > 0 && pl.stride >= pl.width * bytes_per_sample
@@ -1209,13 +1249,23 @@ schro_hip_dc_predict_batch (SchroHipContext * ctx, const SchroHipDcPlane * plane
     jobs[p].h = pl.height;
     jobs[p].pad = 0;
     max_rows = std::max (max_rows, pl.height);
+    max_w = std::max (max_w, pl.width);
   }
   void *d_jobs;
   int r = push_args (ctx, jobs.data (), sizeof (DcJob) * nplanes, &d_jobs);
   if (r)
     return r;
+  unsigned long long *edge = nullptr;
+  int edge_pitch = 0;
+  uint32_t epoch = 0;
+  if (dc_skew_ok (jobs.data (), nplanes, bytes_per_sample)) {
+    r = dc_edge_for (ctx, nplanes, max_rows, max_w, &edge, &edge_pitch, &epoch);
+    if (r)
+      return r;
+  }
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
-  return launch_dc_predict (ctx->stream, (const DcJob *) d_jobs, nplanes, max_rows, bytes_per_sample);
+  return launch_dc_predict (ctx->stream, (const DcJob *) d_jobs, nplanes, max_rows, bytes_per_sample, edge, edge_pitch,
+      epoch);
 }
 
 int
@@ -1422,9 +1472,18 @@ schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture *
   r = push_args (ctx, dc.data (), sizeof (DcJob) * dc.size (), &d_dc);
   if (r)
     return r;
+  unsigned long long *edge = nullptr;
+  int edge_pitch = 0;
+  uint32_t epoch = 0;
+  if (dc_skew_ok (dc.data (), (int) dc.size (), bytes_per_sample)) {
+    r = dc_edge_for (ctx, (int) dc.size (), lp.iwt_luma_height >> depth, lp.iwt_luma_width >> depth, &edge, &edge_pitch,
+        &epoch);
+    if (r)
+      return r;
+  }
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
   return launch_dc_predict (ctx->stream, (const DcJob *) d_dc, (int) dc.size (), lp.iwt_luma_height >> depth,
-      bytes_per_sample);
+      bytes_per_sample, edge, edge_pitch, epoch);
 }
 
 int

@@ -509,7 +509,7 @@ run_turn (RunReader & r, int32_t * mine, int n, uint32_t qf, uint32_t qo)
 template < typename T, int ARITH, int K >
 __device__ __forceinline__ void
 run_string (RunReader & r, const SliceJob & job, const SliceParams & P, int32_t * stage, uint64_t (*rowbase)[64],
-    int lane, int sx, int sy, int nvalid, bool active, int base_index)
+    const uint32_t (*quant)[64], int lane, int sx, int sy, int nvalid, bool active, int base_index)
 {
   const int kRunCap = P.run_cap, kRunPitch = kRunCap + 1;
   constexpr int E = 16 / (int) sizeof (T);
@@ -522,7 +522,7 @@ run_string (RunReader & r, const SliceJob & job, const SliceParams & P, int32_t 
 #pragma unroll 1
   for (int i = 0; i < nsub; i++) {
     const int qi = min (max (base_index - P.quant_matrix[i], 0), 60);
-    const uint32_t qf = kQuant.factor[qi], qo = kQuant.offset[qi];
+    const uint32_t qf = quant[0][qi], qo = quant[1][qi];        // (from LDS: a memory round trip per sub-band otherwise)
     const int position = subband_position (i);
     const int shift = P.depth - (position >> 2);
     const int w = iwt_w >> shift, h = iwt_h >> shift;
@@ -608,6 +608,7 @@ void slice_run_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
 {
   extern __shared__ int32_t stage[];    // 64 * (P.run_cap + 1) words
   __shared__ uint64_t rowbase[2][64];
+  __shared__ uint32_t quant[2][64];     // kQuant
   const SliceJob job = jobs[blockIdx.y];
   const int lane = (int) threadIdx.x;
   const int nslices = P.nh * P.nv;
@@ -623,6 +624,8 @@ void slice_run_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
 
   for (int j = lane; j < 64 * (P.run_cap + 1); j += 64)
     stage[j] = 0;
+  quant[0][lane] = kQuant.factor[min (lane, 60)];
+  quant[1][lane] = kQuant.offset[min (lane, 60)];
 
   // the slice header, with slice_kernel's reader
   const uintptr_t addr = (uintptr_t) job.data;
@@ -647,11 +650,11 @@ void slice_run_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
   RunReader r;
   if (k_first == 0) {
     r.start (hb, y_pos, y_end);
-    run_string < T, ARITH, 0 > (r, job, P, stage, rowbase, lane, sx, sy, nvalid, active, base_index);
+    run_string < T, ARITH, 0 > (r, job, P, stage, rowbase, quant, lane, sx, sy, nvalid, active, base_index);
   }
   if (k_last == 1) {
     r.start (hb, uv_pos, slice_end);
-    run_string < T, ARITH, 1 > (r, job, P, stage, rowbase, lane, sx, sy, nvalid, active, base_index);
+    run_string < T, ARITH, 1 > (r, job, P, stage, rowbase, quant, lane, sx, sy, nvalid, active, base_index);
   }
 }
 
@@ -972,15 +975,345 @@ launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const Sli
   return 0;
 }
 
-int
-launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp)
+// ---- r03: dc_skew_kernel -- the same prediction, one sample per step, strips on separate CUs ----
+// dc_predict_kernel steps by 16-byte pieces with a workgroup barrier per step: 0.5 us per step, 780
+// steps for the 960x540 luma band of config 5.  Here a strip of 64 rows is a workgroup of two waves:
+//  * the COMPUTE wave: lane r = row r of the strip, one SAMPLE behind lane r - 1, so what a lane needs
+//    from the row above is the neighbour lane's result of the step before (one DPP wave shift -- no
+//    LDS exchange, no barrier) and its own `up` of the step before.  It touches LDS only, a block of
+//    16 samples at a time: its rows come out of a ring of 16 blocks per row, its results go into a
+//    ring of 8.  A lone wave issues an instruction every ~6 cycles whatever it is, so a step is
+//    priced in instructions: 8 for s32 (DPP, two adds, the floor division by 3 in five, the sample);
+//  * the MOVER wave keeps the rings going: 4 blocks per row on their way from memory at any time
+//    (the compute wave takes a block every ~0.8 us, less than a memory round trip), finished blocks
+//    out to the band, the strip's last row to the strip below, the last row of the strip above in.
+//    The two meet in three LDS counters (blocks ready / blocks done / blocks stored); a wave's LDS
+//    operations execute in order, so a counter written behind the data is seen behind the data.
+// The strips of a band are workgroups on different CUs.  Strip k + 1 takes the last row of strip k
+// from a hand-over buffer in which every sample carries the launch's epoch (one 64-bit relaxed
+// device-scope store per sample: a sample is valid when its tag is, no fence), and runs 64 samples
+// + the hand-over behind it.  Strips are dispatched in order, so a strip that waits always waits
+// for one that is already running.  w + h + (hand-overs) steps of ~10 instructions instead of
+// w / E + h steps of a workgroup barrier each.
+constexpr int kSkewBlock = 16;  // samples per block
+constexpr int kSkewIn = 16;     // ring of the rows: blocks per row (+ 1: block 0 again behind the last, for reads across the end)
+constexpr int kSkewOut = 8;     // ring of the results (+ 1: samples written across the end)
+constexpr int kSkewDepth = 4;   // blocks per row on their way from memory
+
+template < typename T >
+struct SkewRings {
+  static constexpr int G = kSkewBlock * (int) sizeof (T) / 16;  // 16-byte pieces per block
+  u32x4 in[64][(kSkewIn + 1) * G];
+  u32x4 out[64][(kSkewOut + 1) * G];
+  int32_t above[kSkewIn * kSkewBlock];  // the row above the strip (lane 0's `up`)
+  int ready;                    // blocks of every row (and of the row above) in the ring
+  int done;                     // blocks the compute wave has finished
+  int stored;                   // blocks of every row out of the ring
+};
+
+__device__ __forceinline__ int
+lds_peek (const int *p)
 {
-  // whole waves; a band taller than kDcRows is walked in slabs
-  const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);
-  if (bpp == 4)
-    SCHRO_LAUNCH ((dc_predict_kernel < int32_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+  const int v = __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile ("" : : : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void
+lds_post (int *p, int v)
+{
+  asm volatile ("" : : : "memory");     // (behind the data in program order; the LDS keeps a wave's order)
+  __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one sample of every lane.  EDGE: lanes may be before their row's first or behind its last sample.
+template < typename T, bool FIRST_STRIP, bool EDGE >
+__device__ __forceinline__ int32_t
+dc_skew_step (int32_t q, int32_t from_above, int32_t & left, int32_t & upleft, int x, int w_lane, bool first_row)
+{
+  // the neighbour lane's result of the step before = this column of the row above (lane 0: handed over)
+  const int32_t up = __builtin_amdgcn_update_dpp (from_above, left, 0x138 /* wave_shr:1 */ , 0xf, 0xf, false);
+  const int32_t a = (int32_t) ((uint32_t) up + (uint32_t) upleft + 1u + (uint32_t) left);
+  int32_t mean;
+  if constexpr (sizeof (T) == 4) {
+    // dc_mean3 < int32_t > without a compare: n = a < 0 ? a - 2 : a (wrapping), n / 3 truncated
+    const int32_t n = (int32_t) ((uint32_t) a + ((uint32_t) (a >> 31) << 1));
+    mean = __mulhi (n, 0x55555556) + (int32_t) ((uint32_t) n >> 31);
+  } else {
+    mean = dc_mean3 < T > (a);
+  }
+  int32_t pred = mean;
+  if (EDGE)
+    pred = x == 0 ? up : pred;
+  if (FIRST_STRIP)
+    pred = first_row ? left : pred;
+  const int32_t v = (int32_t) (T) ((uint32_t) q + (uint32_t) pred);
+  upleft = up;
+  if (EDGE)
+    left = (unsigned) x < (unsigned) w_lane ? v : left;
   else
-    SCHRO_LAUNCH ((dc_predict_kernel < int16_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+    left = v;
+  return v;
+}
+
+template < typename T, bool FIRST_STRIP >
+__device__ __forceinline__ void
+dc_skew_compute (SkewRings < T > &sh, const DcJob & job)
+{
+  constexpr int B = kSkewBlock, SZ = (int) sizeof (T);
+  const int lane = (int) threadIdx.x;
+  const int w = job.w, nblocks = (w + B - 1) / B;
+  const int j = (int) blockIdx.x * 64 + lane;
+  const bool first_row = j == 0;
+  const int w_lane = j < job.h ? w : 0;
+  const uint8_t *const my_in = reinterpret_cast < const uint8_t * >(&sh.in[lane][0]);
+  uint8_t *const my_out = reinterpret_cast < uint8_t * >(&sh.out[lane][0]);
+  int32_t left = 0, upleft = 0;
+  int32_t q[B], a[B];           // this block's samples of the lane's row / of the row above the strip
+#pragma unroll
+  for (int e = 0; e < B; e++)
+    q[e] = a[e] = 0;
+  int ready = 0, stored = 0;    // the counters as last seen
+  // lane 63 finishes its row 63 steps behind lane 0; the mover stores a block when lane 63 is through
+  // with it, which it sees from `done` being 5 blocks further
+  const int turns = nblocks + 4;
+#pragma unroll 1
+  for (int b = -1; b < turns; b++) {
+    // ---- the next block's samples out of the rings (lane 0 is in block b + 1 then) ------------------
+    const int need = min (b + 2, nblocks);
+    while (ready < need) {
+      ready = lds_peek (&sh.ready);
+      if (ready < need)
+        __builtin_amdgcn_s_sleep (1);
+    }
+    int32_t qn[B], an[B];
+    const int xn = (b + 1) * B - lane;          // this lane's sample at the next block's first step
+    const uint8_t *from = my_in + ((xn * SZ) & (kSkewIn * B * SZ - 1)); // (B samples from here: up to a block across the ring's end)
+#pragma unroll
+    for (int e = 0; e < B; e++) {
+      qn[e] = (int32_t) * reinterpret_cast < const T * >(from + e * SZ);
+      an[e] = FIRST_STRIP ? 0 : sh.above[((b + 1) & (kSkewIn - 1)) * B + e];
+    }
+    if (b >= 0) {
+      // ---- room for this block's results: the block that had their place is out of the ring ----------
+      while (stored < b - (kSkewOut - 1)) {
+        stored = lds_peek (&sh.stored);
+        if (stored < b - (kSkewOut - 1))
+          __builtin_amdgcn_s_sleep (1);
+      }
+      // ---- B steps ----------------------------------------------------------------------------------------
+      const int xg = b * B - lane;
+      uint8_t *to = my_out + ((xg * SZ) & (kSkewOut * B * SZ - 1));
+      if (b * B >= 63 && b * B + B <= w) {      // every lane is inside its row for the whole block
+#pragma unroll
+        for (int e = 0; e < B; e++)
+          *reinterpret_cast < T * >(to + e * SZ) =
+              (T) dc_skew_step < T, FIRST_STRIP, false > (q[e], a[e], left, upleft, xg + e, w_lane, first_row);
+      } else {
+        // (a sample before / behind the row lands in a place that is rewritten before / done with after its store)
+#pragma unroll
+        for (int e = 0; e < B; e++)
+          *reinterpret_cast < T * >(to + e * SZ) =
+              (T) dc_skew_step < T, FIRST_STRIP, true > (q[e], a[e], left, upleft, xg + e, w_lane, first_row);
+      }
+      lds_post (&sh.done, b + 1);
+    }
+#pragma unroll
+    for (int e = 0; e < B; e++) {
+      q[e] = qn[e];
+      a[e] = an[e];
+    }
+  }
+}
+
+template < typename T, bool FIRST_STRIP >
+__device__ __forceinline__ void
+dc_skew_move (SkewRings < T > &sh, const DcJob & job, unsigned long long *edge, int edge_pitch, uint32_t epoch)
+{
+  constexpr int B = kSkewBlock, E = 16 / (int) sizeof (T), G = B / E, D = kSkewDepth;
+  const int strip = (int) blockIdx.x, strips = (int) gridDim.x;
+  const int lane = (int) threadIdx.x - 64;
+  const int w = job.w, npieces = w / E, nblocks = (w + B - 1) / B;
+  const int j = strip * 64 + lane;
+  const bool have_row = j < job.h;
+  uint8_t *const row = (uint8_t *) job.data + (size_t) min (j, job.h - 1) * job.stride;
+  unsigned long long *const edge_out = edge + ((size_t) blockIdx.y * strips + strip) * edge_pitch;
+  const unsigned long long *const edge_in = edge_out - edge_pitch;      // (strip > 0)
+  const bool publish = (strip + 1) * 64 < job.h;
+  const unsigned long long tag = (unsigned long long) epoch << 32;
+  // A lane writes the first r16 samples of a block a turn before the rest; of the block at the ring's
+  // start they went behind the ring's end.
+  const int r16 = (B - (lane & (B - 1))) & (B - 1);
+  u32x4 across[G];              // all ones in those first r16 samples, piece by piece
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    uint32_t m[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      if constexpr (E == 4)
+        m[d] = g * E + d < r16 ? 0xffffffffu : 0u;
+      else
+        m[d] = (g * E + 2 * d < r16 ? 0xffffu : 0u) | (g * E + 2 * d + 1 < r16 ? 0xffff0000u : 0u);
+    }
+    across[g] = u32x4 { m[0], m[1], m[2], m[3] };
+  }
+  const T *const last_out = reinterpret_cast < const T * >(&sh.out[63][0]);
+
+  int ns = 0;                   // blocks stored
+  // finished blocks (the last row, lane 63, is through with them) out to the band and to the strip below
+  auto service =[&]() {
+    const int done = lds_peek (&sh.done);
+    bool any = false;
+    while (ns < nblocks && done >= ns + 5) {
+      const int slot = ns & (kSkewOut - 1);
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        u32x4 v = sh.out[lane][slot * G + g];
+        if (slot == 0) {
+          const u32x4 o = sh.out[lane][kSkewOut * G + g];
+          v = (v & ~across[g]) | (o & across[g]);
+        }
+        if (have_row && ns * G + g < npieces)
+          gstore < u32x4 > ((u32x4 *) (row + ((size_t) ns * G + g) * 16), v);
+      }
+      if (publish && lane < B && ns * B + lane < w) {
+        // (row 63 writes its first sample of a block -- r16 = 1 -- across the end when the block is the ring's first)
+        const int at = (slot == 0 && lane < 1 ? kSkewOut : slot) * B + lane;
+        const uint32_t s = (uint32_t) (int32_t) last_out[at];
+        __hip_atomic_store (edge_out + ns * B + lane, tag | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ns++;
+      any = true;
+    }
+    if (any)
+      lds_post (&sh.stored, ns);
+  };
+
+  u32x4 fly[D][G];              // blocks on their way in
+  unsigned long long efly[D];   // and the row above's (lanes 0 .. 15: a sample each)
+  auto fetch =[&](int i, int blk) {     // i: compile-time slot of the pipeline
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      if (have_row && blk * G + g < npieces)
+        fly[i][g] = gload < u32x4 > ((const u32x4 *) (row + ((size_t) blk * G + g) * 16));
+    efly[i] = tag;
+    if (!FIRST_STRIP && lane < B && blk * B + lane < w)
+      efly[i] = __hip_atomic_load (edge_in + blk * B + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      fly[i][g] = u32x4 { 0, 0, 0, 0 };
+    efly[i] = tag;
+    if (i < nblocks)
+      fetch (i, i);
+  }
+  int done = 0;
+#pragma unroll 1
+  for (int b0 = 0; b0 < nblocks; b0 += D) {
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const int blk = b0 + i;
+      if (blk < nblocks) {      // uniform
+        // the place's last block (blk - kSkewIn) is behind lane 63, which is 4 blocks behind lane 0
+        while (blk >= done + kSkewIn - 4) {
+          service ();
+          done = lds_peek (&sh.done);
+          if (blk >= done + kSkewIn - 4)
+            __builtin_amdgcn_s_sleep (1);
+        }
+        if (!FIRST_STRIP) {
+          // the strip above has got this far?  If not: ask again, for every block that is on its way
+          while (__any ((uint32_t) (efly[i] >> 32) != epoch)) {
+            service ();
+            __builtin_amdgcn_s_sleep (2);
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+              const int bk = k >= i ? b0 + k : b0 + D + k;      // the block slot k is fetching
+              if ((uint32_t) (efly[k] >> 32) != epoch && bk < nblocks)
+                efly[k] = __hip_atomic_load (edge_in + bk * B + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          if (lane < B)
+            sh.above[(blk & (kSkewIn - 1)) * B + lane] = (int32_t) (uint32_t) efly[i];
+        }
+        const int slot = blk & (kSkewIn - 1);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          sh.in[lane][slot * G + g] = fly[i][g];
+          if (slot == 0)
+            sh.in[lane][kSkewIn * G + g] = fly[i][g];
+        }
+        lds_post (&sh.ready, blk + 1);
+        if (blk + D < nblocks)
+          fetch (i, blk + D);
+        service ();
+      }
+    }
+  }
+  while (ns < nblocks) {
+    service ();
+    __builtin_amdgcn_s_sleep (1);
+  }
+}
+
+template < typename T >
+__global__ __launch_bounds__ (128)
+void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, int edge_pitch, uint32_t epoch)
+{
+  __shared__ SkewRings < T > sh;
+  const DcJob job = jobs[blockIdx.y];
+  if ((int) blockIdx.x * 64 >= job.h)
+    return;
+  if (threadIdx.x == 0)
+    sh.ready = sh.done = sh.stored = 0;
+  __syncthreads ();
+  if (threadIdx.x < 64) {
+    if (blockIdx.x == 0)
+      dc_skew_compute < T, true > (sh, job);
+    else
+      dc_skew_compute < T, false > (sh, job);
+  } else {
+    if (blockIdx.x == 0)
+      dc_skew_move < T, true > (sh, job, edge, edge_pitch, epoch);
+    else
+      dc_skew_move < T, false > (sh, job, edge, edge_pitch, epoch);
+  }
+}
+
+// dc_skew_kernel's conditions: rows of whole 16-byte pieces, 16-byte aligned
+bool
+dc_skew_ok (const DcJob * jobs, int njobs, int bpp)
+{
+  const char *env = getenv ("SCHRO_HIP_DC_SKEW");
+  if (env && atoi (env) == 0)
+    return false;
+  for (int p = 0; p < njobs; p++)
+    if ((((uintptr_t) jobs[p].data | (uintptr_t) jobs[p].stride) & 15) || (jobs[p].w * bpp) % 16)
+      return false;
+  return true;
+}
+
+int
+launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp,
+    unsigned long long *edge, int edge_pitch, uint32_t epoch)
+{
+  if (edge) {
+    // a workgroup (compute wave + mover wave) per strip of 64 rows; x = strips: a band's strips are dispatched in order
+    const dim3 grid ((unsigned) ((max_rows + 63) / 64), (unsigned) njobs);
+    if (bpp == 4)
+      SCHRO_LAUNCH ((dc_skew_kernel < int32_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch);
+    else
+      SCHRO_LAUNCH ((dc_skew_kernel < int16_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch);
+  } else {
+    // whole waves; a band taller than kDcRows is walked in slabs
+    const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);
+    if (bpp == 4)
+      SCHRO_LAUNCH ((dc_predict_kernel < int32_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+    else
+      SCHRO_LAUNCH ((dc_predict_kernel < int16_t >), dim3 (njobs), dim3 (threads), 0, stream, d_jobs);
+  }
   const hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "dc_predict kernel launch: %s", hipGetErrorString (e));

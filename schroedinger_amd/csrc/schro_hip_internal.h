@@ -349,7 +349,14 @@ int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
 void upsample_tile_geometry (int *tw, int *th);
 int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith,
     bool aligned16);
-int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp);
+bool dc_skew_ok (const DcJob * jobs, int njobs, int bpp);
+// edge != NULL: dc_skew_kernel with that hand-over buffer (edge_pitch samples per strip, njobs x strips of
+// them, tagged with `epoch`); NULL: dc_predict_kernel
+int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp,
+    unsigned long long *edge, int edge_pitch, uint32_t epoch);
+// the hand-over buffer of the selected queue for a launch of njobs bands of at most max_rows x max_w
+int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned long long **edge,
+    int *edge_pitch, uint32_t * epoch);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 void dequant_tile_geometry (int *tw, int *th);
 // schro_table_quant[i] and schro_table_offset_1_2[i] (intra) / _3_8[i] (inter)
@@ -444,6 +451,11 @@ struct SchroHipContext {
   void *scratch_q[kQueues];
   size_t scratch_size_q[kQueues];
   void *&scratch_ref () { return scratch_q[cur]; }
+  // dc_skew_kernel's hand-over buffers (one per queue: two launches in flight never share one) and
+  // the launch counter their samples are tagged with
+  void *dc_edge_q[kQueues];
+  size_t dc_edge_size_q[kQueues];
+  uint32_t dc_epoch;
   int cus;                      // compute units of the device (launch shaping)
 };
 

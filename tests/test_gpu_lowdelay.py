@@ -163,6 +163,31 @@ def test_dc_predict_alone(ctx, dtype):
         p.free()
 
 
+@pytest.mark.parametrize("kernel", ["skew", "barrier"])
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_dc_predict_strips(ctx, dtype, kernel, monkeypatch):
+    # bands of whole 16-byte pieces: dc_skew_kernel (strips of 64 rows on separate CUs, the last row
+    # handed from strip to strip) -- one strip, many, a last strip of one row, rows shorter than a block,
+    # rows longer than the rings, a last block that is not whole; full-range values (every sum wraps);
+    # twice, so that the second launch meets the first one's hand-over buffer.  "barrier": the same
+    # through dc_predict_kernel
+    if kernel == "barrier":
+        monkeypatch.setenv("SCHRO_HIP_DC_SKEW", "0")
+    E = 16 // np.dtype(dtype).itemsize
+    shapes = [(1, E), (3, 2 * E), (64, 64), (65, 136), (129, 5 * E), (540, 960), (1100, 40), (200, 2048), (70, 16 * 40 + E)]
+    for rnd in range(2):
+        planes, want = [], []
+        for n, (h, w) in enumerate(shapes):
+            a = synth.full_range(h, w, dtype, seed=50 + n + 100 * rnd) if n % 2 else synth.image_s(h, w, dtype, seed=20 + n) * 5
+            planes.append(ctx.upload(a))
+            want.append(O.dc_predict(a))
+        ctx.dc_predict_batch(planes)
+        for p, wnt, shp in zip(planes, want, shapes):
+            got = p.download()
+            assert np.array_equal(got, wnt), (shp, rnd)
+            p.free()
+
+
 def test_intra_picture_through_the_frame_layer(ctx):
     # a low-delay picture the way a patched schrodecoder.c would run it: compressed slices ->
     # transform frame on the device (schro_decoder_decode_lowdelay_transform_data), inverse
