@@ -427,9 +427,9 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
 def lowdelay_8k(ctx, npic=4, steps=8):
     """BASELINE config 5: VC-2 low-delay 10-bit 4:2:2 7680x4320 -- s32 coefficients, slices of 32x8
     luma samples in 155 bytes, 3-level Haar (no shift).  Per picture: slice decode + dequantisation,
-    DC prediction of the LL bands, inverse wavelet; batches of `npic` pictures alternate between the
-    two kernel queues (the DC prediction is a dependency chain on a few CUs: it runs beside the other
-    batch's slices / wavelet).  Slices come from tests/synth.py's writer (not from oracle/); a sample
+    DC prediction of the LL bands, inverse wavelet; batches of `npic` pictures take turns on three
+    queues (SCHRO_BENCH_LD_QUEUES; the DC prediction is a dependency chain on a few CUs: it runs beside
+    the other batches' slices / wavelet -- one queue 0.220, two 0.197, three 0.187 ms per picture).  Slices come from tests/synth.py's writer (not from oracle/); a sample
     of slices is checked against that writer's values here, the whole path against the oracle in
     tests/test_gpu_lowdelay.py."""
     import schroedinger_amd as sa
@@ -445,7 +445,8 @@ def lowdelay_8k(ctx, npic=4, steps=8):
             pics.append((ctx.upload_bytes(data), [ctx.plane(h, w, np.int32) for (h, w) in dims],
                          [ctx.plane(h, w, np.int32) for (h, w) in dims]))
         return pics, [(sl, co) for sl, co, _ in pics], [(c, p) for _, co, px in pics for c, p in zip(co, px)]
-    sets = [batch() for _ in range(2)]
+    nq = int(os.environ.get("SCHRO_BENCH_LD_QUEUES", "3"))
+    sets = [batch() for _ in range(nq)]
     pics, jobs, pairs = sets[0]
     ctx.select_queue(0)
     ctx.lowdelay_batch(jobs, P)
@@ -474,8 +475,8 @@ def lowdelay_8k(ctx, npic=4, steps=8):
     ctx.profile_enable(False)
 
     def step(k):
-        _, jobs_q, pairs_q = sets[k % 2]
-        ctx.select_queue(k % 2)
+        _, jobs_q, pairs_q = sets[k % nq]
+        ctx.select_queue(k % nq)
         ctx.lowdelay_batch(jobs_q, P)
         ctx.iiwt_batch(pairs_q, depth, filt)
     for k in range(4):
@@ -497,7 +498,8 @@ def lowdelay_8k(ctx, npic=4, steps=8):
     # algorithmic bytes per picture: compressed slices in, 4 B per coefficient out; wavelet: 8 B per s32 sample
     # (4 read + 4 written) -- the one-pass Haar kernel moves exactly that
     return {"workload": "7680x4320 4:2:2 s32 low-delay, 32x8 slices of 155 bytes, 3-level Haar, %d pictures per launch, "
-                        "two batches alternating between the kernel queues" % npic,
+                        "%d batches taking turns on as many queues" % (npic, nq),
+            "slices_frac_of_8TBs": round((4 * samples + data.size) / (per.get("slices", 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "ms_per_picture": round(wall / npic, 4), "Mpix_per_s": round(Wl * Hl * npic / wall / 1e3, 1),
             "kernels_ms_per_picture": {"slices": round(per.get("slices", 0), 4), "dc_predict": round(per.get("dc_predict", 0), 4),
                                        "iiwt_3_levels": round(iiwt, 4)},

@@ -107,7 +107,8 @@ dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned
   void *&buf = ctx->dc_edge_q[ctx->cur];
   size_t & size = ctx->dc_edge_size_q[ctx->cur];
   const int strips = (max_rows + 63) / 64;
-  const size_t bytes = (size_t) njobs * strips * max_w * sizeof (unsigned long long);
+  // (8 words in front: the launch's ticket and finish counters)
+  const size_t bytes = ((size_t) njobs * strips * max_w + 8) * sizeof (unsigned long long);
   if (bytes > size) {
     if (buf) {
       SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));

@@ -1058,12 +1058,12 @@ dc_skew_step (int32_t q, int32_t from_above, int32_t & left, int32_t & upleft, i
 
 template < typename T, bool FIRST_STRIP >
 __device__ __forceinline__ void
-dc_skew_compute (SkewRings < T > &sh, const DcJob & job)
+dc_skew_compute (SkewRings < T > &sh, const DcJob & job, int strip)
 {
   constexpr int B = kSkewBlock, SZ = (int) sizeof (T);
   const int lane = (int) threadIdx.x;
   const int w = job.w, nblocks = (w + B - 1) / B;
-  const int j = (int) blockIdx.x * 64 + lane;
+  const int j = strip * 64 + lane;
   const bool first_row = j == 0;
   const int w_lane = j < job.h ? w : 0;
   const uint8_t *const my_in = reinterpret_cast < const uint8_t * >(&sh.in[lane][0]);
@@ -1128,16 +1128,15 @@ dc_skew_compute (SkewRings < T > &sh, const DcJob & job)
 
 template < typename T, bool FIRST_STRIP >
 __device__ __forceinline__ void
-dc_skew_move (SkewRings < T > &sh, const DcJob & job, unsigned long long *edge, int edge_pitch, uint32_t epoch)
+dc_skew_move (SkewRings < T > &sh, const DcJob & job, int strip, unsigned long long *edge_out, int edge_pitch,
+    uint32_t epoch)
 {
   constexpr int B = kSkewBlock, E = 16 / (int) sizeof (T), G = B / E, D = kSkewDepth;
-  const int strip = (int) blockIdx.x, strips = (int) gridDim.x;
   const int lane = (int) threadIdx.x - 64;
   const int w = job.w, npieces = w / E, nblocks = (w + B - 1) / B;
   const int j = strip * 64 + lane;
   const bool have_row = j < job.h;
   uint8_t *const row = (uint8_t *) job.data + (size_t) min (j, job.h - 1) * job.stride;
-  unsigned long long *const edge_out = edge + ((size_t) blockIdx.y * strips + strip) * edge_pitch;
   const unsigned long long *const edge_in = edge_out - edge_pitch;      // (strip > 0)
   const bool publish = (strip + 1) * 64 < job.h;
   const unsigned long long tag = (unsigned long long) epoch << 32;
@@ -1258,27 +1257,45 @@ dc_skew_move (SkewRings < T > &sh, const DcJob & job, unsigned long long *edge, 
   }
 }
 
+// Which strip a workgroup works on is decided when it starts to run (a ticket from a counter in the
+// hand-over buffer), not by its index: a strip then only ever waits for strips that are running
+// already, whatever the dispatcher's order or however many launches share the CUs.  The last
+// workgroup to finish puts the two counters back to 0 for the queue's next launch.
 template < typename T >
 __global__ __launch_bounds__ (128)
-void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, int edge_pitch, uint32_t epoch)
+void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, int edge_pitch, uint32_t epoch, int strips)
 {
   __shared__ SkewRings < T > sh;
-  const DcJob job = jobs[blockIdx.y];
-  if ((int) blockIdx.x * 64 >= job.h)
-    return;
-  if (threadIdx.x == 0)
+  __shared__ int s_ticket;
+  unsigned int *const ctrl = reinterpret_cast < unsigned int *>(edge);  // [0] tickets, [1] workgroups finished
+  edge += 8;
+  if (threadIdx.x == 0) {
+    s_ticket = (int) __hip_atomic_fetch_add (&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh.ready = sh.done = sh.stored = 0;
+  }
   __syncthreads ();
-  if (threadIdx.x < 64) {
-    if (blockIdx.x == 0)
-      dc_skew_compute < T, true > (sh, job);
-    else
-      dc_skew_compute < T, false > (sh, job);
-  } else {
-    if (blockIdx.x == 0)
-      dc_skew_move < T, true > (sh, job, edge, edge_pitch, epoch);
-    else
-      dc_skew_move < T, false > (sh, job, edge, edge_pitch, epoch);
+  const int ticket = s_ticket, nj = ticket / strips, strip = ticket - nj * strips;
+  const DcJob job = jobs[nj];
+  if (strip * 64 < job.h) {
+    if (threadIdx.x < 64) {
+      if (strip == 0)
+        dc_skew_compute < T, true > (sh, job, strip);
+      else
+        dc_skew_compute < T, false > (sh, job, strip);
+    } else {
+      if (strip == 0)
+        dc_skew_move < T, true > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch);
+      else
+        dc_skew_move < T, false > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch);
+    }
+  }
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    const unsigned int total = gridDim.x;
+    if (__hip_atomic_fetch_add (&ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+      __hip_atomic_store (&ctrl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store (&ctrl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1300,12 +1317,13 @@ launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_
     unsigned long long *edge, int edge_pitch, uint32_t epoch)
 {
   if (edge) {
-    // a workgroup (compute wave + mover wave) per strip of 64 rows; x = strips: a band's strips are dispatched in order
-    const dim3 grid ((unsigned) ((max_rows + 63) / 64), (unsigned) njobs);
+    // a workgroup (compute wave + mover wave) per strip of 64 rows of every band
+    const int strips = (max_rows + 63) / 64;
+    const dim3 grid ((unsigned) (strips * njobs));
     if (bpp == 4)
-      SCHRO_LAUNCH ((dc_skew_kernel < int32_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch);
+      SCHRO_LAUNCH ((dc_skew_kernel < int32_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips);
     else
-      SCHRO_LAUNCH ((dc_skew_kernel < int16_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch);
+      SCHRO_LAUNCH ((dc_skew_kernel < int16_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips);
   } else {
     // whole waves; a band taller than kDcRows is walked in slabs
     const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);

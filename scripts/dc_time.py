@@ -8,8 +8,11 @@ sys.path.insert(0, ROOT)
 import schroedinger_amd as sa
 
 ctx = sa.Context(0)
-for (w, h, n, dt) in [(960, 64, 1, np.int32), (960, 64, 12, np.int32), (1920, 64, 1, np.int32), (960, 128, 1, np.int32),
-                      (960, 540, 1, np.int32), (960, 540, 12, np.int32), (480, 540, 12, np.int32), (960, 540, 12, np.int16)]:
+SHAPES = [(960, 64, 1, np.int32), (960, 64, 12, np.int32), (1920, 64, 1, np.int32), (960, 128, 1, np.int32),
+          (960, 540, 1, np.int32), (960, 540, 12, np.int32), (480, 540, 12, np.int32), (960, 540, 12, np.int16)]
+if len(sys.argv) > 1:           # w h n
+    SHAPES = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), np.int32)]
+for (w, h, n, dt) in SHAPES:
     # planes as the LL band of a depth-3 frame: rows 8 frame rows apart
     planes = []
     for _ in range(n):
@@ -34,3 +37,4 @@ for (w, h, n, dt) in [(960, 64, 1, np.int32), (960, 64, 12, np.int32), (1920, 64
     print("%4d x %3d x %2d %-5s  %.4f ms per launch   %.1f ns per (w + h) step" % (w, h, n, np.dtype(dt).name, ms, ms * 1e6 / steps))
     for full, _ in planes:
         full.free()
+    sys.stdout.flush()
