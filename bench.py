@@ -144,7 +144,9 @@ class Workload:
             # no cross-queue dependency at all in the steady state
             c.select_queue(s)
             if alone or self.prev_alone:
-                c.queue_wait(s, 1 - s)
+                for other in range(self.queues):
+                    if other != s:
+                        c.queue_wait(s, other)
             self.prev_alone = alone
             c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
             obmc_side(b)
@@ -587,7 +589,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
-    ap.add_argument("--queues", type=int, default=2, choices=(1, 2),
+    ap.add_argument("--queues", type=int, default=2, choices=(1, 2, 3),
                     help="picture batches in flight per GPU (2: OBMC of one beside the wavelet of the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",

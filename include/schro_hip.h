@@ -110,6 +110,10 @@ int schro_hip_upload_2d_async (SchroHipContext * ctx, void *dst, int dst_stride,
 int schro_hip_download_2d_async (SchroHipContext * ctx, void *dst, int dst_stride,
     const void *src, int src_stride, int row_bytes, int height);
 int schro_hip_queue_synchronize (SchroHipContext * ctx, int queue);
+/* Restricts a queue's kernels to the compute units whose bits are set in mask[0 .. words) (the queue's
+ * pending work is waited for first; hipExtStreamCreateWithCUMask): two queues with disjoint masks run
+ * side by side without sharing a CU's registers and LDS. */
+int schro_hip_queue_set_cu_mask (SchroHipContext * ctx, int queue, const uint32_t * mask, int words);
 /* waits for everything enqueued on both queues */
 int schro_hip_synchronize (SchroHipContext * ctx);
 /* the selected queue's hipStream_t, for hosts that enqueue their own work or events */

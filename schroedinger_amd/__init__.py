@@ -192,6 +192,16 @@ class Context:
     def queue_synchronize(self, q):
         check(self.lib.schro_hip_queue_synchronize(self.h, q))
 
+    def queue_set_cu_mask(self, q, bits):
+        """bits: iterable of 0 / 1 per compute unit (hipExtStreamCreateWithCUMask's bit order)."""
+        bits = list(bits)
+        words = (len(bits) + 31) // 32
+        arr = (C.c_uint32 * words)()
+        for n, b in enumerate(bits):
+            if b:
+                arr[n // 32] |= 1 << (n % 32)
+        check(self.lib.schro_hip_queue_set_cu_mask(self.h, q, arr, words))
+
     def host_array(self, shape, dtype):
         """A numpy array in pinned host memory (schro_hip_host_alloc): what the asynchronous copies
         read and write at full rate.  Freed with the array."""

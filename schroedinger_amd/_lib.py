@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_context_new", "schro_hip_context_free", "schro_hip_device_count",
     "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind",
     "schro_hip_host_alloc", "schro_hip_host_free", "schro_hip_upload_2d_async", "schro_hip_download_2d_async",
-    "schro_hip_queue_synchronize", "schro_memory_domain_new_hip_host", "schro_hip_codeblock_layout",
+    "schro_hip_queue_synchronize", "schro_hip_queue_set_cu_mask", "schro_memory_domain_new_hip_host", "schro_hip_codeblock_layout",
     "schro_frame_to_hip_async", "schro_hipframe_to_cpu_async", "schro_hip_frame_copy_to",
     "schro_upsampled_hipframe_upsample_inplace",
     "schro_hip_scheduler_new_on", "schro_hip_scheduler_publish_reference", "schro_hip_scheduler_reference_frame",
@@ -245,6 +245,8 @@ def load():
     L.schro_hip_download_2d_async.restype = i
     L.schro_hip_queue_synchronize.argtypes = [vp, i]
     L.schro_hip_queue_synchronize.restype = i
+    L.schro_hip_queue_set_cu_mask.argtypes = [vp, i, C.POINTER(C.c_uint32), i]
+    L.schro_hip_queue_set_cu_mask.restype = i
     L.schro_memory_domain_new_hip_host.argtypes = []
     L.schro_memory_domain_new_hip_host.restype = vp
     L.schro_hip_codeblock_layout.argtypes = [i, i, i, C.POINTER(C.c_int), C.POINTER(C.c_int), i, i, C.POINTER(Codeblock), i]

@@ -609,6 +609,22 @@ schro_hip_queue_synchronize (SchroHipContext * ctx, int queue)
 }
 
 int
+schro_hip_queue_set_cu_mask (SchroHipContext * ctx, int queue, const uint32_t * mask, int words)
+{
+  SCHRO_HIP_REQUIRE (ctx && queue >= 0 && queue < SchroHipContext::kQueues && mask && words > 0,
+      "queue_set_cu_mask: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[queue]));
+  hipStream_t fresh;
+  SCHRO_HIP_CHECK (hipExtStreamCreateWithCUMask (&fresh, (uint32_t) words, mask));
+  (void) hipStreamDestroy (ctx->streams[queue]);
+  ctx->streams[queue] = fresh;
+  if (ctx->cur == queue)
+    ctx->stream = fresh;
+  return 0;
+}
+
+int
 schro_hip_memset (SchroHipContext * ctx, void *dst, int value, size_t bytes)
 {
   SCHRO_HIP_REQUIRE (ctx && dst, "memset: bad arguments");

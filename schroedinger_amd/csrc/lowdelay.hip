@@ -2,7 +2,11 @@
 //
 //   slice_kernel        one thread per slice: exp-Golomb unpack + dequantise into the
 //                       interleaved coefficient frame (schrolowdelay.c:109-310)
+//   slice_run_kernel    r03: the same for slices that divide the sub-bands evenly, a step per
+//                       non-zero value (zero runs counted from the bit window)
 //   dc_predict_kernel   DC prediction of an LL band (schrodecoder.c:3219-3277)
+//   dc_skew_kernel      r03: the same for bands of whole 16-byte pieces, strips of 64 rows on
+//                       separate CUs, a lane one sample behind its neighbour
 //
 // Slices are fixed-size and independent (their offsets follow from the slice number,
 // schrolowdelay.c:607-631), the codes inside one are strictly serial: a lane walks its
