@@ -591,6 +591,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="pictures per step per GPU")
     ap.add_argument("--queues", type=int, default=2, choices=(1, 2, 3),
                     help="picture batches in flight per GPU (2: OBMC of one beside the wavelet of the next)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps for this long before the warm-up steps (GPU clocks / caches in their steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed workload: no CPU baseline, no 1080p / PCIe-inclusive extras "
@@ -641,6 +643,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # The card idles at low clocks while the host builds the inputs: a stretch of the same steps brings
+    # it to the state a decoder that runs continuously is in, before the W warm-up steps (untimed, like
+    # them; --prewarm-ms 0 leaves it out)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(8):
+            wl.step()
+        ctx.synchronize()
     for _ in range(args.warmup):
         wl.step()
     ctx.profile_enable(True)
@@ -720,7 +730,7 @@ def main():
         out = {
             "metric": "Mpix/s IIWT+OBMC decode, 2160p s16",
             "value": round(value, 1), "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "s16", "data": "synthetic",
