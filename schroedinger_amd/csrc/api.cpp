@@ -83,6 +83,42 @@ push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
 }
 
 int
+push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
+{
+  const int q = ctx->cur;
+  ctx->big_turn[q] = (ctx->big_turn[q] + 1) % SchroHipContext::kBigTables;
+  SchroHipContext::BigTable & b = ctx->big_q[q][ctx->big_turn[q]];
+  if (b.pending) {              // the mirror may still be the source of its last copy
+    SCHRO_HIP_CHECK (hipEventSynchronize (b.copied));
+    b.pending = false;
+  }
+  if (bytes > b.cap) {
+    if (b.cap) {
+      SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));     // launches that still read the old table
+      (void) hipHostFree (b.h);
+      (void) hipFree (b.d);
+      b.cap = 0;
+    }
+    const size_t cap = (std::max (bytes + bytes / 2, (size_t) 256 << 10) + 15) & ~(size_t) 15;
+    SCHRO_HIP_CHECK (hipHostMalloc ((void **) &b.h, cap, hipHostMallocDefault));
+    SCHRO_HIP_CHECK (hipMalloc ((void **) &b.d, cap));
+    if (!b.copied)
+      SCHRO_HIP_CHECK (hipEventCreateWithFlags (&b.copied, hipEventDisableTiming));
+    b.cap = cap;
+  }
+  memcpy (b.h, host, bytes);
+  {
+    const int r = launch_table_copy (ctx->stream, b.d, b.h, bytes);
+    if (r)
+      return r;
+  }
+  SCHRO_HIP_CHECK (hipEventRecord (b.copied, ctx->stream));
+  b.pending = true;
+  *dev = b.d;
+  return 0;
+}
+
+int
 ensure_scratch (SchroHipContext * ctx, size_t bytes)
 {
   void *&scratch = ctx->scratch_q[ctx->cur];
@@ -378,6 +414,8 @@ schro_hip_context_new (int device)
     ctx->scratch_q[q] = nullptr;
     ctx->dc_edge_q[q] = nullptr;
     ctx->dc_edge_size_q[q] = 0;
+    memset (ctx->big_q[q], 0, sizeof (ctx->big_q[q]));
+    ctx->big_turn[q] = 0;
     ctx->scratch_size_q[q] = 0;
     ctx->dc_epoch = 0;
     ctx->streams[q] = nullptr;
@@ -461,6 +499,14 @@ schro_hip_context_free (SchroHipContext * ctx)
       (void) hipFree (ctx->scratch_q[q]);
     if (ctx->dc_edge_q[q])
       (void) hipFree (ctx->dc_edge_q[q]);
+    for (auto & b : ctx->big_q[q]) {
+      if (b.cap) {
+        (void) hipHostFree (b.h);
+        (void) hipFree (b.d);
+      }
+      if (b.copied)
+        (void) hipEventDestroy (b.copied);
+    }
   }
   for (int k = 0; k < SchroHipContext::kOrderSlots; k++) {
     if (ctx->order_slots[k].d)
@@ -1296,16 +1342,34 @@ schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * pla
   (void) hipSetDevice (ctx->device);
   int tw, th;
   dequant_tile_geometry (&tw, &th);
-  // job tables travel through the table slots: as many codeblocks per launch as fit one
-  constexpr size_t kPerLaunch = std::min < size_t > (4096, SchroHipContext::kArgSlotBytes / sizeof (DequantJob));
+  // one launch per 2^18 codeblocks (find_dequant_job's three probes): the table of a whole batch of
+  // pictures goes up as one copy (r03; through the 64 KB table slots it was a launch per 1365
+  // codeblocks -- eleven launches of 20 us for 8 x 2160p)
+  // (SCHRO_HIP_DEQUANT_PER_LAUNCH=1300: tables that fit the slots again, for A/B runs)
+  const char *env = getenv ("SCHRO_HIP_DEQUANT_PER_LAUNCH");
+  const size_t kPerLaunch = env && atoi (env) > 0 ? std::min ((size_t) atoi (env), (size_t) 1 << 18) : (size_t) 1 << 18;
   std::vector < DequantJob > jobs;
-  jobs.reserve (kPerLaunch);
+  std::vector < char > table;
   int tile_base = 0;
   auto flush = [&] () -> int {
     if (jobs.empty ())
       return 0;
+    // behind the jobs: their first tiles, every 64th and every 4096th of them, each as a dense array
+    // (find_dequant_job's probes read 64 neighbouring words instead of 64 job records)
+    const size_t n = jobs.size (), n64 = (n + 63) / 64, n4096 = (n + 4095) / 4096;
+    const size_t bytes = sizeof (DequantJob) * n + sizeof (int) * (n + n64 + n4096);
+    table.resize (bytes);
+    memcpy (table.data (), jobs.data (), sizeof (DequantJob) * n);
+    int *index = (int *) (table.data () + sizeof (DequantJob) * n);
+    for (size_t k = 0; k < n; k++)
+      index[k] = jobs[k].tile_base;
+    for (size_t k = 0; k < n64; k++)
+      index[n + k] = jobs[64 * k].tile_base;
+    for (size_t k = 0; k < n4096; k++)
+      index[n + n64 + k] = jobs[4096 * k].tile_base;
     void *d_jobs;
-    int r = push_args (ctx, jobs.data (), sizeof (DequantJob) * jobs.size (), &d_jobs);
+    int r = bytes <= SchroHipContext::kArgSlotBytes ? push_args (ctx, table.data (), bytes, &d_jobs)
+        : push_big_table (ctx, table.data (), bytes, &d_jobs);
     if (r)
       return r;
     {

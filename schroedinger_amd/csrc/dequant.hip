@@ -13,7 +13,9 @@
 // values -- stays on the host; the host hands over quantised values, 1 / 2 / 4 bytes each,
 // only for the codeblocks that are not zero: most of a coefficient frame never crosses PCIe.
 //
-// One 256-thread workgroup = a 64 x 16 sample tile of one codeblock, 4 samples per lane;
+// One 256-thread workgroup = a 64 x 64 sample tile of one codeblock, 4 samples x 4 rows per lane
+// (r03; a 64 x 16 tile per workgroup made 390 k waves per 8 x 2160p, each a chain of the two job
+// probes, the job, the values and the store -- latency-bound at 0.235 ms);
 // coefficient rows of a sub-band are contiguous runs inside the interleaved frame rows, so
 // stores are coalesced.  Bound: HBM write (bpp bytes per sample) + the values read.
 
@@ -22,7 +24,7 @@
 namespace schro {
 namespace {
 
-constexpr int kDqThreads = 256, kDqTW = 64, kDqTH = 16;
+constexpr int kDqThreads = 256, kDqTW = 64, kDqRows = 4, kDqTH = 16 * kDqRows;
 
 struct QuantTables3 {
   uint32_t factor[61], off12[61], off38[61];
@@ -66,20 +68,57 @@ dequant_one (int32_t q, uint32_t factor, uint32_t offset)
   }
 }
 
-// which job owns tile `bid`: two probes of 64 lanes (every 64th job, then the 64 of that run)
+// which job owns tile `bid`: three probes of 64 lanes in the dense arrays of first tiles behind the
+// jobs (every 4096th job, every 64th of that run, the 64 of that run)
 __device__ __forceinline__ int
 find_dequant_job (const DequantJob * jobs, int njobs, int bid)
 {
   const int lane = threadIdx.x & 63;
+  const int *first = reinterpret_cast < const int *>(jobs + njobs);
+  const int n64 = (njobs + 63) / 64;
   int lo = 0;
+  if (njobs > 4096) {
+    const int idx = lane;
+    const bool le = idx * 4096 < njobs && gload < int > (first + njobs + n64 + idx) <= bid;
+    lo = (__popcll (__ballot (le)) - 1) * 4096;
+  }
   if (njobs > 64) {
-    const int idx = lane * 64;
-    const bool le = idx < njobs && gload < int > (&jobs[idx].tile_base) <= bid;
-    lo = (__popcll (__ballot (le)) - 1) * 64;
+    const int idx = (lo >> 6) + lane;
+    const bool le = idx < n64 && gload < int > (first + njobs + idx) <= bid;
+    lo += (__popcll (__ballot (le)) - 1) * 64;
   }
   const int idx = lo + lane;
-  const bool le = idx < njobs && gload < int > (&jobs[idx].tile_base) <= bid;
+  const bool le = idx < njobs && gload < int > (first + idx) <= bid;
   return __builtin_amdgcn_readfirstlane (lo + __popcll (__ballot (le)) - 1);
+}
+
+// 4 quantised values of `bytes` bytes each from s (any alignment: one load of 4 * bytes bytes)
+template < typename Q >
+__device__ __forceinline__ void
+load_quads (const void *src, size_t s, int n, int32_t * q)
+{
+  const Q *p = (const Q *) src + s;
+  if (n == 4) {
+    if constexpr (sizeof (Q) == 1) {
+      // (as a dword at any byte address: the compiler splits a byte-aligned char vector into three loads)
+      typedef uint32_t u32_a1 __attribute__ ((aligned (1)));
+      const uint32_t v = *(const SCHRO_GLOBAL u32_a1 *) p;
+      q[0] = (int32_t) (int8_t) v;
+      q[1] = (int32_t) (int8_t) (v >> 8);
+      q[2] = (int32_t) (int8_t) (v >> 16);
+      q[3] = (int32_t) v >> 24;
+    } else {
+      typedef Q Q4 __attribute__ ((ext_vector_type (4), aligned (sizeof (Q))));
+      const Q4 v = *(const SCHRO_GLOBAL Q4 *) p;
+      q[0] = (int32_t) v.x;
+      q[1] = (int32_t) v.y;
+      q[2] = (int32_t) v.z;
+      q[3] = (int32_t) v.w;
+    }
+  } else {
+    for (int e = 0; e < 4; e++)
+      q[e] = e < n ? (int32_t) gload < Q > (p + e) : 0;
+  }
 }
 
 template < typename T, int ARITH >
@@ -90,38 +129,54 @@ void dequant_kernel (const DequantJob * __restrict__ jobs, int njobs)
   const DequantJob job = jobs[find_dequant_job (jobs, njobs, bid)];
   const int t = bid - job.tile_base;
   const int ty = t / job.tiles_x, tx = t - ty * job.tiles_x;
-  const int x = tx * kDqTW + 4 * (threadIdx.x & 15), y = ty * kDqTH + (threadIdx.x >> 4);
-  if (x >= job.w || y >= job.h)
+  const int x = tx * kDqTW + 4 * (threadIdx.x & 15), y0 = ty * kDqTH + (threadIdx.x >> 4);
+  if (x >= job.w)
     return;
   const int n = min (4, job.w - x);
-  T v[4] = { 0, 0, 0, 0 };
-  if (job.src) {
-    const size_t s = (size_t) y * job.w + x;
-    for (int e = 0; e < n; e++) {
-      const int32_t q = job.src_bytes == 1 ? (int32_t) gload < int8_t > ((const int8_t *) job.src + s + e)
-          : job.src_bytes == 2 ? (int32_t) gload < int16_t > ((const int16_t *) job.src + s + e)
-          : gload < int32_t > ((const int32_t *) job.src + s + e);
-      v[e] = dequant_one < T, ARITH > (q, job.factor, job.offset);
+  // a lane's rows lie 16 apart; the values of all of them are asked for before the first is used
+  int32_t q[kDqRows][4];
+#pragma unroll
+  for (int r = 0; r < kDqRows; r++) {
+    const int y = y0 + 16 * r;
+    q[r][0] = q[r][1] = q[r][2] = q[r][3] = 0;
+    if (job.src && y < job.h) {
+      const size_t s = (size_t) y * job.w + x;
+      if (job.src_bytes == 1)
+        load_quads < int8_t > (job.src, s, n, q[r]);
+      else if (job.src_bytes == 2)
+        load_quads < int16_t > (job.src, s, n, q[r]);
+      else
+        load_quads < int32_t > (job.src, s, n, q[r]);
     }
   }
-  T *d = (T *) ((char *) job.dst + (size_t) y * job.dst_stride) + x;
-  if (n == 4 && (((uintptr_t) d) & (4 * sizeof (T) - 1)) == 0) {
-    if constexpr (sizeof (T) == 2) {
-      u32x2 o;
-      o.x = (uint32_t) (uint16_t) v[0] | ((uint32_t) (uint16_t) v[1] << 16);
-      o.y = (uint32_t) (uint16_t) v[2] | ((uint32_t) (uint16_t) v[3] << 16);
-      gstore < u32x2 > (d, o);
+#pragma unroll
+  for (int r = 0; r < kDqRows; r++) {
+    const int y = y0 + 16 * r;
+    if (y >= job.h)
+      break;
+    T v[4] = { 0, 0, 0, 0 };
+    if (job.src)
+      for (int e = 0; e < 4; e++)
+        v[e] = dequant_one < T, ARITH > (q[r][e], job.factor, job.offset);
+    T *d = (T *) ((char *) job.dst + (size_t) y * job.dst_stride) + x;
+    if (n == 4 && (((uintptr_t) d) & (4 * sizeof (T) - 1)) == 0) {
+      if constexpr (sizeof (T) == 2) {
+        u32x2 o;
+        o.x = (uint32_t) (uint16_t) v[0] | ((uint32_t) (uint16_t) v[1] << 16);
+        o.y = (uint32_t) (uint16_t) v[2] | ((uint32_t) (uint16_t) v[3] << 16);
+        gstore < u32x2 > (d, o);
+      } else {
+        u32x4 o;
+        o.x = (uint32_t) v[0];
+        o.y = (uint32_t) v[1];
+        o.z = (uint32_t) v[2];
+        o.w = (uint32_t) v[3];
+        gstore < u32x4 > (d, o);
+      }
     } else {
-      u32x4 o;
-      o.x = (uint32_t) v[0];
-      o.y = (uint32_t) v[1];
-      o.z = (uint32_t) v[2];
-      o.w = (uint32_t) v[3];
-      gstore < u32x4 > (d, o);
+      for (int e = 0; e < n; e++)
+        gstore < T > (d + e, v[e]);
     }
-  } else {
-    for (int e = 0; e < n; e++)
-      gstore < T > (d + e, v[e]);
   }
 }
 
@@ -140,6 +195,29 @@ dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t * off
   const int q = quant_index < 0 ? 0 : (quant_index > 60 ? 60 : quant_index);
   *factor = kHostQuant.factor[q];
   *offset = is_intra ? kHostQuant.off12[q] : kHostQuant.off38[q];
+}
+
+// A job table from its pinned host mirror to the device by a kernel (16 bytes per lane): a copy
+// through the DMA engines queues up behind the coefficient / value uploads of the copy queue --
+// 0.8 MB of table waited a millisecond for 54 MB of values.
+__global__ __launch_bounds__ (256)
+void table_copy_kernel (u32x4 * __restrict__ dst, const u32x4 * __restrict__ src, size_t n16)
+{
+  const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < n16)
+    dst[i] = src[i];
+}
+
+int
+launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes)
+{
+  const size_t n16 = (bytes + 15) / 16;         // (the buffers are allocated in multiples of 16 bytes)
+  hipLaunchKernelGGL (table_copy_kernel, dim3 ((unsigned) ((n16 + 255) / 256)), dim3 (256), 0, stream, (u32x4 *) dst,
+      (const u32x4 *) src, n16);
+  const hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "table copy launch: %s", hipGetErrorString (e));
+  return 0;
 }
 
 int

@@ -359,6 +359,7 @@ int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsi
     int *edge_pitch, uint32_t * epoch);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 void dequant_tile_geometry (int *tw, int *th);
+int launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes);
 // schro_table_quant[i] and schro_table_offset_1_2[i] (intra) / _3_8[i] (inter)
 void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t * offset);
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
@@ -451,6 +452,19 @@ struct SchroHipContext {
   void *scratch_q[kQueues];
   size_t scratch_size_q[kQueues];
   void *&scratch_ref () { return scratch_q[cur]; }
+  // Job tables too large for a table slot (the codeblocks of a whole batch of pictures): four
+  // grow-only pinned mirrors + device buffers per queue, used in turn (the host runs up to three
+  // batches ahead of the device), never cached (a decoder's codeblock tables differ from picture to
+  // picture)
+  struct BigTable {
+    char *h, *d;
+    size_t cap;
+    hipEvent_t copied;
+    bool pending;
+  };
+  static constexpr int kBigTables = 4;
+  BigTable big_q[kQueues][kBigTables];
+  int big_turn[kQueues];
   // dc_skew_kernel's hand-over buffers (one per queue: two launches in flight never share one) and
   // the launch counter their samples are tagged with
   void *dc_edge_q[kQueues];
@@ -465,6 +479,9 @@ namespace schro {
 int push_args (SchroHipContext * ctx, const void *host, size_t bytes,
     void **dev);
 int ensure_scratch (SchroHipContext * ctx, size_t bytes);
+// a device copy of a job table of any size, valid for the launches enqueued on the context's stream
+// before the fourth call from now on this queue
+int push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **dev);
 // the launches made while a scope is open are timed under its kernel class (when profiling is on)
 struct ProfileScope {
   ProfileScope (SchroHipContext * c, int cls);
