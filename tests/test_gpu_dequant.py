@@ -46,15 +46,15 @@ def pack_codeblocks(plane_shape, itemsize, stride, depth, quant, records):
     return np.frombuffer(bytes(blob) or b"\0", np.uint8), cbs
 
 
-def synthetic_records(h, w, depth, rng, zero_share=0.4):
+def synthetic_records(h, w, depth, rng, zero_share=0.4, counts=None):
     """A codeblock partition of every sub-band (schrodecoder.c:3572-3596 geometry) with random
-    zero flags and quantiser indices."""
+    zero flags and quantiser indices; counts: (horizontal, vertical) codeblocks per sub-band, else random."""
     records = []
     probe = np.zeros((h, w), np.int8)
     for index in range(1 + 3 * depth):
         band = D.subband_view(probe, depth, index)
         bh, bw = band.shape
-        ncx, ncy = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        ncx, ncy = counts if counts else (int(rng.integers(1, 6)), int(rng.integers(1, 5)))
         cbw = bw // ncx
         inc = bw - ncx * cbw
         for cy in range(ncy):
@@ -93,6 +93,35 @@ def test_synthetic_codeblocks(ctx, dtype, arith):
     ctx.dequant_batch(jobs, arith)
     for n, (dst, ref) in enumerate(zip(outs, want)):
         assert np.array_equal(dst.download(), ref), n
+
+
+def test_more_codeblocks_than_a_table_slot_holds(ctx):
+    # 5200 codeblocks in one plane + 900 in another: the job table goes up through the large-table
+    # path (beyond 64 KB) and the kernel finds a tile's codeblock with all three probes (> 4096 jobs);
+    # codeblocks down to 1 x 1 sample
+    rng = np.random.default_rng(23)
+    jobs, want, outs = [], [], []
+    for (h, w, depth, counts) in [(512, 512, 4, (20, 20)), (96, 160, 2, (10, 9))]:
+        quant = rng.integers(-300, 301, (h, w)).astype(np.int32)
+        quant[rng.random((h, w)) < 0.5] = 0
+        records = synthetic_records(h, w, depth, rng, counts=counts)
+        dst = ctx.plane(h, w, np.int16).fill(0x5a)
+        blob, cbs = pack_codeblocks((h, w), 2, dst.stride, depth, quant, records)
+        jobs.append((dst, ctx.upload_bytes(blob), cbs, 0))
+        ref = np.full((h, w), 0x5a5a, np.uint16).astype(np.int16)
+        for (index, x0, y0, x1, y1, zero, qi) in records:
+            band, qb = D.subband_view(ref, depth, index), D.subband_view(quant, depth, index)
+            if x1 > x0 and y1 > y0:
+                O.dequant_codeblock(band[y0:y1, x0:x1], None if zero else qb[y0:y1, x0:x1], qi, 0, 0)
+        want.append(ref)
+        outs.append(dst)
+    assert sum(len(c) for _, _, c, _ in jobs) > 4096
+    for rnd in range(3):            # (the large tables take turns: every one of them gets used)
+        for dst in outs:
+            dst.fill(0x5a)
+        ctx.dequant_batch(jobs, 0)
+        for n, (dst, ref) in enumerate(zip(outs, want)):
+            assert np.array_equal(dst.download(), ref), (n, rnd)
 
 
 def test_bad_arguments_are_refused(ctx):
