@@ -33,6 +33,7 @@ import synth  # noqa: E402  (synthetic input generators shared with tests/)
 
 W, H, DEPTH, FILTER = 3840, 2160, 3, 0
 XBLEN, XBSEP, PREC = 12, 8, 2
+REF_GROUP = 8                   # pictures that share a pair of references
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -55,8 +56,9 @@ class BatchSet:
     def __init__(self, wl, seed):
         import schroedinger_amd as sa
         ctx, dims = wl.ctx, wl.dims
-        self.hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
-        self.up_pairs = [(wl.ref[r][k], self.hp[r][k]) for r in range(2) for k in range(3)]
+        # a pair of references per group of 8 pictures (wl.groups), upsampled once per batch
+        self.hp = [[[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)] for _ in range(wl.groups)]
+        self.up_pairs = [(wl.ref[g][r][k], self.hp[g][r][k]) for g in range(wl.groups) for r in range(2) for k in range(3)]
         self.iwt_pairs, self.obmc_jobs = [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
@@ -79,7 +81,8 @@ class BatchSet:
                 d_res = ctx.plane(h, w, np.int16)
                 out = self.out_arena.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
-                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[0][k], self.hp[1][k], d_res, out))
+                g = min(f // REF_GROUP, wl.groups - 1)
+                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][1][k], d_res, out))
                 co_f.append(co)
                 out_f.append(out)
             self.coeff_np.append(co_f)
@@ -97,10 +100,14 @@ class Workload:
         self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
         dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
         self.dims = dims
-        # two references (planar u8), shared by the batches as between two anchors of a GOP
-        self.ref_np = [[synth.picture_u8(h, w, seed=seed + 100 + 10 * r + k) for k, (h, w) in
-                        enumerate(dims)] for r in range(2)]
-        self.ref = [[ctx.upload(p) for p in comps] for comps in self.ref_np]
+        # two references (planar u8) per group of REF_GROUP pictures, shared by the batches as between two
+        # anchors of a GOP: the work per picture does not depend on the batch size (2 reference
+        # upsamples per 8 pictures)
+        self.groups = max(1, frames // REF_GROUP)
+        self.ref_np_all = [[[synth.picture_u8(h, w, seed=seed + 100 + 1000 * g + 10 * r + k) for k, (h, w) in
+                             enumerate(dims)] for r in range(2)] for g in range(self.groups)]
+        self.ref_np = self.ref_np_all[0]        # (the first group's: picture 0's references, cpu_baseline's check)
+        self.ref = [[[ctx.upload(p) for p in comps] for comps in grp] for grp in self.ref_np_all]
         self.sets = [BatchSet(self, seed + 50 * s) for s in range(queues)]
         s0 = self.sets[0]
         self.coeff_np, self.mv_np, self.out = s0.coeff_np, s0.mv_np, s0.out
@@ -179,7 +186,7 @@ def cpu_baseline(wl, cores, reps=10):
 
     def one(i, n=1):
         for rep in range(n):
-            f = (i + rep) % wl.frames
+            f = (i + rep) % min(wl.frames, REF_GROUP)       # (pictures of the first reference group)
             outs = []
             for k, (h, w) in enumerate(wl.dims):
                 res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
@@ -700,7 +707,8 @@ def main():
             # residual 2 B + output 1 B + 1 B per reference used + 20 B per block
             "obmc": int((2 + 1 + refs_per_px) * samples) + 20 * args.frames
                     * wl.P["x_num_blocks"] * wl.P["y_num_blocks"],
-            "upsample": 2 * (W * H * 3 // 2) * 5,           # 1 B read + 4 B written, two refs
+            # 1 B read + 4 B written per sample of every reference plane of the step (two launches: luma, chroma)
+            "upsample": wl.groups * 2 * (W * H * 3 // 2) * 5,
             "convert": 3 * samples,
         }
         # launches of a class per step (the row-per-lane OBMC kernels run luma and chroma planes as
@@ -709,7 +717,7 @@ def main():
         # of one step / their summed time
         per_step = {k: (n / profiled_steps if profiled_steps else 1) for k, (ms, n) in prof.items()}
         alg_step = dict(alg_bytes)
-        for k in ("iiwt_finest", "iiwt_coarse", "upsample", "convert"):
+        for k in ("iiwt_finest", "iiwt_coarse", "convert"):
             alg_step[k] = alg_bytes[k] * per_step.get(k, 1)
         kernels = {}
         for k, (ms, n) in prof.items():
