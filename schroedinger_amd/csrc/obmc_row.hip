@@ -47,10 +47,16 @@ constexpr int kRMargin = 16;            // accumulator pixels in front of the ti
 // every address of an accumulate had the same word index mod 4 and 64 lanes met in 8 of the 32 banks
 // (7.2 extra cycles per ds_add, simulated; 2.3 with 85)
 constexpr int kRAccW = 85;
+// rows of 8 pixels and shorter (ND <= 2: the chroma planes, the 8/4 block set): a block starts at most
+// 7 pixels in front of the tile -- margin 8, 9 + 128 + 8 pixels = 73 words (odd again).  With the
+// 32-byte block records that is 27.1 KB of LDS for the 6-pixel-row kernels: six workgroups per CU
+// instead of five.
+template < int ND > constexpr int kRMarginOf = ND <= 2 ? 8 : kRMargin;
+template < int ND > constexpr int kRAccWOf = ND <= 2 ? 73 : kRAccW;
 // blocks whose footprint meets a tile and their (block, row) items: by row length (8-pixel rows
 // and shorter are the small, many blocks of chroma planes and of the 8/4 block set)
 template < int ND > struct RowCaps {
-  static constexpr int kBlk = ND <= 2 ? 352 : 128, kItem = ND <= 2 ? 1792 : 1024;
+  static constexpr int kBlk = ND <= 2 ? 344 : 128, kItem = ND <= 2 ? 1792 : 1024;
 };
 // (row, pixel pair) weight words: 2 * ND per row (zero beyond the block), 32 rows
 template < int ND > constexpr int kRWCapOf = 32 * 2 * ND;
@@ -83,24 +89,30 @@ struct __attribute__ ((aligned (4))) RowRef {
 
 struct __attribute__ ((aligned (8))) RowBlk {
   int16_t y, x;                 // block origin relative to the tile
-  int dcs;                      // DC values of the job's planes, 16 bits each (first plane low)
-  int flags;                    // bits 0-1 mode, 2-5 weights fold at top | bottom | left | right,
+  uint32_t fr;                  // first block row inside the tile | rows inside << 8 | flags << 16:
+                                // flag bits 0-1 mode, 2-5 weights fold at top | bottom | left | right,
                                 // 6 + r: reference r's window at a vertical quarter position (edge class)
-  int rows;                     // first block row inside the tile | rows inside << 8
-  RowRef r[2];
+  RowRef r[2];                  // mode 0 (no reference used): r[0].base = the DC values of the job's planes,
+                                // 16 bits each (first plane low)
 };
-static_assert (sizeof (RowBlk) == 40, "block records: 128 (luma) / 352 (chroma) of them beside the accumulator");
+static_assert (sizeof (RowBlk) == 32, "block records: 128 (luma) / 352 (chroma) of them beside the accumulator");
+
+__device__ __forceinline__ uint32_t
+blk_flags (const RowBlk & hb)
+{
+  return hb.fr >> 16;
+}
 
 __device__ __forceinline__ uint32_t
 blk_ry (const RowBlk & hb, int r)
 {
-  return ((uint32_t) hb.flags >> (6 + r)) & 1u;
+  return (hb.fr >> (16 + 6 + r)) & 1u;
 }
 
 __device__ __forceinline__ int
 blk_dc (const RowBlk & hb, int pl)
 {
-  return pl ? hb.dcs >> 16 : (int) (int16_t) hb.dcs;
+  return pl ? hb.r[0].base >> 16 : (int) (int16_t) hb.r[0].base;
 }
 
 
@@ -153,12 +165,13 @@ acc_add_exact (uint32_t * word, int high, uint32_t value)
 }
 
 // the accumulator word and half of tile-relative pixel (x, y); `par` = 1 when block origins are odd
+template < int ND >
 __device__ __forceinline__ uint32_t *
 acc_word (uint32_t * acc, int par, int x, int y, int *half)
 {
-  const int idx = x + kRMargin + par;
+  const int idx = x + kRMarginOf < ND > + par;
   *half = idx & 1;
-  return acc + y * kRAccW + (idx >> 1);
+  return acc + y * kRAccWOf < ND > + (idx >> 1);
 }
 
 // ---- one reference's prediction of a block row: ND dwords of 4 pixels ---------------------
@@ -327,8 +340,8 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     predict_row < ND, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
     __builtin_amdgcn_sched_barrier (0);
     predict_row < ND, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
-    const uint32_t mode = (uint32_t) hb.flags & 3u;
-    const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
+    const uint32_t mode = blk_flags (hb) & 3u;
+    const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;       // (meaningful in mode 0 only)
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int k = 0; k < ND; k++) {
@@ -356,13 +369,13 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   if (it >= hi)
     return;
   int half;
-  uint32_t *aw = acc_word (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
+  uint32_t *aw = acc_word < ND > (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
   // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go
   uint32_t w[2 * ND];
   if constexpr (CLS == kREdge) {
     // weights folded at the picture's rim (schromotion8.c:673-693): 1-D tables per edge type behind
     // the plain products -- (left | right << 1) pairs of x weights, (top | bottom << 1) y weights
-    const uint32_t fb = ((uint32_t) hb.flags >> 2) & 15u;
+    const uint32_t fb = (blk_flags (hb) >> 2) & 15u;
     const uint32_t *wxf = s_wp + kRWCapOf < ND > + 8 * (fb >> 2), *wyf = s_wp + kRWCapOf < ND > + 32 + 32 * (fb & 3u);
     const uint32_t wy2 = wyf[row] * 0x00010001u;
 #pragma unroll
@@ -425,7 +438,7 @@ row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s
 }
 
 // picture-rim block rows: per-sample clamp and weight folding (accumulate_slow), 4 pixels
-template < int PC >
+template < int PC, int ND >
 __device__ __forceinline__ void
 row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const int *fx, const int *fy, int row, int seg,
     int x_lo, int y_lo, int xfold_hi, int yfold_hi, const int *s_wx, const int *s_wy, uint32_t * acc, int par, bool exact)
@@ -492,7 +505,7 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
     if (x >= xfold_hi)
       wx += s_wx[2 * (job.xblen - job.xoff) - idx - 1];
     int half;
-    uint32_t *aw = acc_word (acc, par, x - x_lo, y - y_lo, &half);
+    uint32_t *aw = acc_word < ND > (acc, par, x - x_lo, y - y_lo, &half);
     const uint32_t v = (uint32_t) (pred[e] * wx * wy);
     if (exact)
       acc_add_exact (aw, half, v & 0xffffu);
@@ -525,7 +538,7 @@ row_finish_prefetch (const PlaneIO & io, int tid, int x_lo, int y_lo, int y_hi, 
   }
 }
 
-template < int TH >
+template < int TH, int ND >
 __device__ __forceinline__ void
 row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, int tid, int x_lo, int y_lo,
     int x_hi, int y_hi, bool fast, const u32x4 * res)
@@ -540,7 +553,7 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
       const int y = y_lo + yy;
       if (y >= y_hi || it >= TH * (kRTW / 8))
         continue;
-      const uint32_t *ap = acc + yy * kRAccW + (kRMargin / 2 + 4 * g);
+      const uint32_t *ap = acc + yy * kRAccWOf < ND > + (kRMarginOf < ND > / 2 + 4 * g);
       uint32_t av[4];
       if (par) {
         // pixel 8 g sits in the high half of word 4 g + 8: shift the five words down by one pixel
@@ -581,7 +594,7 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
     if (y >= y_hi || x >= x_hi)
       continue;
     int half;
-    const uint32_t *aw = acc_word (acc, par, xx, yy, &half);
+    const uint32_t *aw = acc_word < ND > (acc, par, xx, yy, &half);
     const int16_t a = (int16_t) (*aw >> (16 * half));
     const char *rrow = (const char *) io.residual + (size_t) y * io.residual_stride;
     const int16_t res = job.res_bpp == 2 ? gload < int16_t > ((const int16_t *) rrow + x)
@@ -597,7 +610,7 @@ template < int ND, int NP, int TH = kRTH >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * kRAccW];
+  __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * kRAccWOf < ND >];
   __shared__ int s_wx[16], s_wy[32];    // (obmc_row_nd: blocks up to 16 x 32)
   constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
@@ -622,8 +635,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
-  static_assert ((TH * kRAccW) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
-  for (int it = tid; it < TH * kRAccW / 4; it += kRThreads)
+  static_assert ((TH * kRAccWOf < ND >) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
+  for (int it = tid; it < TH * kRAccWOf < ND > / 4; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
 #ifdef SCHRO_ROW_DBG_NOWT      // (scratch builds, wrong results: the set-up without its weight tables)
   if (tid < 16)
@@ -725,8 +738,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         return interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
       };
       const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
-      info.dcs = (int) (((uint32_t) pdc & 0xffffu) | ((uint32_t) pdc_b << 16));
-      info.flags = mode;
+      const int dcs = (int) (((uint32_t) pdc & 0xffffu) | ((uint32_t) pdc_b << 16));
+      uint32_t bflags = (uint32_t) mode;
       int ry[2] = { 0, 0 };
       RowRef in_ref[2], edge_ref[2];    // the window as the row classes / the edge class address it
       bool off_h = false, clamped_v = false;
@@ -755,12 +768,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         edge_ref[r].base = colbase;
         edge_ref[r].ydb = (in_h && used ? (uint32_t) hy & 0xffffu : 0u) | (dB << 16);
         edge_ref[r].dci = 0;
-        info.flags |= (in_h && used && ry[r] ? 1 : 0) << (6 + r);
+        bflags |= (uint32_t) (in_h && used && ry[r] ? 1 : 0) << (6 + r);
       }
       info.r[0] = in_ref[0];
       info.r[1] = in_ref[1];
       const int ra = max (0, -(int) info.y), rb = min (yblen, y_hi - by);
-      info.rows = ra | ((rb - ra) << 8);
       // weights fold where the block hangs over the picture's rim: top | bottom << 1 | left << 2 | right << 3
       const int fold = (by < yoff ? 1 : 0) | (by + yblen > yfold_hi ? 2 : 0) | (bx < xoff ? 4 : 0) | (bx + xblen > xfold_hi ? 8 : 0);
       const bool wide_dc = mode == 0 && ((unsigned) pdc > 255u || (unsigned) pdc_b > 255u);
@@ -782,7 +794,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         key = kREdge;
         info.r[0] = edge_ref[0];
         info.r[1] = edge_ref[1];
-        info.flags |= fold << 2;
+        bflags |= (uint32_t) fold << 2;
       } else if (mode == 3) {
         key = kRBoth;
       } else if (mode == 0) {
@@ -793,6 +805,9 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       // which taps the windows need: the slot inside the class
       const int taps0 = (in_ref[0].ydb >> 16 ? 1 : 0) | (in_ref[0].dci ? 2 : 0), taps1 = (in_ref[1].ydb >> 16 ? 1 : 0) | (in_ref[1].dci ? 2 : 0);
       const int slot = row_slot_base (key) + (key == kRBoth ? taps0 | (taps1 << 2) : key == kRRef0 ? taps0 : key == kRRef1 ? taps1 : 0);
+      if (mode == 0)
+        info.r[0].base = dcs;   // (no window: the field is free)
+      info.fr = (uint32_t) ra | ((uint32_t) (rb - ra) << 8) | (bflags << 16);
       s_hot[blk] = info;
       // the block's rows take the next free items of its class (any order within a class will do)
       const int istart = key == kRRim ? 0 : atomicAdd (&s_icnt[slot], rb - ra);
@@ -826,7 +841,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     const int ib = __shfl (sbase, slot);
     if (!have || slot == row_slot_base (kRRim))
       continue;
-    const int rows = s_hot[blk].rows, ra = rows & 0xff, n = (rows >> 8) & 0xff;
+    const int rows = (int) s_hot[blk].fr, ra = rows & 0xff, n = (rows >> 8) & 0xff;
     uint16_t *ip = s_item + ib + (meta >> 5);
     for (int r = 0; r < n; r++)
       ip[r] = (uint16_t) (blk | ((ra + r) << 9));
@@ -897,11 +912,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
         const int fx[2] = { (int) (int16_t) hb.r[0].base, (int) (int16_t) hb.r[1].base }, fy[2] = { hb.r[0].base >> 16, hb.r[1].base >> 16 };
-        const int md = (hb.flags & 3) | (blk_dc (hb, pl) << 8);
+        const int md = (int) (blk_flags (hb) & 3u) | (blk_dc (hb, pl) << 8);      // (the DC part is read in mode 0 only)
         if (job.prec == 1)
-          row_slow < 1 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+          row_slow < 1, ND > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
         else
-          row_slow < 2 > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+          row_slow < 2, ND > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
       }
     }
     RSTAMP (5);
@@ -911,10 +926,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
     __syncthreads ();
     RSTAMP (6);
-    row_finish < TH > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+    row_finish < TH, ND > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
     if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
       __syncthreads ();
-      for (int it = tid; it < TH * kRAccW / 4; it += kRThreads)
+      for (int it = tid; it < TH * kRAccWOf < ND > / 4; it += kRThreads)
         reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
       __syncthreads ();
     }
@@ -933,8 +948,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // ms per 8 x 2160p luma launch): 2 0.278, 3 0.211, 4 0.180, 5 0.162, 6 0.153, 7 0.148 -- a saturating
 // curve: the launch is no longer waiting for anything in particular (compiled-out stages: everything
 // but the passes 0.056, the passes' arithmetic 0.044, their loads 0.047, the LDS atomics 0.009 ms).
-// The 12-pixel-row kernel takes 72 registers: seven waves per SIMD at 20.9 KB of LDS; the
-// 6-pixel-row kernels (chroma: 352 blocks of 40 bytes, 32 KB) run five workgroups per CU.
+// The 12-pixel-row kernel takes 69 registers: seven waves per SIMD at 19.3 KB of LDS; the
+// 6-pixel-row kernels (chroma: 344 blocks of 32 bytes, a 73-word accumulator pitch: 26.8 KB -- LDS is
+// handed out in 1280-byte granules, 27.1 KB still meant five) run six workgroups per CU:
+// 8 x 2160p OBMC 0.2705 -> 0.2667 ms per step.
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
 void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
