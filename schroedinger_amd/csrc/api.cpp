@@ -137,9 +137,27 @@ ensure_scratch (SchroHipContext * ctx, size_t bytes)
 }
 
 int
+dc_gave_up (SchroHipContext * ctx)
+{
+  if (ctx->dc_gave_up && *(volatile uint32_t *) ctx->dc_gave_up)
+    return set_error (SCHRO_HIP_EDEVICE, "DC prediction launch %u: a strip gave up waiting for the strip above it (its band is incomplete)",
+        *(volatile uint32_t *) ctx->dc_gave_up);
+  return 0;
+}
+
+int
 dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned long long **edge, int *edge_pitch,
     uint32_t * epoch)
 {
+  if (!ctx->dc_gave_up) {
+    SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
+    *ctx->dc_gave_up = 0;
+  }
+  {
+    const int r = dc_gave_up (ctx);
+    if (r)
+      return r;
+  }
   void *&buf = ctx->dc_edge_q[ctx->cur];
   size_t & size = ctx->dc_edge_size_q[ctx->cur];
   const int strips = (max_rows + 63) / 64;
@@ -418,6 +436,7 @@ schro_hip_context_new (int device)
     ctx->big_turn[q] = 0;
     ctx->scratch_size_q[q] = 0;
     ctx->dc_epoch = 0;
+    ctx->dc_gave_up = nullptr;
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
   }
@@ -494,6 +513,8 @@ schro_hip_context_free (SchroHipContext * ctx)
       (void) hipStreamSynchronize (ctx->streams[q]);
   for (auto & s : ctx->slots)
     (void) hipFree (s.ptr);
+  if (ctx->dc_gave_up)
+    (void) hipHostFree (ctx->dc_gave_up);
   for (int q = 0; q < SchroHipContext::kQueues; q++) {
     if (ctx->scratch_q[q])
       (void) hipFree (ctx->scratch_q[q]);
@@ -684,7 +705,7 @@ schro_hip_synchronize (SchroHipContext * ctx)
   SCHRO_HIP_REQUIRE (ctx, "synchronize: no context");
   for (int q = 0; q < SchroHipContext::kQueues; q++)
     SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[q]));
-  return 0;
+  return dc_gave_up (ctx);
 }
 
 // Queues.  The reference's scheduler runs the stages of different pictures on several worker
@@ -1328,7 +1349,7 @@ schro_hip_dc_predict_batch (SchroHipContext * ctx, const SchroHipDcPlane * plane
   }
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
   return launch_dc_predict (ctx->stream, (const DcJob *) d_jobs, nplanes, max_rows, bytes_per_sample, edge, edge_pitch,
-      epoch);
+      epoch, ctx->dc_gave_up);
 }
 
 int
@@ -1564,7 +1585,7 @@ schro_hip_lowdelay_batch (SchroHipContext * ctx, const SchroHipLowDelayPicture *
   }
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DC_PREDICT);
   return launch_dc_predict (ctx->stream, (const DcJob *) d_dc, (int) dc.size (), lp.iwt_luma_height >> depth,
-      bytes_per_sample, edge, edge_pitch, epoch);
+      bytes_per_sample, edge, edge_pitch, epoch, ctx->dc_gave_up);
 }
 
 int

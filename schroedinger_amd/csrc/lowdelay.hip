@@ -1003,6 +1003,7 @@ constexpr int kSkewBlock = 16;  // samples per block
 constexpr int kSkewIn = 16;     // ring of the rows: blocks per row (+ 1: block 0 again behind the last, for reads across the end)
 constexpr int kSkewOut = 8;     // ring of the results (+ 1: samples written across the end)
 constexpr int kSkewDepth = 4;   // blocks per row on their way from memory
+constexpr int kSkewPatience = 1 << 20;  // times a mover asks for the strip above's samples (~2 us each) before it gives up
 
 template < typename T >
 struct SkewRings {
@@ -1013,6 +1014,7 @@ struct SkewRings {
   int ready;                    // blocks of every row (and of the row above) in the ring
   int done;                     // blocks the compute wave has finished
   int stored;                   // blocks of every row out of the ring
+  int abort;                    // the mover gave up waiting for the strip above: both waves leave
 };
 
 __device__ __forceinline__ int
@@ -1087,8 +1089,11 @@ dc_skew_compute (SkewRings < T > &sh, const DcJob & job, int strip)
     const int need = min (b + 2, nblocks);
     while (ready < need) {
       ready = lds_peek (&sh.ready);
-      if (ready < need)
+      if (ready < need) {
+        if (lds_peek (&sh.abort))
+          return;
         __builtin_amdgcn_s_sleep (1);
+      }
     }
     int32_t qn[B], an[B];
     const int xn = (b + 1) * B - lane;          // this lane's sample at the next block's first step
@@ -1102,8 +1107,11 @@ dc_skew_compute (SkewRings < T > &sh, const DcJob & job, int strip)
       // ---- room for this block's results: the block that had their place is out of the ring ----------
       while (stored < b - (kSkewOut - 1)) {
         stored = lds_peek (&sh.stored);
-        if (stored < b - (kSkewOut - 1))
+        if (stored < b - (kSkewOut - 1)) {
+          if (lds_peek (&sh.abort))
+            return;
           __builtin_amdgcn_s_sleep (1);
+        }
       }
       // ---- B steps ----------------------------------------------------------------------------------------
       const int xg = b * B - lane;
@@ -1133,7 +1141,7 @@ dc_skew_compute (SkewRings < T > &sh, const DcJob & job, int strip)
 template < typename T, bool FIRST_STRIP >
 __device__ __forceinline__ void
 dc_skew_move (SkewRings < T > &sh, const DcJob & job, int strip, unsigned long long *edge_out, int edge_pitch,
-    uint32_t epoch)
+    uint32_t epoch, uint32_t * gave_up)
 {
   constexpr int B = kSkewBlock, E = 16 / (int) sizeof (T), G = B / E, D = kSkewDepth;
   const int lane = (int) threadIdx.x - 64;
@@ -1228,7 +1236,17 @@ dc_skew_move (SkewRings < T > &sh, const DcJob & job, int strip, unsigned long l
         }
         if (!FIRST_STRIP) {
           // the strip above has got this far?  If not: ask again, for every block that is on its way
+          int asked = 0;
           while (__any ((uint32_t) (efly[i] >> 32) != epoch)) {
+            // Every wait of this kernel ends here: the strip above runs already (tickets), so the samples
+            // come.  Should they not (a strip lost to a fault): after ~2 s of asking both waves leave, the
+            // strips below follow one by one, and the host finds the launch's epoch in *gave_up.
+            if (++asked > kSkewPatience) {
+              if (lane == 0)
+                __hip_atomic_store (gave_up, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              lds_post (&sh.abort, 1);
+              return;
+            }
             service ();
             __builtin_amdgcn_s_sleep (2);
 #pragma unroll
@@ -1267,7 +1285,8 @@ dc_skew_move (SkewRings < T > &sh, const DcJob & job, int strip, unsigned long l
 // workgroup to finish puts the two counters back to 0 for the queue's next launch.
 template < typename T >
 __global__ __launch_bounds__ (128)
-void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, int edge_pitch, uint32_t epoch, int strips)
+void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, int edge_pitch, uint32_t epoch, int strips,
+    uint32_t * gave_up)
 {
   __shared__ SkewRings < T > sh;
   __shared__ int s_ticket;
@@ -1275,7 +1294,7 @@ void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, 
   edge += 8;
   if (threadIdx.x == 0) {
     s_ticket = (int) __hip_atomic_fetch_add (&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh.ready = sh.done = sh.stored = 0;
+    sh.ready = sh.done = sh.stored = sh.abort = 0;
   }
   __syncthreads ();
   const int ticket = s_ticket, nj = ticket / strips, strip = ticket - nj * strips;
@@ -1288,9 +1307,9 @@ void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, 
         dc_skew_compute < T, false > (sh, job, strip);
     } else {
       if (strip == 0)
-        dc_skew_move < T, true > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch);
+        dc_skew_move < T, true > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch, gave_up);
       else
-        dc_skew_move < T, false > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch);
+        dc_skew_move < T, false > (sh, job, strip, edge + ((size_t) nj * strips + strip) * edge_pitch, edge_pitch, epoch, gave_up);
     }
   }
   __syncthreads ();
@@ -1318,16 +1337,16 @@ dc_skew_ok (const DcJob * jobs, int njobs, int bpp)
 
 int
 launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp,
-    unsigned long long *edge, int edge_pitch, uint32_t epoch)
+    unsigned long long *edge, int edge_pitch, uint32_t epoch, uint32_t * gave_up)
 {
   if (edge) {
     // a workgroup (compute wave + mover wave) per strip of 64 rows of every band
     const int strips = (max_rows + 63) / 64;
     const dim3 grid ((unsigned) (strips * njobs));
     if (bpp == 4)
-      SCHRO_LAUNCH ((dc_skew_kernel < int32_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips);
+      SCHRO_LAUNCH ((dc_skew_kernel < int32_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips, gave_up);
     else
-      SCHRO_LAUNCH ((dc_skew_kernel < int16_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips);
+      SCHRO_LAUNCH ((dc_skew_kernel < int16_t >), grid, dim3 (128), 0, stream, d_jobs, edge, edge_pitch, epoch, strips, gave_up);
   } else {
     // whole waves; a band taller than kDcRows is walked in slabs
     const int threads = std::min (kDcRows, (max_rows + 63) / 64 * 64);

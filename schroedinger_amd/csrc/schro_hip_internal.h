@@ -353,10 +353,12 @@ bool dc_skew_ok (const DcJob * jobs, int njobs, int bpp);
 // edge != NULL: dc_skew_kernel with that hand-over buffer (edge_pitch samples per strip, njobs x strips of
 // them, tagged with `epoch`); NULL: dc_predict_kernel
 int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int max_rows, int bpp,
-    unsigned long long *edge, int edge_pitch, uint32_t epoch);
+    unsigned long long *edge, int edge_pitch, uint32_t epoch, uint32_t * gave_up);
 // the hand-over buffer of the selected queue for a launch of njobs bands of at most max_rows x max_w
 int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned long long **edge,
     int *edge_pitch, uint32_t * epoch);
+// non-zero (the launch's epoch) once a dc_skew_kernel strip has given up waiting: reported by the next call
+int dc_gave_up (SchroHipContext * ctx);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 void dequant_tile_geometry (int *tw, int *th);
 int launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes);
@@ -470,6 +472,7 @@ struct SchroHipContext {
   void *dc_edge_q[kQueues];
   size_t dc_edge_size_q[kQueues];
   uint32_t dc_epoch;
+  uint32_t *dc_gave_up;         // pinned host word the kernel writes a launch's epoch to when a strip gives up
   int cus;                      // compute units of the device (launch shaping)
 };
 
