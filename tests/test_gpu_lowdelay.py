@@ -103,6 +103,37 @@ def test_legal_streams(ctx, geo, bpp, slice_kernel):
 
 
 @pytest.mark.parametrize("bpp", [2, 4])
+def test_seeded_geometries(ctx, bpp, slice_kernel):
+    # two dozen seeded pictures: depth 1 .. 4, slices of 8 .. 128 x 4 .. 32 luma samples that divide every
+    # sub-band evenly (slice_run_kernel's case: 16, 32 or 64 staging words per lane, or -- U and V rows
+    # beyond 64 words -- slice_kernel), 4:2:0 / 4:2:2 / 4:4:4, byte budgets from starved (codes cut off
+    # by the slice's end) to roomy, sparse to dense values with the odd long code, slice_y_length
+    # fields that lie now and then
+    rng = np.random.default_rng(1234 + bpp)
+    for case in range(24):
+        depth = int(rng.integers(1, 5))
+        sw = int(rng.choice([8, 16, 32, 64, 128])) * (1 if depth < 4 else 2)
+        sh = int(rng.choice([4, 8, 16, 32]))
+        sw, sh = max(sw, 1 << depth), max(sh, 1 << depth)
+        chroma = [(1, 1), (1, 0), (0, 0)][int(rng.integers(0, 3))]
+        if (sw >> chroma[0]) < (1 << depth) or (sh >> chroma[1]) < (1 << depth):
+            chroma = (0, 0)
+        nx, ny = int(rng.integers(1, 70 if sw <= 16 else 9)), int(rng.integers(1, 5))
+        w, h = sw * nx, sh * ny
+        num = int(rng.integers(max(8, sw * sh // 24), max(12, sw * sh // 2)))
+        den = int(rng.choice([1, 1, 2, 3]))
+        P = synth.lowdelay_params(w, h, chroma, depth, sw, sh, num, den)
+        assert P["n_horiz_slices"] == nx and P["n_vert_slices"] == ny
+        q = synth.quantised_planes(P, seed=case, scale=float(rng.choice([0.3, 0.8, 2.0, 6.0])),
+                                   big_every=int(rng.choice([0, 0, 97, 1031])), big_range=1 << int(rng.integers(17, 31)))
+        bi = synth.lowdelay_base_index(P, seed=case, lo=0, hi=int(rng.choice([20, 60, 127])))
+        data = O.lowdelay_write(q, P, bpp, bi, pad_bit=case & 1, y_length_bias=int(rng.choice([0, 0, 0, -9, 31])))
+        got = decode_gpu(ctx, [data], P, bpp, misalign=case % 3)
+        compare(got[0], decode_cpu(data, P, bpp), "case %d: %dx%d depth %d slices %dx%d chroma %s %d/%d bytes" % (
+            case, w, h, depth, sw, sh, chroma, num, den))
+
+
+@pytest.mark.parametrize("bpp", [2, 4])
 def test_long_codes_wrap_and_quantiser_range(ctx, bpp, slice_kernel):
     # values beyond the 32-bit decode window (|v| >= 65535), products that wrap in 16 / 32 bits,
     # base indices up to 127 (quantiser index clamps at 60; schrolowdelay.c:140)
