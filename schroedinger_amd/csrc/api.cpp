@@ -1016,7 +1016,11 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       for (int p = 0; p < nplanes; p++)
         tiles += (long) div_up ((planes[p].width >> level) / 2, ruc) * div_up ((planes[p].height >> level) / 2, rur);
       const char *env = getenv ("SCHRO_HIP_IIWT_SMALL");
-      small = env ? atoi (env) != 0 : tiles < 2048;
+      const char *envb = getenv ("SCHRO_HIP_IIWT_SMALL_BELOW");
+      // (r03, SCHRO_HIP_IIWT_SMALL_BELOW: with 4096 the 3264-tile level -- 8 x 1080p's finest, 8 x 2160p's
+      // middle one -- takes the small form: alone 0.0381 -> 0.0351 ms, but 0.0263 -> 0.0322 with two batches in
+      // flight, and 0.002 ms of a 2160p step: left at 2048)
+      small = env ? atoi (env) != 0 : tiles < (envb ? atol (envb) : 2048);
       if (small)
         iiwt_reg_geometry (filter, 1, &lruc, &lrur, &lrmin);
     }
