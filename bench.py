@@ -638,7 +638,8 @@ def main():
     ndev = sa.device_count()
     if ndev < 1:
         raise SystemExit("bench.py rank %d: needs a HIP device; there is no CPU fallback" % rank)
-    if world > ndev:
+    share = os.environ.get("SCHRO_BENCH_SHARE_DEVICE") == "1"   # rehearsals of the N > 1 path on a one-GPU box
+    if world > ndev and not share:
         raise SystemExit("bench.py rank %d: %d ranks but only %d HIP device(s); one rank per GPU"
                          % (rank, world, ndev))
     if args.gpus != world:
@@ -651,7 +652,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    ctx = sa.Context(local_rank)
+    ctx = sa.Context(local_rank % ndev if share else local_rank)
     wl = Workload(ctx, args.frames, seed=1 + 1000 * rank, queues=args.queues)
 
     def barrier():
