@@ -82,7 +82,9 @@ class BatchSet:
                 out = self.out_arena.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
                 g = min(f // REF_GROUP, wl.groups - 1)
-                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][1][k], d_res, out))
+                # (SCHRO_BENCH_ONE_REF=1, a footprint experiment: both references read the same planes)
+                r1 = 0 if os.environ.get("SCHRO_BENCH_ONE_REF") == "1" else 1
+                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][r1][k], d_res, out))
                 co_f.append(co)
                 out_f.append(out)
             self.coeff_np.append(co_f)
