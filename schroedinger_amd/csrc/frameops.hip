@@ -176,7 +176,11 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     const uint8_t *row = job.src + (size_t) gy * job.src_stride;
     u32x4 q;
     if (src_al && gx >= 0 && gx + 16 <= w) {
+#ifdef SCHRO_UP_NT_SRC            // (scratch builds: the reference picture as streaming loads)
+      q = __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x4 *) (row + gx));
+#else
       q = gload < u32x4 > (row + gx);
+#endif
     } else {
       uint32_t d[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll

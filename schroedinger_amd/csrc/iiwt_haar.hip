@@ -113,6 +113,13 @@ haar_quad (uint32_t ll, uint32_t hl, uint32_t lh, uint32_t hh, uint32_t * o00, u
   *o11 = hh;
 }
 
+#ifdef SCHRO_HAAR3_NT             // (scratch builds: coefficients and pixels as streaming accesses)
+#define H3_LOAD(V, p) __builtin_nontemporal_load ((const SCHRO_GLOBAL V *) (p))
+#define H3_STORE(p, ...) __builtin_nontemporal_store ((__VA_ARGS__), (SCHRO_GLOBAL u32x4 *) (p))
+#else
+#define H3_LOAD(V, p) gload < V > (p)
+#define H3_STORE(p, ...) gstore < u32x4 > ((p), (__VA_ARGS__))
+#endif
 template < int SHIFT >
 __global__ __launch_bounds__ (kHaarThreads)
 void iiwt_haar3_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)
@@ -128,23 +135,23 @@ void iiwt_haar3_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)
   const char *base = (const char *) job.sb[0] + (size_t) (8 * by) * job.sb_stride[0];
   const size_t S = (size_t) job.sb_stride[0];
   // level 2 (the coarsest): one coefficient per band; LL2 / HL2 in frame row 8 by, LH2 / HH2 in row 8 by + 4
-  const uint32_t ll2 = gload < uint32_t > (base + (size_t) bx * 4), hl2 = gload < uint32_t > (base + (size_t) (w / 8 + bx) * 4);
-  const uint32_t lh2 = gload < uint32_t > (base + 4 * S + (size_t) bx * 4), hh2 = gload < uint32_t > (base + 4 * S + (size_t) (w / 8 + bx) * 4);
+  const uint32_t ll2 = H3_LOAD (uint32_t, base + (size_t) bx * 4), hl2 = H3_LOAD (uint32_t, base + (size_t) (w / 8 + bx) * 4);
+  const uint32_t lh2 = H3_LOAD (uint32_t, base + 4 * S + (size_t) bx * 4), hh2 = H3_LOAD (uint32_t, base + 4 * S + (size_t) (w / 8 + bx) * 4);
   // level 1: 2 x 2 per band; HL1 in rows 8 by + 4 i, LH1 / HH1 in rows 8 by + 4 i + 2
   u32x2 hl1[2], lh1[2], hh1[2];
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    hl1[i] = gload < u32x2 > (base + (size_t) (4 * i) * S + (size_t) (w / 4 + 2 * bx) * 4);
-    lh1[i] = gload < u32x2 > (base + (size_t) (4 * i + 2) * S + (size_t) (2 * bx) * 4);
-    hh1[i] = gload < u32x2 > (base + (size_t) (4 * i + 2) * S + (size_t) (w / 4 + 2 * bx) * 4);
+    hl1[i] = H3_LOAD (u32x2, base + (size_t) (4 * i) * S + (size_t) (w / 4 + 2 * bx) * 4);
+    lh1[i] = H3_LOAD (u32x2, base + (size_t) (4 * i + 2) * S + (size_t) (2 * bx) * 4);
+    hh1[i] = H3_LOAD (u32x2, base + (size_t) (4 * i + 2) * S + (size_t) (w / 4 + 2 * bx) * 4);
   }
   // level 0: 4 x 4 per band; HL0 in rows 8 by + 2 i, LH0 / HH0 in rows 8 by + 2 i + 1
   u32x4 hl0[4], lh0[4], hh0[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    hl0[i] = gload < u32x4 > (base + (size_t) (2 * i) * S + (size_t) (w / 2 + 4 * bx) * 4);
-    lh0[i] = gload < u32x4 > (base + (size_t) (2 * i + 1) * S + (size_t) (4 * bx) * 4);
-    hh0[i] = gload < u32x4 > (base + (size_t) (2 * i + 1) * S + (size_t) (w / 2 + 4 * bx) * 4);
+    hl0[i] = H3_LOAD (u32x4, base + (size_t) (2 * i) * S + (size_t) (w / 2 + 4 * bx) * 4);
+    lh0[i] = H3_LOAD (u32x4, base + (size_t) (2 * i + 1) * S + (size_t) (4 * bx) * 4);
+    hh0[i] = H3_LOAD (u32x4, base + (size_t) (2 * i + 1) * S + (size_t) (w / 2 + 4 * bx) * 4);
   }
   uint32_t l1[2][2], l0[4][4], px[8][8];
   haar_quad < SHIFT > (ll2, hl2, lh2, hh2, &l1[0][0], &l1[0][1], &l1[1][0], &l1[1][1]);
@@ -163,8 +170,8 @@ void iiwt_haar3_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)
   char *d = (char *) job.dst + (size_t) (8 * by) * job.dst_stride + (size_t) (8 * bx) * 4;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    gstore < u32x4 > (d + (size_t) r * job.dst_stride, (u32x4) { px[r][0], px[r][1], px[r][2], px[r][3] });
-    gstore < u32x4 > (d + (size_t) r * job.dst_stride + 16, (u32x4) { px[r][4], px[r][5], px[r][6], px[r][7] });
+    H3_STORE (d + (size_t) r * job.dst_stride, (u32x4) { px[r][0], px[r][1], px[r][2], px[r][3] });
+    H3_STORE (d + (size_t) r * job.dst_stride + 16, (u32x4) { px[r][4], px[r][5], px[r][6], px[r][7] });
   }
 }
 

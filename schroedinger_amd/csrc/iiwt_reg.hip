@@ -41,6 +41,12 @@
 namespace schro {
 namespace {
 
+#ifdef SCHRO_IIWT_NT_LOAD         // (scratch builds: the coefficients, read once (+ halo), as streaming loads)
+#define IWT_LOAD8(p) __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x2 *) (p))
+#else
+#define IWT_LOAD8(p) gload < u32x2 > (p)
+#endif
+
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
 typedef uint32_t P;             // two packed s16 samples
 
@@ -267,7 +273,11 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
   o.z = __builtin_amdgcn_perm (b1, a1, 0x05040100u);
   o.w = __builtin_amdgcn_perm (b1, a1, 0x07060302u);
   if (store_lane)
+#ifdef SCHRO_IIWT_NT_STORE        // (scratch builds: streaming stores for the transform's output)
+    __builtin_nontemporal_store (o, (SCHRO_GLOBAL u32x4 *) dst);
+#else
     gstore < u32x4 > (dst, o);
+#endif
 }
 
 // LO..HI: region row pairs that exist in the picture (compile-time: see the header)
@@ -285,16 +295,16 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
   for (int k = 0; k < RP; k++) {
     const int r = clampi (r0 + k, 0, nr - 1);
     if (k >= le.lo && k <= le.hi) {
-      const u32x2 ll = gload < u32x2 > ((const char *) job.sb[0] + (size_t) r * job.sb_stride[0] + voff);
-      const u32x2 hl = gload < u32x2 > ((const char *) job.sb[1] + (size_t) r * job.sb_stride[1] + voff);
+      const u32x2 ll = IWT_LOAD8 ((const char *) job.sb[0] + (size_t) r * job.sb_stride[0] + voff);
+      const u32x2 hl = IWT_LOAD8 ((const char *) job.sb[1] + (size_t) r * job.sb_stride[1] + voff);
       E[k][0] = ll.x;
       E[k][1] = ll.y;
       E[k][2] = hl.x;
       E[k][3] = hl.y;
     }
     if (k >= lo.lo && k <= lo.hi) {
-      const u32x2 lh = gload < u32x2 > ((const char *) job.sb[2] + (size_t) r * job.sb_stride[2] + voff);
-      const u32x2 hh = gload < u32x2 > ((const char *) job.sb[3] + (size_t) r * job.sb_stride[3] + voff);
+      const u32x2 lh = IWT_LOAD8 ((const char *) job.sb[2] + (size_t) r * job.sb_stride[2] + voff);
+      const u32x2 hh = IWT_LOAD8 ((const char *) job.sb[3] + (size_t) r * job.sb_stride[3] + voff);
       O[k][0] = lh.x;
       O[k][1] = lh.y;
       O[k][2] = hh.x;
