@@ -157,6 +157,8 @@ class Workload:
                     if other != s:
                         c.queue_wait(s, other)
             self.prev_alone = alone
+            if order == 0:
+                c.upsample_batch(b.up_pairs)
             c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
             obmc_side(b)
             c.select_queue(0)
