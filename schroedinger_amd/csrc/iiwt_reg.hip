@@ -345,8 +345,17 @@ reg_tile_bottom (int nout, const IwtJob & job, int r0, int c0, int nr, int nc, i
   }
 }
 
+// Register budget: four waves per SIMD (128 registers; DD(9,7) with 12 row pairs takes 106 -- left to itself the
+// compiler spreads to 144, three waves).  Alone the kernel runs the same either way; beside the other batch's
+// OBMC (seven waves of 69 registers on every SIMD) the smaller waves find room: finest level 0.0722 -> 0.0703 ms,
+// the 8 x 2160p step 0.4054 -> 0.4012.  Five waves (102 registers) spill: 0.101 ms.
+#ifndef SCHRO_IIWT_WAVES
+#define SCHRO_IIWT_WAVES 4
+#endif
+// (the Haar filters have no halo: all 12 row pairs are worked on, and 128 registers would spill 80 - 90 of them)
+#define IIWT_REG_WAVES(F, RP) (((F) == 3 || (F) == 4) && (RP) == 12 ? 3 : SCHRO_IIWT_WAVES)
 template < int F, int RP >
-__global__ __launch_bounds__ (kRegThreads)
+__global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES (F, RP), IIWT_REG_WAVES (F, RP))))
 void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)
 {
   constexpr int H = filter_halo (F), UR = RP - 2 * H;
