@@ -205,7 +205,9 @@ def test_dc_predict_strips(ctx, dtype, kernel, monkeypatch):
     if kernel == "barrier":
         monkeypatch.setenv("SCHRO_HIP_DC_SKEW", "0")
     E = 16 // np.dtype(dtype).itemsize
-    shapes = [(1, E), (3, 2 * E), (64, 64), (65, 136), (129, 5 * E), (540, 960), (1100, 40), (200, 2048), (70, 16 * 40 + E)]
+    shapes = [(1, E), (3, 2 * E), (64, 64), (65, 136), (129, 5 * E), (540, 960), (1100, 40), (200, 2048), (70, 16 * 40 + E),
+              # the in-ring's wrap (16 blocks of 16 samples) and its neighbours; strips of 63 / 64 / 127 / 128 rows
+              (63, 256), (64, 240), (127, 272), (128, 16 * 33), (66, 16 * 32 - E)]
     for rnd in range(2):
         planes, want = [], []
         for n, (h, w) in enumerate(shapes):
