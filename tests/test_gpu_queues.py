@@ -65,3 +65,31 @@ def test_queue_arguments_are_checked(ctx):
         ctx.queue_mark(16)
     ctx.queue_wait_mark(7)      # never recorded: no-op
     ctx.select_queue(0)
+
+
+def test_queues_on_disjoint_compute_units():
+    # schro_hip_queue_set_cu_mask: queue 0 on every fourth CU, queue 1 on the others -- the inverse wavelet on
+    # one, the same on the other, both equal to the oracle's (a mask changes where a kernel runs, not what it does);
+    # a context of its own: the masks stay with its queues
+    ctx = sa.Context(0)
+    try:
+        q0 = [1 if i % 4 == 0 else 0 for i in range(256)]
+        ctx.queue_set_cu_mask(0, q0)
+        ctx.queue_set_cu_mask(1, [1 - b for b in q0])
+        h, w, depth, filt = 144, 208, 3, 0
+        coeff = synth.image_s(h, w, np.int16, seed=77) >> 3
+        want = O.inverse_iwt(coeff, depth, filt)
+        outs = []
+        for q in (0, 1, 0):
+            ctx.select_queue(q)
+            src, dst = ctx.upload(coeff), ctx.plane(h, w, np.int16)
+            ctx.iiwt_batch([(src, dst)], depth, filt)
+            outs.append(dst)
+        ctx.select_queue(0)
+        ctx.synchronize()
+        for n, dst in enumerate(outs):
+            assert np.array_equal(dst.download(), want), n
+        with pytest.raises(sa.SchroHipError):
+            ctx.queue_set_cu_mask(7, q0)
+    finally:
+        ctx.close()
