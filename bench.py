@@ -56,9 +56,20 @@ class BatchSet:
     def __init__(self, wl, seed):
         import schroedinger_amd as sa
         ctx, dims = wl.ctx, wl.dims
-        # a pair of references per group of 8 pictures (wl.groups), upsampled once per batch
-        self.hp = [[[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)] for _ in range(wl.groups)]
-        self.up_pairs = [(wl.ref[g][r][k], self.hp[g][r][k]) for g in range(wl.groups) for r in range(2) for k in range(3)]
+        # a pair of references per group of 8 pictures (wl.groups), upsampled once per batch: the luma planes'
+        # half-pel image and ONE (U, V) pair image for the chroma planes (include/schro_hip.h, r04;
+        # SCHRO_BENCH_PAIR=0: an image per chroma plane, the r03 form)
+        pair = os.environ.get("SCHRO_BENCH_PAIR", "1") != "0"
+        (ch, cw) = dims[1]
+        if pair:
+            self.hp = [[[ctx.hp_plane(*dims[0])] + [ctx.hp_plane(ch, cw, pair=True)] * 2 for _ in range(2)] for _ in range(wl.groups)]
+            self.up_luma = [(wl.ref[g][r][0], self.hp[g][r][0]) for g in range(wl.groups) for r in range(2)]
+            self.up_chroma = [((wl.ref[g][r][1], wl.ref[g][r][2]), self.hp[g][r][1]) for g in range(wl.groups) for r in range(2)]
+        else:
+            self.hp = [[[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)] for _ in range(wl.groups)]
+            self.up_luma = [(wl.ref[g][r][0], self.hp[g][r][0]) for g in range(wl.groups) for r in range(2)]
+            self.up_chroma = [(wl.ref[g][r][k], self.hp[g][r][k]) for g in range(wl.groups) for r in range(2) for k in (1, 2)]
+        self.up_pairs = self.up_luma + self.up_chroma
         self.iwt_pairs, self.obmc_jobs = [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
@@ -135,9 +146,9 @@ class Workload:
                 c.upsample_batch(b.up_pairs)
                 c.obmc_batch(b.obmc_jobs)
             else:
-                c.upsample_batch([p for n, p in enumerate(b.up_pairs) if n % 3 == 0])
+                c.upsample_batch(b.up_luma)
                 c.obmc_batch([j for n, j in enumerate(b.obmc_jobs) if n % 3 == 0])
-                c.upsample_batch([p for n, p in enumerate(b.up_pairs) if n % 3])
+                c.upsample_batch(b.up_chroma)
                 c.obmc_batch([j for n, j in enumerate(b.obmc_jobs) if n % 3])
         if self.queues == 1:
             b = self.sets[0]

@@ -46,6 +46,7 @@ extern "C" {
 #define SCHRO_HIP_EDEVICE (-2)  /* HIP runtime error */
 #define SCHRO_HIP_ENOMEM (-3)
 #define SCHRO_HIP_EUNSUPPORTED (-4)
+#define SCHRO_HIP_ESKIPPED (-5) /* scheduler: the picture did not run, one of its references had failed */
 
 /* schroedinger/schrodomain.h:30-36 -- ids for the new domain */
 #define SCHRO_EXEC_DOMAIN_HIP 0x0004
@@ -79,6 +80,7 @@ void schro_hip_init (void);
  * calling THREAD is bound to -- and fails loudly on a thread bound to none.  schro_hip_context_new
  * binds the creating thread; the scheduler's threads bind theirs. */
 void schro_hip_thread_bind (SchroHipContext * ctx);
+SchroHipContext *schro_hip_thread_bound (void);        /* the calling thread's domain, NULL if none */
 
 /* SchroMemoryDomain.alloc / .free (schrodomain.h:18-22) */
 void *schro_hip_domain_alloc (SchroHipContext * ctx, size_t size);
@@ -365,21 +367,38 @@ int schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * 
  *   before: offset - 512 + 16.  stride = bytes per band of 4 rows = 512 * ((width + 79) / 16 + 1);
  *   the buffer holds ceil (height / 4) bands and must be 128-byte aligned.
  * schro_hip_upsampled_bytes () gives stride and size, schro_hip_upsampled_download () copies the
- * half-pel image to the host in linear order.  Plain (not upsampled) frames are linear. */
+ * half-pel image to the host in linear order.  Plain (not upsampled) frames are linear.
+ *
+ * r04 -- PAIR images.  The U and V components of a 4:2:0 / 4:2:2 picture have the same blocks, motion
+ * vectors and sample windows; a pair image holds both in the layout above over samples of TWO bytes
+ * (U, V): byte column 2 * xp + c of a plane row (c = 0 U, 1 V), i.e. a chunk is 16 samples wide and
+ * advances by 8, the aprons are 64 bytes:
+ *   offset (X, Y, c) = (y >> 2) * stride + (xb >> 4) * 512 + plane * 128 + (y & 3) * 32 + (xb & 15),
+ *   xb = 2 * ((X >> 1) + 32) + c; stride = 512 * ((2 * width + 143) / 16 + 1).
+ * One load per tap then brings a block row of both components (schro_hip_obmc_batch: ref_pair).
+ * schro_hip_upsample_batch writes a pair image when src_v is set (src = the U plane);
+ * schro_hip_upsampled_pair_bytes / _pair_download are the helpers. */
 typedef struct {
   const uint8_t *src;
   int src_stride;
   uint8_t *dst;                 /* the four tiled planes, see above */
-  int dst_stride;               /* bytes per band of 4 rows, from schro_hip_upsampled_bytes */
+  int dst_stride;               /* bytes per band of 4 rows, from schro_hip_upsampled_bytes / _pair_bytes */
   int width;
   int height;
+  const uint8_t *src_v;         /* NULL: one component.  Else: src / src_v are the U / V planes (same size), dst a pair image */
+  int src_v_stride;
 } SchroHipUpsamplePlane;
 
 /* bytes to allocate for the half-pel planes of a width x height component; *stride
  * receives the band pitch */
 size_t schro_hip_upsampled_bytes (int width, int height, int *stride);
+/* ... for the pair image of two width x height components */
+size_t schro_hip_upsampled_pair_bytes (int width, int height, int *stride);
 /* half-pel planes (on the device) -> linear host rows of 2 * width samples, 2 * height of them */
 int schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride,
+    const void *dev, int dev_stride, int width, int height);
+/* ... of a pair image: both components, each as above */
+int schro_hip_upsampled_pair_download (SchroHipContext * ctx, void *host_u, void *host_v, int host_stride,
     const void *dev, int dev_stride, int width, int height);
 
 int schro_hip_upsample_batch (SchroHipContext * ctx,
@@ -396,7 +415,11 @@ int schro_hip_upsample_batch (SchroHipContext * ctx,
  * schromotion8.c:730-758 does.
  * ref1/ref2: mv_precision == 0 -> plain u8 planes (width x height);
  *            mv_precision >= 1 -> tiled half-pel planes (see above), strides = their band pitch.
- *            ref2 may be NULL when no block uses it. */
+ *            ref2 may be NULL when no block uses it.
+ * ref_pair:  (mv_precision >= 1, component 1 or 2) ref1 / ref2 are PAIR images of the picture's U and V
+ *            components.  The U and the V plane of a picture given next to each other (U first) with the
+ *            same pair images are predicted together -- one fetch per tap for both; any other use
+ *            reads the component's bytes out of the pair image (correct, slower). */
 typedef struct {
   const void *mvs;
   int x_num_blocks, y_num_blocks;
@@ -416,6 +439,7 @@ typedef struct {
   int out_stride;
   int width;                    /* component picture size */
   int height;
+  int ref_pair;                 /* 0: one component per reference image; 1: pair images */
 } SchroHipObmcPlane;
 
 int schro_hip_obmc_batch (SchroHipContext * ctx,
@@ -712,6 +736,13 @@ int schro_hipframe_to_cpu_async (SchroHipFrame * dest, SchroHipFrame * src);
  * component on dst_ctx's selected queue, complete on return (the scheduler's reference migration) */
 SchroHipFrame *schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src);
 
+/* How the stage calls below end.  complete_on_return != 0 (the default): the reference's contract -- a stage
+ * is complete when its function returns (schroasync-pthread.c:320-328); the call waits for the selected
+ * queue.  0: the calls only ENQUEUE on the selected queue (frames must be on the device already; the
+ * motion vectors go through pinned staging buffers), for a host that keeps several pictures in flight and
+ * orders them with marks: three 2160p pictures in flight run at the plane layer's rate. */
+int schro_hip_context_set_stage_completion (SchroHipContext * ctx, int complete_on_return);
+
 /* schro_frame_inverse_iwt_transform_cuda (schrocuda.h:13-14) replacement, same arguments:
  * upload transform_frame (host) or use it where it is (device), run the multi-level inverse
  * transform into `frame` (device, iwt-padded size). */
@@ -734,7 +765,9 @@ int schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame);
 /* schro_motion_render (motion, dest, addframe, add, output_frame) (schromotion.h:100, as
  * x_render_motion calls it, schrodecoder.c:1905-1935) replacement, same arguments: add must
  * be TRUE, `dest` (the CPU path's s16 scratch frame) is not used and may be NULL.  addframe:
- * device s16/s32 residual (picture->frame), output_frame: device u8.  Global motion is not
+ * device s16/s32 residual (picture->frame), or NULL for a zero_residual picture (nothing is added,
+ * nothing is read: schrodecoder.c:1904-1906); output_frame: device u8.  motion->motion_vectors: the
+ * host array, or a device copy of it.  Global motion is not
  * supported (the reference routes it to a different renderer, schromotion.c:113-118)
  * -> SCHRO_HIP_EUNSUPPORTED. */
 int schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest,
@@ -799,6 +832,15 @@ int schro_hip_scheduler_retire (SchroHipScheduler * sched, int picture_number);
 int schro_hip_scheduler_publish_reference (SchroHipScheduler * sched, int device_index, void *frame);
 void *schro_hip_scheduler_reference_frame (SchroHipScheduler * sched, int device_index, int picture_number);
 long schro_hip_scheduler_moves (SchroHipScheduler * sched);       /* frames copied between devices so far */
+/* r04: nothing on the path drains a device.  A reference picture is complete when an event stands behind
+ * the work its function enqueued; pictures of the same device follow it in the in-order queues, a picture
+ * on another device waits for the event on its copy queue and copies asynchronously (TODO-CUDA:5-7).
+ * A reference whose function returned an error is marked failed: its dependents -- and theirs -- do not
+ * run, they finish with SCHRO_HIP_ESKIPPED (the reference decoder skips such pictures: picture->error,
+ * schrodecoder.c:1308-1311, :1399-1418); schro_hip_scheduler_wait still reports the first real error. */
+long schro_hip_scheduler_skipped (SchroHipScheduler * sched);     /* pictures skipped so far */
+/* most reference pictures of ONE device whose device work was still running when the next one had been enqueued */
+int schro_hip_scheduler_refs_in_flight_max (SchroHipScheduler * sched);
 /* waits until every submitted picture has run; returns the first non-zero result of a func */
 int schro_hip_scheduler_wait (SchroHipScheduler * sched);
 

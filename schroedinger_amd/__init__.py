@@ -86,15 +86,19 @@ class DevicePlane:
 
 class HpPlane(DevicePlane):
     """The half-pel (2x upsampled) image of a width x height u8 component: 2*height x
-    2*width samples as the four tiled half-pel planes of include/schro_hip.h."""
+    2*width samples as the four tiled half-pel planes of include/schro_hip.h.
+    pair=True: the PAIR image of two such components (the U and V planes of a picture,
+    samples interleaved)."""
 
-    def __init__(self, ctx, height, width):
+    def __init__(self, ctx, height, width, pair=False):
         self.ctx = ctx
         self.dtype = np.dtype(np.uint8)
+        self.pair = bool(pair)
         self.comp_height, self.comp_width = int(height), int(width)
         self.height, self.width = 2 * self.comp_height, 2 * self.comp_width
         st = C.c_int(0)
-        self.nbytes = ctx.lib.schro_hip_upsampled_bytes(self.comp_width, self.comp_height, C.byref(st))
+        size_of = ctx.lib.schro_hip_upsampled_pair_bytes if pair else ctx.lib.schro_hip_upsampled_bytes
+        self.nbytes = size_of(self.comp_width, self.comp_height, C.byref(st))
         self.stride = st.value
         self.ptr = ctx.alloc(self.nbytes)
 
@@ -102,7 +106,13 @@ class HpPlane(DevicePlane):
         raise SchroHipError("half-pel images are produced by upsample_batch")
 
     def download(self):
-        """Linear (2*height, 2*width) array."""
+        """Linear (2*height, 2*width) array; a pair image: the two components' arrays."""
+        if self.pair:
+            u, v = (np.empty((self.height, self.width), np.uint8) for _ in range(2))
+            check(self.ctx.lib.schro_hip_upsampled_pair_download(
+                self.ctx.h, u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), u.strides[0], self.ptr,
+                self.stride, self.comp_width, self.comp_height))
+            return u, v
         out = np.empty((self.height, self.width), np.uint8)
         check(self.ctx.lib.schro_hip_upsampled_download(
             self.ctx.h, out.ctypes.data_as(C.c_void_p), out.strides[0], self.ptr, self.stride,
@@ -263,9 +273,10 @@ class Context:
     def plane(self, height, width, dtype, stride=None):
         return DevicePlane(self, height, width, dtype, stride)
 
-    def hp_plane(self, height, width):
-        """Half-pel image buffer for a height x width u8 component (upsample_batch's dst)."""
-        return HpPlane(self, height, width)
+    def hp_plane(self, height, width, pair=False):
+        """Half-pel image buffer for a height x width u8 component (upsample_batch's dst); pair: for
+        the (U, V) components of a picture together."""
+        return HpPlane(self, height, width, pair)
 
     def upload(self, a, stride=None):
         a = np.ascontiguousarray(a)
@@ -428,12 +439,19 @@ class Context:
         check(self.lib.schro_hip_convert_u8_batch(self.h, arr, n, bpp))
 
     def upsample_batch(self, pairs):
-        """pairs: [(src u8 plane h x w, dst u8 plane 2h x 2w)]."""
+        """pairs: [(src u8 plane h x w, dst HpPlane)] or [((src U, src V), dst pair HpPlane)]."""
         n = len(pairs)
         arr = (_lib.UpsamplePlane * n)()
         for k, (s, d) in enumerate(pairs):
+            sv = None
+            if isinstance(s, (tuple, list)):
+                s, sv = s
+                assert getattr(d, "pair", False) and (sv.height, sv.width) == (s.height, s.width)
+            else:
+                assert not getattr(d, "pair", False)
             assert d.height == 2 * s.height and d.width == 2 * s.width
-            arr[k] = _lib.UpsamplePlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height)
+            arr[k] = _lib.UpsamplePlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height,
+                                        sv.ptr if sv is not None else None, sv.stride if sv is not None else 0)
         check(self.lib.schro_hip_upsample_batch(self.h, arr, n))
 
     def obmc_batch(self, planes):
@@ -459,6 +477,8 @@ def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
     p.residual_bpp = residual.dtype.itemsize
     p.out, p.out_stride = out.ptr, out.stride
     p.width, p.height = out.width, out.height
+    p.ref_pair = 1 if getattr(ref1, "pair", False) else 0      # (U, V) pair images (HpPlane (pair=True))
+    assert ref2 is None or bool(getattr(ref2, "pair", False)) == bool(p.ref_pair)
     return p
 
 
@@ -521,6 +541,14 @@ class Scheduler:
 
     def moves(self):
         return self.lib.schro_hip_scheduler_moves(self.h)
+
+    def skipped(self):
+        """Pictures that did not run because a reference of theirs had failed (or had been skipped)."""
+        return self.lib.schro_hip_scheduler_skipped(self.h)
+
+    def refs_in_flight_max(self):
+        """Most reference pictures of one device whose device work was still running at once."""
+        return self.lib.schro_hip_scheduler_refs_in_flight_max(self.h)
 
     def wait(self):
         r = self.lib.schro_hip_scheduler_wait(self.h)

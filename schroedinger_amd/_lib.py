@@ -13,13 +13,13 @@ LIB_PATH = os.environ.get("SCHRO_HIP_LIB") or os.path.join(_HERE, "libschro_hip.
 # every extern "C" symbol include/schro_hip.h declares
 EXPORTED_SYMBOLS = [
     "schro_hip_context_new", "schro_hip_context_free", "schro_hip_device_count",
-    "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind",
+    "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind", "schro_hip_thread_bound", "schro_hip_context_set_stage_completion",
     "schro_hip_host_alloc", "schro_hip_host_free", "schro_hip_upload_2d_async", "schro_hip_download_2d_async",
     "schro_hip_queue_synchronize", "schro_hip_queue_set_cu_mask", "schro_memory_domain_new_hip_host", "schro_hip_codeblock_layout",
     "schro_frame_to_hip_async", "schro_hipframe_to_cpu_async", "schro_hip_frame_copy_to",
     "schro_upsampled_hipframe_upsample_inplace",
     "schro_hip_scheduler_new_on", "schro_hip_scheduler_publish_reference", "schro_hip_scheduler_reference_frame",
-    "schro_hip_scheduler_moves",
+    "schro_hip_scheduler_moves", "schro_hip_scheduler_skipped", "schro_hip_scheduler_refs_in_flight_max",
     "schro_hip_domain_alloc", "schro_hip_domain_free", "schro_hip_domain_bytes",
     "schro_hip_upload_2d", "schro_hip_download_2d", "schro_hip_memset",
     "schro_hip_synchronize", "schro_hip_stream",
@@ -34,7 +34,8 @@ EXPORTED_SYMBOLS = [
     "schro_hip_timer_begin", "schro_hip_timer_end",
     "schro_hip_profile_enable", "schro_hip_profile_reset", "schro_hip_profile_read",
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
-    "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_pack_u8_batch",
+    "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_upsampled_pair_bytes",
+    "schro_hip_upsampled_pair_download", "schro_hip_pack_u8_batch",
     "schro_hip_pack_v210_batch", "schro_hip_pack_wide_batch", "schro_hip_shift_right_batch",
     "schro_hipframe_shift_right",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
@@ -100,7 +101,8 @@ class DcPlane(C.Structure):
 class UpsamplePlane(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int),
+                ("src_v", C.c_void_p), ("src_v_stride", C.c_int)]
 
 
 class ObmcPlane(C.Structure):
@@ -118,7 +120,7 @@ class ObmcPlane(C.Structure):
                 ("residual", C.c_void_p), ("residual_stride", C.c_int),
                 ("residual_bpp", C.c_int),
                 ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("ref_pair", C.c_int)]
 
 
 class FrameData(C.Structure):
@@ -235,6 +237,10 @@ def load():
     L.schro_hip_init.restype = None
     L.schro_hip_thread_bind.argtypes = [vp]
     L.schro_hip_thread_bind.restype = None
+    L.schro_hip_thread_bound.argtypes = []
+    L.schro_hip_thread_bound.restype = vp
+    L.schro_hip_context_set_stage_completion.argtypes = [vp, i]
+    L.schro_hip_context_set_stage_completion.restype = i
     L.schro_hip_host_alloc.argtypes = [C.c_size_t]
     L.schro_hip_host_alloc.restype = vp
     L.schro_hip_host_free.argtypes = [vp]
@@ -267,6 +273,10 @@ def load():
     L.schro_hip_scheduler_reference_frame.restype = vp
     L.schro_hip_scheduler_moves.argtypes = [vp]
     L.schro_hip_scheduler_moves.restype = C.c_long
+    L.schro_hip_scheduler_skipped.argtypes = [vp]
+    L.schro_hip_scheduler_skipped.restype = C.c_long
+    L.schro_hip_scheduler_refs_in_flight_max.argtypes = [vp]
+    L.schro_hip_scheduler_refs_in_flight_max.restype = i
     L.schro_hip_scheduler_new.argtypes = [i]
     L.schro_hip_scheduler_new.restype = vp
     L.schro_hip_scheduler_new_virtual.argtypes = [i]
@@ -333,6 +343,10 @@ def load():
     L.schro_hip_upsampled_bytes.restype = C.c_size_t
     L.schro_hip_upsampled_download.argtypes = [vp, vp, i, vp, i, i, i]
     L.schro_hip_upsampled_download.restype = i
+    L.schro_hip_upsampled_pair_bytes.argtypes = [i, i, C.POINTER(C.c_int)]
+    L.schro_hip_upsampled_pair_bytes.restype = C.c_size_t
+    L.schro_hip_upsampled_pair_download.argtypes = [vp, vp, vp, i, vp, i, i, i]
+    L.schro_hip_upsampled_pair_download.restype = i
     L.schro_hip_obmc_batch.argtypes = [vp, C.POINTER(ObmcPlane), i]
     L.schro_hip_obmc_batch.restype = i
     L.schro_hip_frame_new_and_alloc.argtypes = [vp, i, i, i, i]

@@ -4,6 +4,8 @@
 // frameops.hip and obmc.hip.
 
 #include "schro_hip_internal.h"
+#include <mutex>
+#include <set>
 
 #include <cstdarg>
 #include <cstdio>
@@ -136,12 +138,18 @@ ensure_scratch (SchroHipContext * ctx, size_t bytes)
   return 0;
 }
 
+// Reported ONCE, by the first call that looks (the launch's epoch names the batch it belongs to); the word is
+// cleared so that later launches of the context are judged on their own.  (The kernel's counters need no
+// reset: they are tagged with the launch's epoch.)
 int
 dc_gave_up (SchroHipContext * ctx)
 {
-  if (ctx->dc_gave_up && *(volatile uint32_t *) ctx->dc_gave_up)
+  if (ctx->dc_gave_up && *(volatile uint32_t *) ctx->dc_gave_up) {
+    const uint32_t epoch = *(volatile uint32_t *) ctx->dc_gave_up;
+    *(volatile uint32_t *) ctx->dc_gave_up = 0;
     return set_error (SCHRO_HIP_EDEVICE, "DC prediction launch %u: a strip gave up waiting for the strip above it (its band is incomplete)",
-        *(volatile uint32_t *) ctx->dc_gave_up);
+        epoch);
+  }
   return 0;
 }
 
@@ -294,11 +302,24 @@ schro_hip_init (void)
 // creates a context, the scheduler's exec-domain threads bind theirs -- and a thread that never bound
 // one gets an error instead of, silently, device 0's domain (the HIP runtime's per-thread default).
 static thread_local SchroHipContext *t_bound_ctx = nullptr;
+// r04: the contexts that exist.  A thread may still be bound to a context another thread has freed
+// (schro_hip_context_free can only clear the CALLING thread's binding): the table's alloc then fails
+// loudly instead of following a dangling pointer.
+static std::mutex g_live_mutex;
+static std::set < SchroHipContext * >g_live;
 
 static SchroHipContext *
 current_device_context ()
 {
-  return t_bound_ctx;
+  SchroHipContext *ctx = t_bound_ctx;
+  if (!ctx)
+    return nullptr;
+  std::lock_guard < std::mutex > lock (g_live_mutex);
+  if (!g_live.count (ctx)) {
+    t_bound_ctx = nullptr;      // freed by another thread
+    return nullptr;
+  }
+  return ctx;
 }
 
 static void *
@@ -346,6 +367,12 @@ schro_hip_thread_bind (SchroHipContext * ctx)
   t_bound_ctx = ctx;
   if (ctx)
     (void) hipSetDevice (ctx->device);
+}
+
+SchroHipContext *
+schro_hip_thread_bound (void)
+{
+  return current_device_context ();
 }
 
 // ---- pinned host memory: what the DMA engines copy from / to at full rate and asynchronously ----
@@ -412,8 +439,13 @@ frame_ctx (const SchroHipFrame * f)
   return f->domain->ctx;
 }
 
+}                               // extern "C"
+
+namespace schro {
+// A context that does not touch the calling thread's domain binding (the scheduler's contexts belong to its
+// worker threads; the thread that creates the scheduler may own a context of its own).
 SchroHipContext *
-schro_hip_context_new (int device)
+context_new_unbound (int device)
 {
   if (hipSetDevice (device) != hipSuccess) {
     set_error (SCHRO_HIP_EDEVICE, "hipSetDevice(%d) failed", device);
@@ -445,6 +477,7 @@ schro_hip_context_new (int device)
     ctx->cus = hipGetDeviceProperties (&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   ctx->cur = 0;
+  ctx->stage_complete = true;
   memset (ctx->marks, 0, sizeof (ctx->marks));
   ctx->arg_clock = 0;
   memset (ctx->arg_slots, 0, sizeof (ctx->arg_slots));
@@ -472,7 +505,39 @@ schro_hip_context_new (int device)
     delete ctx;
     return nullptr;
   }
-  t_bound_ctx = ctx;            // the creating thread is the context's exec-domain thread until told otherwise
+  {
+    std::lock_guard < std::mutex > lock (g_live_mutex);
+    g_live.insert (ctx);
+  }
+  return ctx;
+}
+
+// Queue 0 waits for everything enqueued so far on the context's other queues, then `ev` is recorded on it:
+// one event behind all the device work of a picture, whichever queues its function used.  No host wait.
+int
+context_join_queues (SchroHipContext * ctx, hipEvent_t ev)
+{
+  (void) hipSetDevice (ctx->device);
+  for (int q = 1; q < SchroHipContext::kQueues; q++) {
+    SCHRO_HIP_CHECK (hipEventRecord (ctx->queue_ev[q], ctx->streams[q]));
+    SCHRO_HIP_CHECK (hipStreamWaitEvent (ctx->streams[0], ctx->queue_ev[q], 0));
+  }
+  SCHRO_HIP_CHECK (hipEventRecord (ev, ctx->streams[0]));
+  return 0;
+}
+}                               // namespace schro
+
+extern "C" {
+
+// The creating thread becomes the context's exec-domain thread -- unless it is one already (r03 rebound it
+// unconditionally: a thread that owned device 0's context and created a second one found its argument-less
+// alloc table serving the wrong device).
+SchroHipContext *
+schro_hip_context_new (int device)
+{
+  SchroHipContext *ctx = schro::context_new_unbound (device);
+  if (ctx && !current_device_context ())
+    t_bound_ctx = ctx;
   return ctx;
 }
 
@@ -550,6 +615,11 @@ schro_hip_context_free (SchroHipContext * ctx)
   }
   (void) hipEventDestroy (ctx->ev_begin);
   (void) hipEventDestroy (ctx->ev_end);
+  // (threads still bound to this context elsewhere find it gone: current_device_context)
+  {
+    std::lock_guard < std::mutex > lock (g_live_mutex);
+    g_live.erase (ctx);
+  }
   if (t_bound_ctx == ctx)
     t_bound_ctx = nullptr;
   free (ctx->domain);
@@ -1272,33 +1342,63 @@ schro_hip_shift_right_batch (SchroHipContext * ctx, const SchroHipDcPlane * plan
   return launch_shift_right (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bytes_per_sample, shift);
 }
 
-size_t
-schro_hip_upsampled_bytes (int width, int height, int *stride)
+static size_t
+upsampled_bytes (int width, int height, int ps, int *stride)
 {
   if (width <= 0 || height <= 0)
     return 0;
-  const size_t st = (size_t) hp_chunks (width) * 512;
+  const size_t st = (size_t) hp_chunks (width, ps) * 512;
   if (stride)
     *stride = (int) st;
   return st * (size_t) div_up (height, kHpBandRows);
+}
+
+size_t
+schro_hip_upsampled_bytes (int width, int height, int *stride)
+{
+  return upsampled_bytes (width, height, 0, stride);
+}
+
+size_t
+schro_hip_upsampled_pair_bytes (int width, int height, int *stride)
+{
+  return upsampled_bytes (width, height, 1, stride);
+}
+
+static int
+upsampled_download (SchroHipContext * ctx, void *const *host, int host_stride, const void *dev, int dev_stride, int width,
+    int height, int ps)
+{
+  SCHRO_HIP_REQUIRE (ctx && host[0] && (!ps || host[1]) && dev && width > 0 && height > 0
+      && dev_stride >= hp_chunks (width, ps) * 512 && dev_stride % 512 == 0 && host_stride >= 2 * width,
+      "upsampled_download: bad arguments");
+  (void) hipSetDevice (ctx->device);
+  std::vector < uint8_t > raw ((size_t) dev_stride * (size_t) div_up (height, kHpBandRows));
+  SCHRO_HIP_CHECK (hipMemcpyAsync (raw.data (), dev, raw.size (), hipMemcpyDeviceToHost, ctx->stream));
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (int c = 0; c <= ps; c++)
+    for (int y = 0; y < 2 * height; y++) {
+      uint8_t *d = (uint8_t *) host[c] + (size_t) y * host_stride;
+      for (int x = 0; x < 2 * width; x++)
+        d[x] = raw[hp_offset (x, y, dev_stride, ps, c)];
+    }
+  return 0;
 }
 
 int
 schro_hip_upsampled_download (SchroHipContext * ctx, void *host, int host_stride, const void *dev,
     int dev_stride, int width, int height)
 {
-  SCHRO_HIP_REQUIRE (ctx && host && dev && width > 0 && height > 0 && dev_stride >= hp_chunks (width) * 512
-      && dev_stride % 512 == 0 && host_stride >= 2 * width, "upsampled_download: bad arguments");
-  (void) hipSetDevice (ctx->device);
-  std::vector < uint8_t > raw ((size_t) dev_stride * (size_t) div_up (height, kHpBandRows));
-  SCHRO_HIP_CHECK (hipMemcpyAsync (raw.data (), dev, raw.size (), hipMemcpyDeviceToHost, ctx->stream));
-  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
-  for (int y = 0; y < 2 * height; y++) {
-    uint8_t *d = (uint8_t *) host + (size_t) y * host_stride;
-    for (int x = 0; x < 2 * width; x++)
-      d[x] = raw[hp_offset (x, y, dev_stride)];
-  }
-  return 0;
+  void *const hosts[2] = { host, nullptr };
+  return upsampled_download (ctx, hosts, host_stride, dev, dev_stride, width, height, 0);
+}
+
+int
+schro_hip_upsampled_pair_download (SchroHipContext * ctx, void *host_u, void *host_v, int host_stride, const void *dev,
+    int dev_stride, int width, int height)
+{
+  void *const hosts[2] = { host_u, host_v };
+  return upsampled_download (ctx, hosts, host_stride, dev, dev_stride, width, height, 1);
 }
 
 // ---- VC-2 low-delay transform data (lowdelay.hip) ---------------------------------
@@ -1604,18 +1704,22 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
   int tile_base = 0;
   for (int p = 0; p < nplanes; p++) {
     const SchroHipUpsamplePlane & pl = planes[p];
+    const int ps = pl.src_v ? 1 : 0;    // a (U, V) pair: samples of two bytes, tiles half as wide
     SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0
-        && pl.dst_stride >= hp_chunks (pl.width) * 512 && pl.dst_stride % 512 == 0 && pl.src_stride >= pl.width
-        && ((uintptr_t) pl.dst & 127) == 0,
-        "upsample_batch: plane %d invalid (half-pel image: 128-byte aligned, stride from schro_hip_upsampled_bytes)", p);
+        && pl.dst_stride >= hp_chunks (pl.width, ps) * 512 && pl.dst_stride % 512 == 0 && pl.src_stride >= pl.width
+        && (!pl.src_v || pl.src_v_stride >= pl.width) && ((uintptr_t) pl.dst & 127) == 0,
+        "upsample_batch: plane %d invalid (half-pel image: 128-byte aligned, stride from schro_hip_upsampled_bytes / _pair_bytes)", p);
     UpsampleJob & j = jobs[p];
+    memset (&j, 0, sizeof (j));
     j.src = pl.src;
     j.dst = pl.dst;
     j.src_stride = pl.src_stride;
     j.dst_stride = pl.dst_stride;
     j.w = pl.width;
     j.h = pl.height;
-    j.tiles_x = div_up (pl.width, tw);
+    j.src_b = pl.src_v;
+    j.src_b_stride = pl.src_v_stride;
+    j.tiles_x = div_up (pl.width, tw >> ps);
     j.tile_base = tile_base;
     tile_base += j.tiles_x * div_up (pl.height, th);
   }
@@ -1794,12 +1898,14 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     static const int sup_x = getenv ("SCHRO_HIP_OBMC_SUPER_X") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_X"))) : 4;
     static const int sup_y = getenv ("SCHRO_HIP_OBMC_SUPER_Y") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_Y"))) : 4;
     for (size_t j = 0; j < jobs.size (); j++) {
-      // (a U + V pair reads two planes of each reference: half the width)
-      const int sx = jobs[j].nplanes == 2 ? std::max (1, sup_x / 2) : sup_x;
+      // (a U + V pair reads two planes of each reference: half the width; pairs from pair images -- variant 4,
+      // tiles of 64 x 32 chroma pixels -- cover the picture area of a luma tile twice as high: half the height)
+      const int sx = variant == 4 ? sup_x : jobs[j].nplanes == 2 ? std::max (1, sup_x / 2) : sup_x;
+      const int sy = variant == 4 ? std::max (1, sup_y / 2) : sup_y;
       const int nsx = div_up (jobs[j].tiles_x, sx);
       for (int ty = 0; ty < tiles_y[j]; ty++)
         for (int tx = 0; tx < jobs[j].tiles_x; tx++)
-          keys.push_back (Key { (uint32_t) ((ty / sup_y) * nsx + tx / sx), ref_class[j],
+          keys.push_back (Key { (uint32_t) ((ty / sy) * nsx + tx / sx), ref_class[j],
               (uint32_t) (j << 16) | (uint32_t) (ty * jobs[j].tiles_x + tx) });
     }
     if (keys.size () != (size_t) total)
@@ -1898,11 +2004,12 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   std::vector < int >key (nplanes), row_nd (nplanes);
   for (int p = 0; p < nplanes; p++) {
     const SchroHipObmcPlane & pl = planes[p];
-    SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.residual && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
+    // (residual NULL: nothing to add -- the prediction alone, clamped)
+    SCHRO_HIP_REQUIRE (pl.mvs && pl.ref1 && pl.out, "obmc_batch: plane %d has a NULL pointer", p);
     SCHRO_HIP_REQUIRE (pl.mv_precision >= 0 && pl.mv_precision <= 3,
         "obmc_batch: mv_precision %d out of range", pl.mv_precision);
     SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
-    SCHRO_HIP_REQUIRE (pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
+    SCHRO_HIP_REQUIRE (!pl.residual || pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
     SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
         "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
     // bits 0 with a gain other than 1: the reference's edge-block ROUND_SHIFT is
@@ -1947,14 +2054,25 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     j.ref[1] = pl.ref2 ? pl.ref2 : pl.ref1;
     j.ref_stride[1] = pl.ref2 ? pl.ref2_stride : pl.ref1_stride;
     j.residual = pl.residual;
-    j.residual_stride = pl.residual_stride;
-    j.res_bpp = pl.residual_bpp;
+    j.residual_stride = pl.residual ? pl.residual_stride : 0;
+    j.res_bpp = pl.residual ? pl.residual_bpp : 2;
     j.out = pl.out;
     j.out_stride = pl.out_stride;
     j.w = pl.width;
     j.h = pl.height;
+    // pair images (r04): the component is byte component - 1 of the (U, V) samples
+    SCHRO_HIP_REQUIRE (!pl.ref_pair || (pl.mv_precision >= 1 && pl.component >= 1),
+        "obmc_batch: plane %d: ref_pair is for the chroma components of half-pel references", p);
+    j.ref_ps = pl.ref_pair ? 1 : 0;
+    j.ref_cb = pl.ref_pair ? pl.component - 1 : 0;
+    if (pl.mv_precision >= 1)   // the tiled half-pel layout: a plain plane or an image of another layout read as one goes out of bounds
+      for (int r = 0; r < 2; r++)
+        SCHRO_HIP_REQUIRE (j.ref_stride[r] % 512 == 0 && j.ref_stride[r] >= hp_chunks (j.w, j.ref_ps) * 512
+            && ((uintptr_t) j.ref[r] & 127) == 0,
+            "obmc_batch: plane %d: reference %d is not a half-pel image of this component (128-byte aligned, stride from "
+            "schro_hip_upsampled_bytes / _pair_bytes)", p, r + 1);
     const int variant = variant_of (pl);
-    const int nd_row = (variant == 1 && use_row) ? obmc_row_nd (j) : 0;
+    const int nd_row = (variant == 1 && use_row) ? obmc_row_nd (j, false) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
     key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0);
     row_nd[p] = nd_row;
@@ -1969,13 +2087,29 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     if (row_nd[p] && all[p].comp != 0)
       pair_tiles += (long) ((all[p].w + 127) / 128) * ((all[p].h + 31) / 32);
   const bool pairs_pay = obmc_row_merge_mode () == 2 || (obmc_row_merge_mode () == 1 && pair_tiles > 6L * ctx->cus);
-  for (int p = 0; pairs_pay && p + 1 < nplanes; p++) {
-    const ObmcJob & a = all[p], &b = all[p + 1];
-    if (row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && a.comp == 1 && b.comp == 2
+  auto same_blocks = [](const ObmcJob & a, const ObmcJob & b) {
+    return a.comp == 1 && b.comp == 2
         && a.mvs == b.mvs && a.w == b.w && a.h == b.h && a.nbx == b.nbx && a.nby == b.nby && a.xblen == b.xblen
         && a.yblen == b.yblen && a.xbsep == b.xbsep && a.ybsep == b.ybsep && a.mv_shift_x == b.mv_shift_x
         && a.mv_shift_y == b.mv_shift_y && a.res_bpp == b.res_bpp && a.ref_stride[0] == b.ref_stride[0]
-        && a.ref_stride[1] == b.ref_stride[1]) {
+        && a.ref_stride[1] == b.ref_stride[1] && a.prec == b.prec;
+  };
+  for (int p = 0; p + 1 < nplanes; p++) {
+    const ObmcJob & a = all[p], &b = all[p + 1];
+    // r04: the U and V planes of a picture from PAIR images: one job, one fetch per tap for both
+    // (obmc_row.hip, UV form); what it does not take (eighth pel, other weights, long rows) reads
+    // its component out of the pair images in obmc.hip
+    if (a.ref_ps && b.ref_ps && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
+        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1]) {
+      const int nd = obmc_row_nd (a, true);
+      if (nd) {
+        row_nd[p] = row_nd[p + 1] = nd;
+        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18);
+        p++;
+      }
+      continue;
+    }
+    if (pairs_pay && row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && same_blocks (a, b)) {
       key[p] |= 1 << 17;
       key[p + 1] |= 1 << 17;
       p++;
@@ -1993,8 +2127,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       for (int p = first; p < nplanes; p++)
         if (!done[p] && key[p] == key[first])
           nd = std::max (nd, row_nd[p]);
-    const int variant = nd ? 3 : ((key[first] >> 4) & 15);
-    const bool paired = (key[first] >> 17) & 1;
+    const bool paired = (key[first] >> 17) & 1, uv = (key[first] >> 18) & 1;
+    const int variant = uv ? 4 : nd ? 3 : ((key[first] >> 4) & 15);
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
     for (int p = first; p < nplanes; p++) {
@@ -2008,7 +2142,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       obmc_item_geometry (&j);
       j.stamps = obmc_stamp_buffer ();
       j.nplanes = 1;
-      if (paired && j.comp == 2) {
+      if ((paired || uv) && j.comp == 2) {
         // the V plane joins the U plane in front of it (checked above)
         ObmcJob & a = jobs.back ();
         a.nplanes = 2;
@@ -2036,7 +2170,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, paired ? 2 : 1, d_order)
+      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order)
           : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
     }
     if (r)
@@ -2046,6 +2180,28 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
 }
 
 // ---- frame layer -----------------------------------------------------------------
+
+// How a stage call ends.  The reference's scheduler expects a stage complete when its function returns
+// (schroasync-pthread.c:320-328): the default -- the selected queue is waited for (that queue only: r03
+// drained all four).  A host that pipelines pictures itself turns that off
+// (schro_hip_context_set_stage_completion (ctx, 0)): the same calls then only enqueue on the selected
+// queue, and marks / schro_hip_queue_synchronize order and end them.
+static int
+stage_done (SchroHipContext * ctx, int r)
+{
+  if (r || !ctx->stage_complete)
+    return r;
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return dc_gave_up (ctx);
+}
+
+int
+schro_hip_context_set_stage_completion (SchroHipContext * ctx, int complete_on_return)
+{
+  SCHRO_HIP_REQUIRE (ctx, "set_stage_completion: no context");
+  ctx->stage_complete = complete_on_return != 0;
+  return 0;
+}
 
 static int
 format_bpp (int format)
@@ -2104,8 +2260,11 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
   f->format = format;
   f->width = width;
   f->height = height;
-  f->is_upsampled = upsampled;
   int h_shift = SCHRO_HIP_FORMAT_H_SHIFT (format), v_shift = SCHRO_HIP_FORMAT_V_SHIFT (format);
+  // r04: the chroma of a horizontally subsampled upsampled frame is ONE pair image (is_upsampled == 2):
+  // components[1] holds it, components[2] points at the same bytes (length 0: nothing of its own)
+  const bool pair = upsampled && h_shift == 1;
+  f->is_upsampled = pair ? 2 : upsampled ? 1 : 0;
   // chroma size rounds up, schroframe.c:95-96
   int cw = (width + (1 << h_shift) - 1) >> h_shift, ch = (height + (1 << v_shift) - 1) >> v_shift;
   size_t total = 0;
@@ -2120,8 +2279,11 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     c->length = c->stride * c->height;
     if (upsampled) {            // the four half-pel planes, tiled (include/schro_hip.h): stride = bytes per band of 4 rows
       int st = 0;
-      c->length = (int) schro_hip_upsampled_bytes (c->width, c->height, &st);
+      c->length = (int) (pair && k ? schro_hip_upsampled_pair_bytes (c->width, c->height, &st)
+          : schro_hip_upsampled_bytes (c->width, c->height, &st));
       c->stride = st;
+      if (pair && k == 2)
+        c->length = 0;
     }
     total += round_up ((size_t) c->length, 256);
   }
@@ -2136,6 +2298,8 @@ schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int
     f->components[k].data = (char *) base + off;
     off += round_up ((size_t) f->components[k].length, 256);
   }
+  if (pair)
+    f->components[2].data = f->components[1].data;
   return f;
 }
 
@@ -2241,36 +2405,64 @@ schro_hipframe_to_cpu_async (SchroHipFrame * dest, SchroHipFrame * src)
   return copy_frame_async (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
 }
 
+}                               // extern "C"
+
+namespace schro {
 // A copy of a device frame on another context's device (the scheduler moves a reference across two
 // chains with it): same format, size and layout -- plain or upsampled --, one
-// hipMemcpyPeerAsync per component on the destination context's queue, complete on return.
+// hipMemcpyPeerAsync per component on the destination context's host-to-device COPY queue, behind
+// `wait_for` (the owner's event: all the work that writes `src`); `done` is recorded behind the copies
+// and the destination's kernel queues wait for it.  Nothing is waited for on the host (r04).
 SchroHipFrame *
-schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src)
+frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done)
 {
   SchroHipContext *src_ctx = frame_ctx (src);
   if (!dst_ctx || !src_ctx) {
     set_error (SCHRO_HIP_EINVAL, "frame_copy_to: needs a destination context and a device frame");
     return nullptr;
   }
-  SchroHipFrame *dst = schro_hip_frame_new_and_alloc (dst_ctx, src->format, src->width, src->height, src->is_upsampled);
+  SchroHipFrame *dst = schro_hip_frame_new_and_alloc (dst_ctx, src->format, src->width, src->height, src->is_upsampled ? 1 : 0);
   if (!dst)
     return nullptr;
   (void) hipSetDevice (dst_ctx->device);
+  hipStream_t q = dst_ctx->streams[SCHRO_HIP_QUEUE_H2D];
   const int ncomp = (src->format & 0x100) ? 1 : 3;
-  bool ok = true;
+  bool ok = dst->is_upsampled == src->is_upsampled && (!wait_for || hipStreamWaitEvent (q, wait_for, 0) == hipSuccess);
   for (int k = 0; ok && k < ncomp; k++) {
     const SchroHipFrameData *s = &src->components[k];
     SchroHipFrameData *d = &dst->components[k];
     ok = d->length == s->length && d->stride == s->stride
-        && hipMemcpyPeerAsync (d->data, dst_ctx->device, s->data, src_ctx->device, (size_t) s->length, dst_ctx->stream) == hipSuccess;
+        && (s->length == 0        // (the V component of a pair image: components[1] carries it)
+        || hipMemcpyPeerAsync (d->data, dst_ctx->device, s->data, src_ctx->device, (size_t) s->length, q) == hipSuccess);
   }
-  ok = ok && hipStreamSynchronize (dst_ctx->stream) == hipSuccess;
+  if (ok && done) {
+    ok = hipEventRecord (done, q) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+      ok = hipStreamWaitEvent (dst_ctx->streams[k], done, 0) == hipSuccess;
+  }
   if (!ok) {
     set_error (SCHRO_HIP_EDEVICE, "frame_copy_to: peer copy device %d -> %d failed", src_ctx->device, dst_ctx->device);
+    (void) hipStreamSynchronize (q);
     schro_hip_frame_unref (dst);
     return nullptr;
   }
   dst->upsample_done = src->upsample_done;
+  return dst;
+}
+}                               // namespace schro
+
+extern "C" {
+
+// the synchronous form: complete on return
+SchroHipFrame *
+schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src)
+{
+  SchroHipFrame *dst = schro::frame_copy_to_async (dst_ctx, src, nullptr, nullptr);
+  if (dst && hipStreamSynchronize (dst_ctx->streams[SCHRO_HIP_QUEUE_H2D]) != hipSuccess) {
+    set_error (SCHRO_HIP_EDEVICE, "frame_copy_to: the copy queue of device %d failed", dst_ctx->device);
+    schro_hip_frame_unref (dst);
+    return nullptr;
+  }
   return dst;
 }
 
@@ -2289,6 +2481,9 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
   // schro_frame_inverse_iwt_transform_cuda, schrogpuframe.c:584-599)
   SchroHipFrame *staged = nullptr;
   SchroHipFrame *src = transform_frame;
+  SCHRO_HIP_REQUIRE (ctx->stage_complete || frame_ctx (transform_frame),
+      "inverse_iwt_transform: with stage completion off the transform frame must be on the device "
+      "(schro_frame_to_hip_async on the copy queue)");
   if (!frame_ctx (transform_frame)) {
     staged = schro_hip_frame_new_and_alloc (ctx, transform_frame->format, transform_frame->width,
         transform_frame->height, 0);
@@ -2318,8 +2513,7 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
   }
   int r = schro_hip_iiwt_batch (ctx, planes, 3, params->transform_depth,
       params->wavelet_filter_index, bpp);
-  if (!r)
-    r = schro_hip_synchronize (ctx);
+  r = stage_done (ctx, r);
   if (staged)
     schro_hip_frame_unref (staged);
   return r;
@@ -2369,6 +2563,7 @@ schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
   if (dest->upsample_done)      // schroframe.c:2006-2009
     return 0;
   SchroHipUpsamplePlane planes[3];
+  const bool pair = dest->is_upsampled == 2;    // chroma as one pair image
   for (int k = 0; k < 3; k++) {
     SCHRO_HIP_REQUIRE (dest->components[k].width == src->components[k].width
         && dest->components[k].height == src->components[k].height,
@@ -2379,10 +2574,14 @@ schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
     planes[k].dst_stride = dest->components[k].stride;
     planes[k].width = src->components[k].width;
     planes[k].height = src->components[k].height;
+    planes[k].src_v = nullptr;
+    planes[k].src_v_stride = 0;
   }
-  int r = schro_hip_upsample_batch (frame_ctx (dest), planes, 3);
-  if (!r)
-    r = schro_hip_synchronize (frame_ctx (dest));
+  if (pair) {
+    planes[1].src_v = planes[2].src;
+    planes[1].src_v_stride = planes[2].src_stride;
+  }
+  int r = stage_done (frame_ctx (dest), schro_hip_upsample_batch (frame_ctx (dest), planes, pair ? 2 : 3));
   if (!r)
     dest->upsample_done = 1;
   return r;
@@ -2403,8 +2602,10 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
     SchroHipFrame * output_frame)
 {
   (void) dest;                  // the CPU path's s16 scratch frame: the accumulator lives in LDS here
-  SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors && addframe
-      && output_frame && frame_ctx (output_frame) && addframe->domain == output_frame->domain,
+  // addframe NULL: nothing to add -- a zero_residual picture has no frame (schrodecoder.c:1800, :1861,
+  // :1904-1906: the GPU paths take mc_tmp_frame as the combined frame); the prediction alone is clamped
+  SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors
+      && output_frame && frame_ctx (output_frame) && (!addframe || addframe->domain == output_frame->domain),
       "motion_render: bad arguments");
   SCHRO_HIP_REQUIRE (add, "motion_render: only the fused form (add = TRUE, output_frame) is exact on this domain");
   const SchroHipParams *p = motion->params;
@@ -2412,28 +2613,34 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
     return set_error (SCHRO_HIP_EUNSUPPORTED, "motion_render: global motion is not supported");
   SchroHipContext *ctx = frame_ctx (output_frame);
   const int upsampled = p->mv_precision > 0;
-  SCHRO_HIP_REQUIRE (motion->src1->is_upsampled == upsampled
-      && (!motion->src2 || motion->src2->is_upsampled == upsampled),
+  SCHRO_HIP_REQUIRE ((motion->src1->is_upsampled != 0) == upsampled
+      && (!motion->src2 || motion->src2->is_upsampled == motion->src1->is_upsampled),
       "motion_render: references must be %s for mv_precision %d",
       upsampled ? "upsampled frames" : "plain frames", p->mv_precision);
   if (p->num_refs == 1)         // schromotion8.c:711-713
     SCHRO_HIP_REQUIRE (p->picture_weight_2 == 1, "motion_render: one reference needs picture_weight_2 == 1");
 
-  // SchroMotionVector array -> device (schrogpumotion.c:68-120 did a repack; the
-  // kernel reads the 20-byte records as they are)
-  size_t mv_bytes = (size_t) 20 * p->x_num_blocks * p->y_num_blocks;
-  void *d_mvs = schro_hip_domain_alloc (ctx, round_up (mv_bytes, 256));
-  if (!d_mvs)
-    return SCHRO_HIP_ENOMEM;
+  // SchroMotionVector array -> device (schrogpumotion.c:68-120 did a repack; the kernel reads the
+  // 20-byte records as they are).  r04: through the context's pinned table mirrors (push_big_table: one
+  // memcpy into pinned memory + an asynchronous copy on the queue, buffers used in turn) -- no allocation,
+  // no pageable-memory copy and no wait per call; a motion whose vectors are ALREADY on the device (a
+  // host that uploaded them on the copy queue) is used where it is.
   (void) hipSetDevice (ctx->device);
-  hipError_t e = hipMemcpyAsync (d_mvs, motion->motion_vectors, mv_bytes, hipMemcpyHostToDevice,
-      ctx->stream);
-  if (e != hipSuccess) {
-    schro_hip_domain_free (ctx, d_mvs);
-    return set_error (SCHRO_HIP_EDEVICE, "motion_render: MV upload: %s", hipGetErrorString (e));
+  size_t mv_bytes = (size_t) 20 * p->x_num_blocks * p->y_num_blocks;
+  void *d_mvs = nullptr;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes (&attr, motion->motion_vectors) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+      d_mvs = motion->motion_vectors;
+    } else {
+      (void) hipGetLastError ();        // (an ordinary host pointer is "invalid value" to the query)
+      int r = push_big_table (ctx, motion->motion_vectors, mv_bytes, &d_mvs);
+      if (r)
+        return r;
+    }
   }
   SchroHipObmcPlane planes[3];
-  const int res_bpp = format_bpp (addframe->format);
+  const int res_bpp = addframe ? format_bpp (addframe->format) : 2;
   for (int k = 0; k < 3; k++) {
     SchroHipObmcPlane & pl = planes[k];
     memset (&pl, 0, sizeof (pl));
@@ -2457,18 +2664,18 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
       pl.ref2 = (const uint8_t *) motion->src2->components[k].data;
       pl.ref2_stride = motion->src2->components[k].stride;
     }
-    pl.residual = addframe->components[k].data;
-    pl.residual_stride = addframe->components[k].stride;
+    if (addframe) {
+      pl.residual = addframe->components[k].data;
+      pl.residual_stride = addframe->components[k].stride;
+    }
     pl.residual_bpp = res_bpp;
     pl.out = (uint8_t *) output_frame->components[k].data;
     pl.out_stride = output_frame->components[k].stride;
     pl.width = output_frame->components[k].width;
     pl.height = output_frame->components[k].height;
+    pl.ref_pair = k && motion->src1->is_upsampled == 2;
   }
-  int r = schro_hip_obmc_batch (ctx, planes, 3);
-  int r2 = schro_hip_synchronize (ctx);
-  schro_hip_domain_free (ctx, d_mvs);
-  return r ? r : r2;
+  return stage_done (ctx, schro_hip_obmc_batch (ctx, planes, 3));
 }
 
 int
@@ -2499,7 +2706,7 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
     pl.format = dest->format;
     int r = wide ? schro_hip_pack_wide_batch (ctx, &pl, 1, format_bpp (src->format))
         : v210 ? schro_hip_pack_v210_batch (ctx, &pl, 1, format_bpp (src->format)) : schro_hip_pack_u8_batch (ctx, &pl, 1);
-    return r ? r : schro_hip_synchronize (ctx);
+    return stage_done (ctx, r);
   }
   int sb = format_bpp (src->format), db = format_bpp (dest->format);
   if (db == 1 && (sb == 2 || sb == 4)) {
@@ -2512,8 +2719,7 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
       planes[k].width = std::min (dest->components[k].width, src->components[k].width);
       planes[k].height = std::min (dest->components[k].height, src->components[k].height);
     }
-    int r = schro_hip_convert_u8_batch (ctx, planes, 3, sb);
-    return r ? r : schro_hip_synchronize (ctx);
+    return stage_done (ctx, schro_hip_convert_u8_batch (ctx, planes, 3, sb));
   }
   if (db == sb) {
     (void) hipSetDevice (ctx->device);
@@ -2524,7 +2730,7 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
               src->components[k].data, src->components[k].stride, (size_t) w * sb, h,
               hipMemcpyDeviceToDevice, ctx->stream));
     }
-    return schro_hip_synchronize (ctx);
+    return stage_done (ctx, 0);
   }
   return set_error (SCHRO_HIP_EUNSUPPORTED, "hipframe_convert: depth %d -> %d is not on the decode path",
       sb, db);
@@ -2542,8 +2748,7 @@ schro_hipframe_shift_right (SchroHipFrame * frame, int shift)
     planes[k].width = frame->components[k].width;
     planes[k].height = frame->components[k].height;
   }
-  int r = schro_hip_shift_right_batch (frame_ctx (frame), planes, 3, format_bpp (frame->format), shift);
-  return r ? r : schro_hip_synchronize (frame_ctx (frame));
+  return stage_done (frame_ctx (frame), schro_hip_shift_right_batch (frame_ctx (frame), planes, 3, format_bpp (frame->format), shift));
 }
 
 }                               // extern "C"

@@ -98,7 +98,6 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
 #define SCHRO_UP_TH 16
 #endif
 constexpr int kUpTW = 128, kUpTH = SCHRO_UP_TH;
-constexpr int kUpDW = kUpTW / 4 + 2;    // LDS dwords per row: pixels x0-4 .. x0+TW+3
 
 typedef short short2v __attribute__ ((ext_vector_type (2)));
 
@@ -150,37 +149,42 @@ mas8_row4 (uint32_t d0, uint32_t d1, uint32_t d2, int *out)
   out[3] = mas8_bytes (d1, d2);
 }
 
-__global__ __launch_bounds__ (kThreads)
-void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
-{
-  // LDS rows: dword i holds pixels x0 - 16 + 4 i .. + 3, so that 16-byte source chunks land
-  // aligned; the filters use dwords 3 .. 36 (pixels x0 - 4 .. x0 + TW + 3)
-  constexpr int kUpLD = kUpTW / 4 + 8, kUpCh = kUpLD / 4;
-  __shared__ __attribute__ ((aligned (16))) uint32_t s0[kUpTH + 7][kUpLD];     // integer pels, rows y0-3 .. y0+TH+3
-  __shared__ __attribute__ ((aligned (16))) uint32_t s2[kUpTH][kUpLD];         // v-half
+// PAIR: the workgroup's tile is 64 x kUpTH pixels of BOTH planes of a (U, V) pair, staged side by side
+// in the LDS rows (U's half row, then V's), filtered as two independent pictures and stored
+// byte-interleaved (schro_hip_internal.h: pair images).  Everything else is the one-plane kernel.
+constexpr int kUpMaxLD = 2 * (kUpTW / 8 + 8);   // LDS dwords per row of the pair form (48; one plane: 40)
 
-  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
-  const int t = bid - job.tile_base;
+template < bool PAIR >
+__device__ __forceinline__ void
+upsample_body (const UpsampleJob & job, int t, uint32_t (*s0)[kUpMaxLD], uint32_t (*s2)[kUpMaxLD])
+{
+  // LDS rows, per plane: dword i holds pixels x0 - 16 + 4 i .. + 3, so that 16-byte source chunks
+  // land aligned; the filters use dwords 3 .. kTWp / 4 + 4 (pixels x0 - 4 .. x0 + kTWp + 3)
+  constexpr int kTWp = PAIR ? kUpTW / 2 : kUpTW;        // tile width in pixels of a plane
+  constexpr int kHalfLD = kTWp / 4 + 8;                 // LDS dwords per plane and row
+  constexpr int kUpCh = (PAIR ? 2 : 1) * kHalfLD / 4, kHalfCh = kHalfLD / 4;
+  constexpr int kHalfDW = kTWp / 4 + 2, kVDW = (PAIR ? 2 : 1) * kHalfDW;
+  constexpr int ps = PAIR ? 1 : 0;
+  static_assert ((PAIR ? 2 : 1) * kHalfLD <= kUpMaxLD, "LDS row");
+
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
-  const int x0 = tx * kUpTW, y0 = ty * kUpTH;
+  const int x0 = tx * kTWp, y0 = ty * kUpTH;
   const int w = job.w, h = job.h;
   const int tid = threadIdx.x;
-  const bool src_al = ((((uintptr_t) job.src) | job.src_stride) & 15) == 0;
 
-  // one 16-byte chunk per lane (230 of them): picture coordinates clamped on the way in
+  // one 16-byte chunk per lane: picture coordinates clamped on the way in
   for (int it = tid; it < (kUpTH + 7) * kUpCh; it += kThreads) {
     const int ly = it / kUpCh, c = it - ly * kUpCh;
+    const int half = PAIR ? c / kHalfCh : 0, cc = c - half * kHalfCh;
+    const uint8_t *src = half ? job.src_b : job.src;
+    const int sstride = half ? job.src_b_stride : job.src_stride;
+    const bool src_al = ((((uintptr_t) src) | (uintptr_t) sstride) & 15) == 0;
     const int gy = clampi (y0 - 3 + ly, 0, h - 1);
-    const int gx = x0 - 16 + 16 * c;
-    const uint8_t *row = job.src + (size_t) gy * job.src_stride;
+    const int gx = x0 - 16 + 16 * cc;
+    const uint8_t *row = src + (size_t) gy * sstride;
     u32x4 q;
     if (src_al && gx >= 0 && gx + 16 <= w) {
-#ifdef SCHRO_UP_NT_SRC            // (scratch builds: the reference picture as streaming loads)
-      q = __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x4 *) (row + gx));
-#else
       q = gload < u32x4 > (row + gx);
-#endif
     } else {
       uint32_t d[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
@@ -192,8 +196,9 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   }
   __syncthreads ();
 
-  for (int it = tid; it < kUpTH * kUpDW; it += kThreads) {
-    const int g = it % kUpDW + 3, ly = it / kUpDW;
+  for (int it = tid; it < kUpTH * kVDW; it += kThreads) {
+    const int gi = it % kVDW, ly = it / kVDW;
+    const int half = PAIR ? gi / kHalfDW : 0, g = half * kHalfLD + (gi - half * kHalfDW) + 3;
     uint32_t out;
     if (y0 + ly >= h - 1) {
       out = s0[ly + 3][g];      // last row of the v-half is a copy (schroframe.c:1642-1644)
@@ -213,19 +218,22 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   __syncthreads ();
 
   // Phase 3: horizontal half-pel samples, store.  One lane = 8 pixels of one row of all four
-  // planes; adjacent lanes = adjacent 8-pixel groups of the same row, a wave = 4 rows x 128 pixels
-  // = whole 128-byte lines of the tiled planes (schro_hip_internal.h: 32-byte chunks advancing by
-  // 16 columns, 4 rows per line).  A lane pair swaps its 8 bytes (DPP) so that both hold the pair's
-  // 16 pixels: the even lane stores them as the first half of their own chunk, the odd lane as the
-  // second half of the chunk before.
+  // planes; a row of 16 lanes = the 128 pixels of a tile row (PAIR: 64 pixels of U, then the same 64
+  // of V), a wave = 4 rows = whole 128-byte lines of the tiled planes (schro_hip_internal.h: 32-byte
+  // chunks advancing by 16 byte columns, 4 rows per line).  One plane: a lane pair swaps its 8 bytes
+  // (DPP) so that both hold the pair's 16 pixels; the even lane stores them as the first half of
+  // their own chunk, the odd lane as the second half of the chunk before.  PAIR: the U lane and the V
+  // lane of the same 8 pixels (8 lanes apart) swap theirs, both interleave the 16 bytes; the U lane
+  // stores the first home, the V lane the second.
   static_assert ((kUpTW / 8) * kUpTH % kThreads == 0 && kUpTW / 8 == 16 && kUpTH % kHpBandRows == 0,
       "a lane per 8 pixels of 16 rows of the tile at a time");
   const int stride = job.dst_stride;
 #pragma unroll 1
   for (int part = 0; part < (kUpTW / 8) * kUpTH / kThreads; part++) {
   const int ly = (tid >> 4) + part * (kThreads / 16), g8 = tid & 15;
-  const int gx = x0 + 8 * g8, gy = y0 + ly;
-  const int gd = 2 * g8 + 3;            // LDS dword of the 4 pixels left of this lane's
+  const int half = PAIR ? g8 >> 3 : 0, gg = PAIR ? g8 & 7 : g8;
+  const int gx = x0 + 8 * gg, gy = y0 + ly;
+  const int gd = half * kHalfLD + 2 * gg + 3;   // LDS dword of the 4 pixels left of this lane's
   uint32_t pl[4][2];                    // planes 0..3 (integer, h-half, v-half, hv-half), 2 dwords each
   {
     const uint32_t a0 = s0[ly + 3][gd], a1 = s0[ly + 3][gd + 1], a2 = s0[ly + 3][gd + 2], a3 = s0[ly + 3][gd + 3];
@@ -241,34 +249,61 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     pl[2][0] = b1;
     pl[2][1] = b2;
     // the tile holds the picture's last column or row (a whole-workgroup branch): copies there
-    const bool edge_tile = x0 + kUpTW >= w || y0 + kUpTH >= h;
+    const bool edge_tile = x0 + kTWp >= w || y0 + kUpTH >= h;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
+    for (int hf = 0; hf < 2; hf++) {
       if (edge_tile) {
-        pl[1][half] = pl[3][half] = 0;
+        pl[1][hf] = pl[3][hf] = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           // last column: copy (mas8_u8_edgeextend d[n-1] = s[n-1]; for n <= 8 the following
           // schro_frame_mc_edgeextend_horiz overwrites it the same way)
-          const bool lastcol = gx + 4 * half + e >= w - 1;
-          int v1 = lastcol ? (int) ((pl[0][half] >> (8 * e)) & 0xff) : p1[4 * half + e];
-          int v3 = lastcol ? (int) ((pl[2][half] >> (8 * e)) & 0xff) : p3[4 * half + e];
+          const bool lastcol = gx + 4 * hf + e >= w - 1;
+          int v1 = lastcol ? (int) ((pl[0][hf] >> (8 * e)) & 0xff) : p1[4 * hf + e];
+          int v3 = lastcol ? (int) ((pl[2][hf] >> (8 * e)) & 0xff) : p3[4 * hf + e];
           if (gy >= h - 1)
             v3 = v1;            // last row of the hv-half comes from the h-half (schroframe.c:2028)
-          pl[1][half] |= (uint32_t) v1 << (8 * e);
-          pl[3][half] |= (uint32_t) v3 << (8 * e);
+          pl[1][hf] |= (uint32_t) v1 << (8 * e);
+          pl[3][hf] |= (uint32_t) v3 << (8 * e);
         }
       } else {
-        pl[1][half] = (uint32_t) p1[4 * half] | ((uint32_t) p1[4 * half + 1] << 8) | ((uint32_t) p1[4 * half + 2] << 16)
-            | ((uint32_t) p1[4 * half + 3] << 24);
-        pl[3][half] = (uint32_t) p3[4 * half] | ((uint32_t) p3[4 * half + 1] << 8) | ((uint32_t) p3[4 * half + 2] << 16)
-            | ((uint32_t) p3[4 * half + 3] << 24);
+        pl[1][hf] = (uint32_t) p1[4 * hf] | ((uint32_t) p1[4 * hf + 1] << 8) | ((uint32_t) p1[4 * hf + 2] << 16)
+            | ((uint32_t) p1[4 * hf + 3] << 24);
+        pl[3][hf] = (uint32_t) p3[4 * hf] | ((uint32_t) p3[4 * hf + 1] << 8) | ((uint32_t) p3[4 * hf + 2] << 16)
+            | ((uint32_t) p3[4 * hf + 3] << 24);
       }
     }
   }
+  uint8_t *row = job.dst + hp_row_offset (min (gy, h - 1), stride);
+  if constexpr (PAIR) {
+    // the 8 pixels of both components start at byte column xb (a multiple of 16)
+    const int xb = 2 * (gx + kHpApron);
+    const bool group_in = gx + 8 <= w;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      // the other component's dwords: row_ror:8 (the lane 8 on / back inside the row of 16)
+      const uint32_t n0 = (uint32_t) __builtin_amdgcn_mov_dpp ((int) pl[p][0], 0x128, 0xf, 0xf, true);
+      const uint32_t n1 = (uint32_t) __builtin_amdgcn_mov_dpp ((int) pl[p][1], 0x128, 0xf, 0xf, true);
+      if (group_in && gy < h) {
+        const uint32_t u0 = half ? n0 : pl[p][0], u1 = half ? n1 : pl[p][1];
+        const uint32_t v0 = half ? pl[p][0] : n0, v1 = half ? pl[p][1] : n1;
+        const u32x4 v = (u32x4) { __builtin_amdgcn_perm (v0, u0, 0x05010400u), __builtin_amdgcn_perm (v0, u0, 0x07030602u),
+          __builtin_amdgcn_perm (v1, u1, 0x05010400u), __builtin_amdgcn_perm (v1, u1, 0x07030602u) };
+        // U lane: bytes 0..15 of chunk xb >> 4; V lane: bytes 16..31 of the chunk before
+        gstore < u32x4 > (row + (size_t) ((xb >> 4) - half) * 512 + (size_t) (p * 128 + 16 * half), v);
+      } else if (gy < h) {
+        // ragged right edge: this lane's component byte by byte, both homes of every byte column
+        for (int e = 0; e < 8 && gx + e < w; e++) {
+          const uint8_t v = (uint8_t) (pl[p][e >> 2] >> (8 * (e & 3)));
+          const int xbe = xb + 2 * e + half;
+          gstore < uint8_t > (row + hp_col_offset (xbe) + p * 128, v);
+          gstore < uint8_t > (row + hp_col_offset (xbe - 16) + p * 128 + 16, v);
+        }
+      }
+    }
+  } else {
   // the pair's 16 pixels start at padded column xp16 (a multiple of 16)
   const int odd = g8 & 1, xp16 = gx - 8 * odd + kHpApron;
-  uint8_t *row = job.dst + hp_row_offset (min (gy, h - 1), stride);
   // whole pair inside the picture (a whole-wave property except in the tile on the right edge)
   const bool pair_in = gx - 8 * odd + 16 <= w;
 #pragma unroll
@@ -291,45 +326,69 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
     }
   }
   }
+  }
   // Aprons (tiles on the left / right edge of the picture): kHpApron columns in front of column 0
   // and everything behind column w - 1 to the end of the row's last chunk repeat the edge sample --
   // of plane 0 in planes 0 and 1, of plane 2 in planes 2 and 3 (schro_frame_mc_edgeextend_horiz's
   // sources in schro_upsampled_frame_upsample, schroframe.c:2012-2029) = the half-pel column
-  // clamped to [0, 2w - 2].  LDS dword i of a row holds pixels x0 - 16 + 4 i ..
+  // clamped to [0, 2w - 2].  LDS dword i of a plane's half row holds pixels x0 - 16 + 4 i ..
+  // The edge sample as a dword of byte columns: one plane e e e e, a pair u v u v.
+  auto edge_dword = [&](int p, int r, int pos) {
+    const uint32_t u = ((p < 2 ? s0[r + 3][pos >> 2] : s2[r][pos >> 2]) >> (8 * (pos & 3))) & 0xffu;
+    if constexpr (!PAIR) {
+      return u * 0x01010101u;
+    } else {
+      const uint32_t v = ((p < 2 ? s0[r + 3][kHalfLD + (pos >> 2)] : s2[r][kHalfLD + (pos >> 2)]) >> (8 * (pos & 3))) & 0xffu;
+      return (u | (v << 8)) * 0x00010001u;
+    }
+  };
   if (x0 == 0) {
-    // columns 0..31 padded: chunk 0 whole, chunk 1's first half; three 16-byte pieces per (row, plane)
-    for (int it = tid; it < kUpTH * 4 * 3; it += kThreads) {
-      const int piece = it % 3, p = (it / 3) & 3, r = it / 12;
+    // byte columns 0 .. (kHpApron << ps) - 1: whole chunks and the first half of the chunk behind them, 16-byte pieces
+    constexpr int kPieces = 2 * ((kHpApron << ps) / 16) - 1;
+    for (int it = tid; it < kUpTH * 4 * kPieces; it += kThreads) {
+      const int piece = it % kPieces, p = (it / kPieces) & 3, r = it / (4 * kPieces);
       if (y0 + r >= h)
         continue;
-      const uint32_t e = ((p < 2 ? s0[r + 3][4] : s2[r][4]) & 0xffu) * 0x01010101u;
-      uint8_t *d = job.dst + hp_row_offset (y0 + r, stride) + (size_t) (piece == 2 ? 512 : 16 * piece) + p * 128;
+      const uint32_t e = edge_dword (p, r, 16);
+      uint8_t *d = job.dst + hp_row_offset (y0 + r, stride) + (size_t) ((piece >> 1) * 512 + 16 * (piece & 1)) + p * 128;
       gstore < u32x4 > (d, (u32x4) { e, e, e, e });
     }
   }
-  if (x0 + kUpTW >= w) {
-    // padded columns w + 32 .. end: every chunk that holds one of them, byte by byte at the boundary
-    const int nch = stride >> 9, first = w + kHpApron, c_lo = max (0, (first >> 4) - 1);
+  if (x0 + kTWp >= w) {
+    // byte columns behind the last sample .. end: every chunk that holds one of them, byte by byte at the boundary
+    const int nch = stride >> 9, first = (w + kHpApron) << ps, c_lo = max (0, (first >> 4) - 1);
     const int ndw = (nch - c_lo) * 8;   // dwords per (row, plane)
-    const int xl = w - 1 - (x0 - 16);   // position of the last column in the LDS row
+    const int xl = w - 1 - (x0 - 16);   // position of the last column in the plane's LDS half row
     for (int it = tid; it < kUpTH * 4 * ndw; it += kThreads) {
       const int dwi = it % ndw, p = (it / ndw) & 3, r = it / (4 * ndw);
       if (y0 + r >= h)
         continue;
-      const int c = c_lo + (dwi >> 3), o = (dwi & 7) * 4, col = 16 * c + o;     // padded column of the dword's first byte
+      const int c = c_lo + (dwi >> 3), o = (dwi & 7) * 4, col = 16 * c + o;     // byte column of the dword's first byte
       if (col + 3 < first)
         continue;
-      const uint32_t src = p < 2 ? s0[r + 3][xl >> 2] : s2[r][xl >> 2];
-      const uint32_t e = ((src >> (8 * (xl & 3))) & 0xffu) * 0x01010101u;
+      const uint32_t e = edge_dword (p, r, xl);
       uint8_t *d = job.dst + hp_row_offset (y0 + r, stride) + (size_t) c * 512 + p * 128 + o;
       if (col >= first) {
         gstore < uint32_t > (d, e);
       } else {
         for (int k = first - col; k < 4; k++)
-          gstore < uint8_t > (d + k, (uint8_t) e);
+          gstore < uint8_t > (d + k, (uint8_t) (e >> (8 * k)));
       }
     }
   }
+}
+
+__global__ __launch_bounds__ (kThreads)
+void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
+{
+  __shared__ __attribute__ ((aligned (16))) uint32_t s0[kUpTH + 7][kUpMaxLD];  // integer pels, rows y0-3 .. y0+TH+3
+  __shared__ __attribute__ ((aligned (16))) uint32_t s2[kUpTH][kUpMaxLD];      // v-half
+  const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
+  const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
+  if (job.src_b)                // (uniform over the workgroup)
+    upsample_body < true > (job, bid - job.tile_base, s0, s2);
+  else
+    upsample_body < false > (job, bid - job.tile_base, s0, s2);
 }
 
 // ---- packed copy-out -----------------------------------------------------------

@@ -141,7 +141,7 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
           int fy = clampi (by * (1 << prec) + dy, -expx, max_fast_y + expx - 1);
           int sx = fx + (px - bx) * (1 << prec);
           int sy = fy + (py - by) * (1 << prec);
-          val[r] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h, sx, sy, prec);
+          val[r] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h, sx, sy, prec, job.ref_ps, job.ref_cb);
         }
         if (mode == 3) {
           if constexpr (SIMPLE) {
@@ -187,7 +187,9 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
   int16_t t1 = (int16_t) ((int16_t) acc + 32);
   t1 = (int16_t) (t1 >> 6);
   int16_t res;
-  if (job.res_bpp == 2)
+  if (!job.residual)            // no residual to add (a zero_residual picture, schrodecoder.c:1904-1906)
+    res = 0;
+  else if (job.res_bpp == 2)
     res = gload < int16_t > ((const int16_t *) ((const char *) job.residual
             + (size_t) py * job.residual_stride) + px);
   else
@@ -314,8 +316,8 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
 #pragma unroll
         for (int j = 0; j < 9; j++) {
           const int X = clampi (hx + j, 0, 2 * job.w - 2);
-          p[0][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y0, job.ref_stride[r]));
-          p[1][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y1, job.ref_stride[r]));
+          p[0][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y0, job.ref_stride[r], job.ref_ps, job.ref_cb));
+          p[1][j] = gload < uint8_t > (job.ref[r] + hp_offset (X, Y1, job.ref_stride[r], job.ref_ps, job.ref_cb));
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -326,7 +328,7 @@ obmc_item_slow (const ObmcJob & job, const BlkInfo & bi, int row, int seg, const
       } else {
         for (int e = 0; e < 4; e++)
           val[r][e] = fetch_ref < PC > (job.ref[r], job.ref_stride[r], job.w, job.h,
-              bi.fx[r] + (4 * seg + e) * (1 << prec), bi.fy[r] + row * (1 << prec), prec);
+              bi.fx[r] + (4 * seg + e) * (1 << prec), bi.fy[r] + row * (1 << prec), prec, job.ref_ps, job.ref_cb);
       }
     }
     for (int e = 0; e < 4; e++)
@@ -380,7 +382,8 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
         if (y >= y_hi)
           continue;
         const uint32_t sel = half ? 0x07060302u : 0x05040100u;
-        const u32x4 r = gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * x);
+        const u32x4 r = job.residual ? gload < u32x4 > ((const char *) job.residual + (size_t) y * job.residual_stride + 2 * x)
+            : (u32x4) { 0u, 0u, 0u, 0u };
         const uint32_t av[4] = {
           __builtin_amdgcn_perm ((uint32_t) a0.y, (uint32_t) a0.x, sel),
           __builtin_amdgcn_perm ((uint32_t) a0.w, (uint32_t) a0.z, sel),
@@ -417,7 +420,9 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
     uint8_t *orow = job.out + (size_t) y * job.out_stride + x;
     __attribute__ ((aligned (8))) int16_t res[4];
     const bool full = x + 4 <= job.w;
-    if (job.res_bpp == 2) {
+    if (!job.residual) {
+      res[0] = res[1] = res[2] = res[3] = 0;
+    } else if (job.res_bpp == 2) {
       const int16_t *rp = (const int16_t *) rrow + x;
       if (full && (((uintptr_t) rp) & 7) == 0) {
         *reinterpret_cast < u32x2 * >(res) = gload < u32x2 > (rp);
@@ -498,10 +503,22 @@ hp_predict4 (const ObmcJob & job, int r, int off_r, int ya, int row, int seg, ui
 {
   static_assert (PC >= 1, "plain references are linear");
   const int stride = job.ref_stride[r];
-  const int xp = (off_r & 0xffff) + 4 * seg, px = (off_r >> 16) & 1, py = (off_r >> 17) & 1;
+  // pair images (ref_ps 1): a sample is two bytes, this component byte ref_cb of it -- the segment is
+  // eight contiguous bytes (still inside its chunk: it starts at an even byte <= 14 and the X + 1 tap
+  // two bytes on), of which every second one is taken
+  const int ps = job.ref_ps;
+  const int xp = ((off_r & 0xffff) + 4 * seg) << ps, px = (off_r >> 16) & 1, py = (off_r >> 17) & 1;
   const int y = ya + row;
+  const uint32_t pick = job.ref_cb ? 0x07050301u : 0x06040200u;
+  auto load4 = [&](const uint8_t * p) {
+    if (ps) {
+      const u32x2 q = gload < u32x2_u > (p);
+      return __builtin_amdgcn_perm (q.y, q.x, pick);
+    }
+    return gload < u32_u > (p);
+  };
   const uint8_t *a = job.ref[r] + hp_row_offset (y, stride) + hp_col_offset (xp) + (px + 2 * py) * 128;
-  const uint32_t A = gload < u32_u > (a);
+  const uint32_t A = load4 (a);
   if constexpr (PC == 1) {
     val[0] = A & 0xff;
     val[1] = (A >> 8) & 0xff;
@@ -509,11 +526,11 @@ hp_predict4 (const ObmcJob & job, int r, int off_r, int ya, int row, int seg, ui
     val[3] = A >> 24;
     (void) wpk;
   } else {
-    // X + 1: the other column parity, one column on when X is odd (that column is in the same
+    // X + 1: the other column parity, one sample on when X is odd (that sample is in the same
     // chunk: chunks hold 32 bytes and advance by 16); Y + 1: the other row parity, one row on when Y is odd
-    const int dB = px ? 1 - 128 : 128;
+    const int dB = px ? (1 << ps) - 128 : 128;
     const uint8_t *c = job.ref[r] + hp_row_offset (y + py, stride) + hp_col_offset (xp) + (px + 2 * (py ^ 1)) * 128;
-    const uint32_t B = gload < u32_u > (a + dB), C = gload < u32_u > (c), D = gload < u32_u > (c + dB);
+    const uint32_t B = load4 (a + dB), C = load4 (c), D = load4 (c + dB);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const uint32_t sel = 0x0c0c0000u | (uint32_t) e | ((uint32_t) (4 + e) << 8);
@@ -873,9 +890,7 @@ obmc_item_geometry (ObmcJob * j)
   const int nseg = (j->xblen + 3) >> 2;
   const int lpi = nseg;         // an item's lanes: one per 4-pixel segment
   j->nseg = nseg;
-  j->nch = 0;
   j->lpi = lpi;
-  j->item_bytes = 0;
   j->ipw = 64 / lpi;            // items per wave pass
   j->chunk_cap = std::min (kItemBlkCap, kItemCap / std::min (j->yblen, kFTH));
   j->m_tiles_x = div_magic (j->tiles_x);
@@ -889,12 +904,14 @@ obmc_item_geometry (ObmcJob * j)
 
 // variant 0: per-pixel kernel (any weights), 64x4 tiles
 // variant 1: LDS-accumulate item kernel (default weights), 128x32 tiles
+// variant 3 / 4: row kernels (obmc_row.hip): 128x32; (U, V) pairs from pair images 64x32
 void
 obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 {
   (void) xoff;
   if (variant >= 1) {
-    *tiles_x = (w + kFTW - 1) / kFTW;
+    const int tw = variant >= 3 ? obmc_row_tile_width (variant == 4) : kFTW;
+    *tiles_x = (w + tw - 1) / tw;
     *tiles_y = (h + kFTH - 1) / kFTH;
   } else {
     *tiles_x = (w + kTW - 1) / kTW;

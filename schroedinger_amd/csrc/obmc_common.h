@@ -40,23 +40,24 @@ obmc_weight_1d (int i, int blen, int offset)
 // PC 0: plain plane.  PC 1: half-pel image (tiled).  PC 2: 1/4- or 1/8-pel bilinear
 // of four half-pel samples (orc_combine4_nxm_u8, schroorc.orc:1635-1662; the
 // avg2 / copy special cases of schroframe.c:2306-2350 are the same formula).
+// ps / cb: the sample's width shift and the component's byte in it (pair images, schro_hip_internal.h)
 template < int PC >
 __device__ __forceinline__ int
-fetch_ref (const uint8_t * __restrict__ ref, int stride, int w, int h, int sx, int sy, int prec)
+fetch_ref (const uint8_t * __restrict__ ref, int stride, int w, int h, int sx, int sy, int prec, int ps, int cb)
 {
   if constexpr (PC == 0) {
     int X = clampi (sx, 0, w - 1), Y = clampi (sy, 0, h - 1);
     return gload < uint8_t > (ref + (size_t) Y * stride + X);
   } else if constexpr (PC == 1) {
     int X = clampi (sx, 0, 2 * w - 2), Y = clampi (sy, 0, 2 * h - 2);
-    return gload < uint8_t > (ref + hp_offset (X, Y, stride));
+    return gload < uint8_t > (ref + hp_offset (X, Y, stride, ps, cb));
   } else {
     int x8 = prec == 2 ? sx * 2 : sx, y8 = prec == 2 ? sy * 2 : sy;
     int hx = x8 >> 2, hy = y8 >> 2, rx = x8 & 3, ry = y8 & 3;
     int X0 = clampi (hx, 0, 2 * w - 2), X1 = clampi (hx + 1, 0, 2 * w - 2);
     int Y0 = clampi (hy, 0, 2 * h - 2), Y1 = clampi (hy + 1, 0, 2 * h - 2);
-    int p00 = gload < uint8_t > (ref + hp_offset (X0, Y0, stride)), p01 = gload < uint8_t > (ref + hp_offset (X1, Y0, stride));
-    int p10 = gload < uint8_t > (ref + hp_offset (X0, Y1, stride)), p11 = gload < uint8_t > (ref + hp_offset (X1, Y1, stride));
+    int p00 = gload < uint8_t > (ref + hp_offset (X0, Y0, stride, ps, cb)), p01 = gload < uint8_t > (ref + hp_offset (X1, Y0, stride, ps, cb));
+    int p10 = gload < uint8_t > (ref + hp_offset (X0, Y1, stride, ps, cb)), p11 = gload < uint8_t > (ref + hp_offset (X1, Y1, stride, ps, cb));
     int v = (4 - ry) * ((4 - rx) * p00 + rx * p01) + ry * ((4 - rx) * p10 + rx * p11);
     return (v + 8) >> 4;
   }

@@ -40,26 +40,32 @@ namespace schro {
 namespace {
 
 constexpr int kRThreads = 256;
-constexpr int kRTW = 128, kRTH = 32;    // output tile: obmc_tiles (variant >= 1); the kernels take the height as TH
-constexpr int kRMargin = 16;            // accumulator pixels in front of the tile (+ 1 when block origins are odd)
-// accumulator row, 32-bit words of two pixels: 17 + 128 + 16 pixels = 81 words.  An ODD pitch: the lanes of
-// a pass are rows of blocks whose origins are multiples of 4 words apart, so with the r02 pitch of 84
-// every address of an accumulate had the same word index mod 4 and 64 lanes met in 8 of the 32 banks
-// (7.2 extra cycles per ds_add, simulated; 2.3 with 85)
-constexpr int kRAccW = 85;
-// rows of 8 pixels and shorter (ND <= 2: the chroma planes, the 8/4 block set): a block starts at most
-// 7 pixels in front of the tile -- margin 8, 9 + 128 + 8 pixels = 73 words (odd again).  With the
-// 32-byte block records that is 27.1 KB of LDS for the 6-pixel-row kernels: six workgroups per CU
-// instead of five.
-template < int ND > constexpr int kRMarginOf = ND <= 2 ? 8 : kRMargin;
-template < int ND > constexpr int kRAccWOf = ND <= 2 ? 73 : kRAccW;
-// blocks whose footprint meets a tile and their (block, row) items: by row length (8-pixel rows
-// and shorter are the small, many blocks of chroma planes and of the 8/4 block set)
-template < int ND > struct RowCaps {
-  static constexpr int kBlk = ND <= 2 ? 344 : 128, kItem = ND <= 2 ? 1792 : 1024;
+constexpr int kRTH = 32;                // output tile height: obmc_tiles (variant >= 1); the kernels take it as TH
+// What depends on the row length (ND dwords of prediction per block row) and on the form of the job:
+//   UV = false: one plane (or the U and the V plane one after the other, NP == 2); a prediction byte is a pixel,
+//     an accumulator word holds two pixels; the tile is 128 pixels wide;
+//   UV = true (r04): the U and V planes of a picture from PAIR images (schro_hip_internal.h): a prediction byte
+//     pair is the (U, V) sample of one pixel, an accumulator word holds that pixel's two sums (U low, V high);
+//     the tile is 64 pixels wide -- the same 128 byte columns, the same pass body.
+template < int ND, bool UV > struct RowGeo {
+  static constexpr int kTW = UV ? 64 : 128;
+  // accumulator pixels in front of the tile (+ 1 when block origins are odd): a block starts at most
+  // xblen - 1 pixels in front of it.  Rows of 8 pixels and shorter (ND <= 2: 8/4 block sets, chroma planes on
+  // their own; UV: at most 8 pixels = 16 bytes): 8, else 16.
+  static constexpr int kMargin = (UV || ND <= 2) ? 8 : 16;
+  // accumulator row in 32-bit words: (17 + 128 + 16) / 2 -> 81, (9 + 128 + 8) / 2 -> 73, UV 8 + 64 + 8 = 80 --
+  // made ODD: the lanes of a pass are rows of blocks whose origins are multiples of 4 words apart, so with
+  // the r02 pitch of 84 every address of an accumulate had the same word index mod 4 and 64 lanes met in 8
+  // of the 32 banks (7.2 extra cycles per ds_add, simulated; 2.3 with 85)
+  static constexpr int kAccW = UV ? 81 : (ND <= 2 ? 73 : 85);
+  // blocks whose footprint meets a tile and their (block, row) items (8-pixel rows and shorter are the
+  // small, many blocks of chroma planes and of the 8/4 block set; a 64-pixel UV tile of 6 x 6 blocks
+  // every 4 pixels meets 18 x 10 of them)
+  static constexpr int kBlk = ND <= 2 ? 344 : (UV ? 192 : 128), kItem = ND <= 2 ? 1792 : (UV ? 1152 : 1024);
+  // (row, pixel pair | UV: pixel) weight words: 2 * ND per row (zero beyond the block), 32 rows
+  static constexpr int kWCap = 32 * 2 * ND;
+  static constexpr bool kPadBlk = UV || ND > 2;        // block records of nine words (see RowBlkT)
 };
-// (row, pixel pair) weight words: 2 * ND per row (zero beyond the block), 32 rows
-template < int ND > constexpr int kRWCapOf = 32 * 2 * ND;
 // Item classes (one straight-line pass body each): both references / the first / the second / DC /
 // edge (windows clamped vertically and / or folded weights, any mode: still a row per lane) / rim (DC
 // values outside 8 bits, geometries beyond the weight table: per sample).  Inside the reference
@@ -87,30 +93,40 @@ struct __attribute__ ((aligned (4))) RowRef {
   int dci;                      // dC << 16 | inc: the Y + 1 taps are dC bytes and inc plane rows on (+256, 0 | -256, 1 | 0, 0)
 };
 
-struct __attribute__ ((aligned (8))) RowBlk {
+// 36 bytes: a pitch of NINE words.  The lanes of a pass read the records of the 5 - 11 blocks their items
+// belong to; with r03's 32-byte records (eight words) blocks four apart shared their banks
+// (SQ_LDS_BANK_CONFLICT 11.9 M -> 20.1 M cycles per 8 x 2160p step against the 40-byte records before);
+// an odd pitch maps 32 consecutive blocks to 32 different banks.
+// (The 6-pixel-row kernels of chroma planes on their own keep 32 bytes: 344 records, and the 1.4 KB more
+// would cost them the sixth workgroup per CU.)
+template < bool PAD > struct alignas (PAD ? 4 : 8) RowBlkT {
   int16_t y, x;                 // block origin relative to the tile
   uint32_t fr;                  // first block row inside the tile | rows inside << 8 | flags << 16:
                                 // flag bits 0-1 mode, 2-5 weights fold at top | bottom | left | right,
                                 // 6 + r: reference r's window at a vertical quarter position (edge class)
   RowRef r[2];                  // mode 0 (no reference used): r[0].base = the DC values of the job's planes,
                                 // 16 bits each (first plane low)
+  uint32_t pad[PAD ? 1 : 0];
 };
-static_assert (sizeof (RowBlk) == 32, "block records: 128 (luma) / 352 (chroma) of them beside the accumulator");
+static_assert (sizeof (RowBlkT < true >) == 36 && sizeof (RowBlkT < false >) == 32, "block records: an odd number of words / r03's");
 
+template < typename B >
 __device__ __forceinline__ uint32_t
-blk_flags (const RowBlk & hb)
+blk_flags (const B & hb)
 {
   return hb.fr >> 16;
 }
 
+template < typename B >
 __device__ __forceinline__ uint32_t
-blk_ry (const RowBlk & hb, int r)
+blk_ry (const B & hb, int r)
 {
   return (hb.fr >> (16 + 6 + r)) & 1u;
 }
 
+template < typename B >
 __device__ __forceinline__ int
-blk_dc (const RowBlk & hb, int pl)
+blk_dc (const B & hb, int pl)
 {
   return pl ? hb.r[0].base >> 16 : (int) (int16_t) hb.r[0].base;
 }
@@ -164,14 +180,20 @@ acc_add_exact (uint32_t * word, int high, uint32_t value)
   } while (old != assumed);
 }
 
-// the accumulator word and half of tile-relative pixel (x, y); `par` = 1 when block origins are odd
-template < int ND >
+// the accumulator word and half of tile-relative pixel (x, y); `par` = 1 when block origins are odd.
+// UV: the pixel's word; its halves are the two components
+template < typename G, bool UV >
 __device__ __forceinline__ uint32_t *
 acc_word (uint32_t * acc, int par, int x, int y, int *half)
 {
-  const int idx = x + kRMarginOf < ND > + par;
-  *half = idx & 1;
-  return acc + y * kRAccWOf < ND > + (idx >> 1);
+  if constexpr (UV) {
+    *half = 0;
+    return acc + y * G::kAccW + (x + G::kMargin);
+  } else {
+    const int idx = x + G::kMargin + par;
+    *half = idx & 1;
+    return acc + y * G::kAccW + (idx >> 1);
+  }
 }
 
 // ---- one reference's prediction of a block row: ND dwords of 4 pixels ---------------------
@@ -191,11 +213,6 @@ issue_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, RawRun < ND > &r)
 {
   const uint32_t al = off & ~3u;
   r.sh = off & 3u;
-#ifdef SCHRO_ROW_DBG_NOLOAD     // (scratch builds: what the passes cost without their memory traffic)
-  for (int k = 0; k <= ND; k++)
-    r.c[k] = al + k;
-  return;
-#endif
   if constexpr (ND == 2) {
     typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
     const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) al, 0, 0);
@@ -256,12 +273,8 @@ predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, c
   } else {
     const uint32_t y = (rr.ydb & 0xffffu) + (uint32_t) row;
     offA = (uint32_t) rr.base + row_ofs (y, stride);
-#ifdef SCHRO_ROW_ALL_TAPS       // (A/B builds: every pass fetches four taps)
-    any_b = any_c = true;
-#else
     any_b = __ballot (dB != 0) != 0;
     any_c = __ballot (rr.dci != 0) != 0;
-#endif
     if (any_c)
       offC = (uint32_t) (rr.base + (rr.dci >> 16)) + row_ofs (y + ((uint32_t) rr.dci & 1u), stride);
   }
@@ -317,23 +330,32 @@ struct RowRefs {
   uint32_t stride[2];
 };
 
-template < int ND, int CLS, bool EXACT >
+// the DC value(s) of a block as prediction bytes: a plane's byte four times, UV: (U, V) twice
+template < bool UV, typename B >
+__device__ __forceinline__ uint32_t
+dc_bytes (const B & hb, int pl)
+{
+  if constexpr (UV)
+    return ((uint32_t) (blk_dc (hb, 0) & 0xff) | ((uint32_t) (blk_dc (hb, 1) & 0xff) << 8)) * 0x00010001u;
+  else
+    return (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
+}
+
+template < int ND, bool UV, int CLS, bool EXACT >
 __device__ __forceinline__ void
-row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlk * s_hot,
+row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlkT < RowGeo < ND, UV >::kPadBlk > *s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int it, int hi)
 {
-#ifdef SCHRO_ROW_STAMPS
-  const bool st = CLS == kRBoth && job.stamps && threadIdx.x == 0 && blockIdx.x < 16384;
-  const uint64_t t0 = st ? __builtin_amdgcn_s_memtime () : 0;
-#endif
+  typedef RowGeo < ND, UV > G;
   const int e = s_item[min (it, hi - 1)];
-  const RowBlk & hb = s_hot[e & 0x1ff];
+  const auto & hb = s_hot[e & 0x1ff];
   const int row = e >> 9;
   uint32_t p[ND];
   if constexpr (CLS == kRDc) {
+    // (DC values outside 0..255 are not in this class: rim)
 #pragma unroll
     for (int k = 0; k < ND; k++)
-      p[k] = (uint32_t) blk_dc (hb, pl) * 0x01010101u;
+      p[k] = dc_bytes < UV > (hb, pl);
   } else if constexpr (CLS == kREdge) {
     // any mode: both references are read (an unused one at offset 0) and the mode selects
     uint32_t p1[ND];
@@ -341,7 +363,7 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     __builtin_amdgcn_sched_barrier (0);
     predict_row < ND, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
     const uint32_t mode = blk_flags (hb) & 3u;
-    const uint32_t dc = (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;       // (meaningful in mode 0 only)
+    const uint32_t dc = dc_bytes < UV > (hb, pl);       // (meaningful in mode 0 only)
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int k = 0; k < ND; k++) {
@@ -360,23 +382,18 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     constexpr int r = CLS == kRRef1 ? 1 : 0;
     predict_row < ND > (job, refs.rsrc[r], refs.stride[r], hb.r[r], 0u, row, p);
   }
-#ifdef SCHRO_ROW_STAMPS
-  if (st) {
-    asm volatile ("" :: "v" (p[0]));
-    job.stamps[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime () - t0;
-  }
-#endif
   if (it >= hi)
     return;
   int half;
-  uint32_t *aw = acc_word < ND > (acc, par, hb.x, hb.y + row, &half);  // (block origins + par are even: half == 0)
-  // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go
+  uint32_t *aw = acc_word < G, UV > (acc, par, hb.x, hb.y + row, &half);       // (block origins + par are even: half == 0)
+  // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go.  A word's two
+  // 16-bit weights multiply the two bytes of a prediction byte pair: two neighbouring pixels, UV: the pixel's U and V
   uint32_t w[2 * ND];
   if constexpr (CLS == kREdge) {
     // weights folded at the picture's rim (schromotion8.c:673-693): 1-D tables per edge type behind
     // the plain products -- (left | right << 1) pairs of x weights, (top | bottom << 1) y weights
     const uint32_t fb = (blk_flags (hb) >> 2) & 15u;
-    const uint32_t *wxf = s_wp + kRWCapOf < ND > + 8 * (fb >> 2), *wyf = s_wp + kRWCapOf < ND > + 32 + 32 * (fb & 3u);
+    const uint32_t *wxf = s_wp + G::kWCap + 8 * (fb >> 2), *wyf = s_wp + G::kWCap + 32 + 32 * (fb & 3u);
     const uint32_t wy2 = wyf[row] * 0x00010001u;
 #pragma unroll
     for (int k = 0; k < 2 * ND; k++)
@@ -398,28 +415,18 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
       acc_add_exact (aw + k, 0, v & 0xffffu);
       acc_add_exact (aw + k, 1, v >> 16);
     } else {
-#ifdef SCHRO_ROW_DBG_NOACC      // (scratch builds: the passes without the LDS atomics)
-      asm volatile ("" :: "v" (v), "v" (aw));
-#else
       atomicAdd (aw + k, v);    // sums of pred * weight <= 255 * 64: no carry between the halves
-#endif
     }
   }
-#ifdef SCHRO_ROW_STAMPS
-  if (st) {
-    __builtin_amdgcn_s_waitcnt (0);
-    job.stamps[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime () - t0;
-  }
-#endif
 }
 
 // the passes of one class; *turn counts the passes of the classes before it, so that the four
 // waves take the tile's passes in turn whatever the class sizes (with nine classes most have one
 // or two passes: "wave w takes the w-th pass of every class" left wave 0 with nine passes and
 // wave 3 with none)
-template < int ND, int CLS >
+template < int ND, bool UV, int CLS >
 __device__ __forceinline__ void
-row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlk * s_hot,
+row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlkT < RowGeo < ND, UV >::kPadBlk > *s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int lo, int hi, bool exact, int *turn)
 {
   // (wave-uniform values in scalar registers: the class loops are scalar branches, not exec masks)
@@ -430,19 +437,21 @@ row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s
   *turn = (*turn + npass) & (kWaves - 1);
   if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, true > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
+      row_pass < ND, UV, CLS, true > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   } else {
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, CLS, false > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
+      row_pass < ND, UV, CLS, false > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   }
 }
 
-// picture-rim block rows: per-sample clamp and weight folding (accumulate_slow), 4 pixels
-template < int PC, int ND >
+// picture-rim block rows: per-sample clamp and weight folding (accumulate_slow), 4 pixels.
+// UV: of component cb of the pair images, into that half of the pixels' words
+template < int PC, typename G, bool UV >
 __device__ __forceinline__ void
-row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const int *fx, const int *fy, int row, int seg,
+row_slow (const ObmcJob & job, const PlaneIO & io, int cb, int bx, int by, int md, const int *fx, const int *fy, int row, int seg,
     int x_lo, int y_lo, int xfold_hi, int yfold_hi, const int *s_wx, const int *s_wy, uint32_t * acc, int par, bool exact)
 {
+  constexpr int ps = UV ? 1 : 0;
   const uint8_t *const refs[2] = { io.ref[0], io.ref[1] };
   const int prec = job.prec;
   const int y = by + row, xs = bx + 4 * seg;
@@ -469,8 +478,8 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
         for (int j = 0; j < 9; j++) {
           const int X = clampi (hx + j, 0, 2 * job.w - 2);
           const bool need = (j & 1) == 0 || rx != 0;
-          p0[j] = need ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y0, job.ref_stride[r])) : 0;
-          p1[j] = need && ry != 0 ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y1, job.ref_stride[r])) : 0;
+          p0[j] = need ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y0, job.ref_stride[r], ps, cb)) : 0;
+          p1[j] = need && ry != 0 ? (int) gload < uint8_t > (refs[r] + hp_offset (X, Y1, job.ref_stride[r], ps, cb)) : 0;
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -482,7 +491,7 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
 #pragma unroll
         for (int e = 0; e < 4; e++)
           val[r][e] = fetch_ref < PC > (refs[r], job.ref_stride[r], job.w, job.h,
-              fx[r] + (4 * seg + e) * (1 << prec), fy[r] + row * (1 << prec), prec);
+              fx[r] + (4 * seg + e) * (1 << prec), fy[r] + row * (1 << prec), prec, ps, cb);
       }
     }
 #pragma unroll
@@ -505,7 +514,9 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
     if (x >= xfold_hi)
       wx += s_wx[2 * (job.xblen - job.xoff) - idx - 1];
     int half;
-    uint32_t *aw = acc_word < ND > (acc, par, x - x_lo, y - y_lo, &half);
+    uint32_t *aw = acc_word < G, UV > (acc, par, x - x_lo, y - y_lo, &half);
+    if constexpr (UV)
+      half = cb;
     const uint32_t v = (uint32_t) (pred[e] * wx * wy);
     if (exact)
       acc_add_exact (aw, half, v & 0xffffu);
@@ -515,54 +526,83 @@ row_slow (const ObmcJob & job, const PlaneIO & io, int bx, int by, int md, const
 }
 
 // out = sat_u8 (residual + ((acc + 32) >> 6)) for one tile
+template < typename G >
 __device__ __forceinline__ bool
 row_finish_is_fast (const ObmcJob & job, const PlaneIO & io, int x_lo, int x_hi)
 {
-  return job.res_bpp == 2 && x_hi - x_lo == kRTW
+  return job.res_bpp == 2 && x_hi - x_lo == G::kTW
       && ((((uintptr_t) io.residual) | (uintptr_t) io.residual_stride) & 15) == 0
       && ((((uintptr_t) io.out) | (uintptr_t) io.out_stride) & 7) == 0;
 }
 
-// the fast finish's residual: 8 pixels of two rows per lane, fetched before the tile's last barrier
-template < int TH > constexpr int kRFinishRounds = (TH * (kRTW / 8) + kRThreads - 1) / kRThreads;
+// the fast finish's residual: 8 pixels of one row per lane and round (UV: of both planes), fetched before the
+// tile's last barrier
+template < int TH, typename G > constexpr int kRFinishRounds = (TH * (G::kTW / 8) + kRThreads - 1) / kRThreads;
 
-template < int TH >
+// The residual is read once and the picture written once; the half-pel planes are gathered from by
+// every picture of the batch.  Streaming (non-temporal) accesses for the first two leave the caches
+// to the planes: OBMC 0.2716 -> 0.2509 ms per 8 x 2160p step, the step 0.428 -> 0.410 (loads alone:
+// 0.257 / 0.417).  Half the distinct reference bytes are worth 7 % of OBMC (bench.py
+// SCHRO_BENCH_ONE_REF): it is the planes' residency that pays.
+// (res[STEP * n + FIRST]: UV keeps the two planes' pieces of a round side by side)
+template < int TH, typename G, int STEP, int FIRST >
 __device__ __forceinline__ void
 row_finish_prefetch (const PlaneIO & io, int tid, int x_lo, int y_lo, int y_hi, u32x4 * res)
 {
+  constexpr int kG = G::kTW / 8;        // 8-pixel groups per tile row (a power of two)
 #pragma unroll
-  for (int n = 0; n < kRFinishRounds < TH >; n++) {
-    const int it = tid + n * kRThreads, g = it & (kRTW / 8 - 1), y = y_lo + (it >> 4);
-    if (y < y_hi && it < TH * (kRTW / 8))
-      // The residual is read once and the picture written once; the half-pel planes are gathered from by
-      // every picture of the batch.  Streaming (non-temporal) accesses for the first two leave the caches
-      // to the planes: OBMC 0.2716 -> 0.2509 ms per 8 x 2160p step, the step 0.428 -> 0.410 (loads alone:
-      // 0.257 / 0.417; -DSCHRO_ROW_PLAIN_IO: ordinary accesses).  Half the distinct reference bytes are
-      // worth 7 % of OBMC (bench.py SCHRO_BENCH_ONE_REF): it is the planes' residency that pays.
-#ifndef SCHRO_ROW_PLAIN_IO
-      res[n] = __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x4 *) ((const char *) io.residual + (size_t) y * io.residual_stride + 2 * (x_lo + 8 * g)));
-#else
-      res[n] = gload < u32x4 > ((const char *) io.residual + (size_t) y * io.residual_stride + 2 * (x_lo + 8 * g));
-#endif
+  for (int n = 0; n < kRFinishRounds < TH, G >; n++) {
+    const int it = tid + n * kRThreads, g = it & (kG - 1), y = y_lo + it / kG;
+    if (!io.residual)           // no residual to add (a zero_residual picture, schrodecoder.c:1904-1906)
+      res[STEP * n + FIRST] = (u32x4) { 0u, 0u, 0u, 0u };
+    else if (y < y_hi && it < TH * kG)
+      res[STEP * n + FIRST] = __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x4 *) ((const char *) io.residual + (size_t) y * io.residual_stride + 2 * (x_lo + 8 * g)));
   }
 }
 
-template < int TH, int ND >
+// orc_rrshift6_add_s16_2d / _s32_2d on one pixel per lane and step (any residual depth, any alignment);
+// UV: component cb of the pixels' words
+template < int TH, typename G, bool UV >
+__device__ __forceinline__ void
+row_finish_plain (const ObmcJob & job, const PlaneIO & io, int cb, const uint32_t * acc, int par, int tid, int x_lo, int y_lo,
+    int x_hi, int y_hi)
+{
+  for (int it = tid; it < TH * G::kTW; it += kRThreads) {
+    const int xx = it & (G::kTW - 1), yy = it / G::kTW;
+    const int x = x_lo + xx, y = y_lo + yy;
+    if (y >= y_hi || x >= x_hi)
+      continue;
+    int half;
+    const uint32_t *aw = acc_word < G, UV > (const_cast < uint32_t * >(acc), par, xx, yy, &half);
+    if constexpr (UV)
+      half = cb;
+    const int16_t a = (int16_t) (*aw >> (16 * half));
+    const char *rrow = (const char *) io.residual + (size_t) y * io.residual_stride;
+    const int16_t res = !io.residual ? (int16_t) 0 : job.res_bpp == 2 ? gload < int16_t > ((const int16_t *) rrow + x)
+        : (int16_t) gload < int32_t > ((const int32_t *) rrow + x);   // convlw
+    int16_t t1 = (int16_t) (a + 32);
+    t1 = (int16_t) (t1 >> 6);
+    t1 = (int16_t) (res + t1);
+    gstore < uint8_t > (io.out + (size_t) y * io.out_stride + x, (uint8_t) clampi (t1, 0, 255));
+  }
+}
+
+template < int TH, typename G >
 __device__ __forceinline__ void
 row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, int tid, int x_lo, int y_lo,
     int x_hi, int y_hi, bool fast, const u32x4 * res)
 {
+  constexpr int kG = G::kTW / 8;
   if (fast) {
     // one lane: 8 pixels of one row, packed 16-bit arithmetic (the reference's adds wrap at 16 bits)
 #pragma unroll
-    for (int n = 0; n < kRFinishRounds < TH >; n++) {
+    for (int n = 0; n < kRFinishRounds < TH, G >; n++) {
       const int it = tid + n * kRThreads;
-      const int g = it & (kRTW / 8 - 1), yy = it >> 4;
-      static_assert (kRTW / 8 == 16, "8-pixel groups per tile row");
+      const int g = it & (kG - 1), yy = it / kG;
       const int y = y_lo + yy;
-      if (y >= y_hi || it >= TH * (kRTW / 8))
+      if (y >= y_hi || it >= TH * kG)
         continue;
-      const uint32_t *ap = acc + yy * kRAccWOf < ND > + (kRMarginOf < ND > / 2 + 4 * g);
+      const uint32_t *ap = acc + yy * G::kAccW + (G::kMargin / 2 + 4 * g);
       uint32_t av[4];
       if (par) {
         // pixel 8 g sits in the high half of word 4 g + 8: shift the five words down by one pixel
@@ -591,46 +631,70 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
       u32x2 o;
       o.x = __builtin_amdgcn_perm (t[1], t[0], 0x06040200u);
       o.y = __builtin_amdgcn_perm (t[3], t[2], 0x06040200u);
-#ifndef SCHRO_ROW_PLAIN_IO
       __builtin_nontemporal_store (o, (SCHRO_GLOBAL u32x2 *) (io.out + (size_t) y * io.out_stride + x));
-#else
-      gstore < u32x2 > (io.out + (size_t) y * io.out_stride + x, o);
-#endif
     }
     return;
   }
-  // orc_rrshift6_add_s16_2d / _s32_2d on one pixel per lane and step
-  for (int it = tid; it < TH * kRTW; it += kRThreads) {
-    const int xx = it & (kRTW - 1), yy = it >> 7;
-    static_assert (kRTW == 128, "tile row = 128 pixels");
-    const int x = x_lo + xx, y = y_lo + yy;
-    if (y >= y_hi || x >= x_hi)
+  row_finish_plain < TH, G, false > (job, io, 0, acc, par, tid, x_lo, y_lo, x_hi, y_hi);
+}
+
+// UV: a lane takes 8 pixels of one row of BOTH planes: eight accumulator words (U sum low, V sum high),
+// 16 bytes of each plane's residual (res[2 n], res[2 n + 1]), 8 bytes of each plane's picture
+template < int TH, typename G >
+__device__ __forceinline__ void
+row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, int tid, int x_lo, int y_lo, int y_hi, const u32x4 * res)
+{
+  constexpr int kG = G::kTW / 8;
+#pragma unroll
+  for (int n = 0; n < kRFinishRounds < TH, G >; n++) {
+    const int it = tid + n * kRThreads;
+    const int g = it & (kG - 1), yy = it / kG;
+    const int y = y_lo + yy;
+    if (y >= y_hi || it >= TH * kG)
       continue;
-    int half;
-    const uint32_t *aw = acc_word < ND > (acc, par, xx, yy, &half);
-    const int16_t a = (int16_t) (*aw >> (16 * half));
-    const char *rrow = (const char *) io.residual + (size_t) y * io.residual_stride;
-    const int16_t res = job.res_bpp == 2 ? gload < int16_t > ((const int16_t *) rrow + x)
-        : (int16_t) gload < int32_t > ((const int32_t *) rrow + x);   // convlw
-    int16_t t1 = (int16_t) (a + 32);
-    t1 = (int16_t) (t1 >> 6);
-    t1 = (int16_t) (res + t1);
-    gstore < uint8_t > (io.out + (size_t) y * io.out_stride + x, (uint8_t) clampi (t1, 0, 255));
+    const uint32_t *ap = acc + yy * G::kAccW + (G::kMargin + 8 * g);
+    const u32x4 ru = res[2 * n], rv = res[2 * n + 1];
+    const uint32_t ruw[4] = { ru.x, ru.y, ru.z, ru.w }, rvw[4] = { rv.x, rv.y, rv.z, rv.w };
+    uint32_t t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      // the pixel's residuals as (U, V): the low / high 16 bits of the planes' dwords
+      const uint32_t r = __builtin_amdgcn_perm (rvw[k >> 1], ruw[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
+      s16x2 v = (__builtin_bit_cast (s16x2, ap[k]) + (short) 32) >> 6;
+      v = v + __builtin_bit_cast (s16x2, r);
+      v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+      t[k] = __builtin_bit_cast (uint32_t, v);
+    }
+    // t[k] = (U_k, 0, V_k, 0) -> (U0 U1 V0 V1), (U2 U3 V2 V3) -> U0 .. U3 | V0 .. V3
+    const uint32_t a01 = __builtin_amdgcn_perm (t[1], t[0], 0x06020400u), a23 = __builtin_amdgcn_perm (t[3], t[2], 0x06020400u);
+    const uint32_t a45 = __builtin_amdgcn_perm (t[5], t[4], 0x06020400u), a67 = __builtin_amdgcn_perm (t[7], t[6], 0x06020400u);
+    u32x2 ou, ov;
+    ou.x = __builtin_amdgcn_perm (a23, a01, 0x05040100u);
+    ou.y = __builtin_amdgcn_perm (a67, a45, 0x05040100u);
+    ov.x = __builtin_amdgcn_perm (a23, a01, 0x07060302u);
+    ov.y = __builtin_amdgcn_perm (a67, a45, 0x07060302u);
+    const int x = x_lo + 8 * g;
+    __builtin_nontemporal_store (ou, (SCHRO_GLOBAL u32x2 *) (iou.out + (size_t) y * iou.out_stride + x));
+    __builtin_nontemporal_store (ov, (SCHRO_GLOBAL u32x2 *) (iov.out + (size_t) y * iov.out_stride + x));
   }
 }
 
-template < int ND, int NP, int TH = kRTH >
+template < int ND, int NP, bool UV = false, int TH = kRTH >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
 {
-  __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * kRAccWOf < ND >];
+  typedef RowGeo < ND, UV > G;
+  static_assert (!UV || NP == 1, "a UV job is one virtual plane of (U, V) samples");
+  constexpr int kRTW = G::kTW, ps = UV ? 1 : 0;
+  __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * G::kAccW + 3];
   __shared__ int s_wx[16], s_wy[32];    // (obmc_row_nd: blocks up to 16 x 32)
-  constexpr int kRBlkCap = RowCaps < ND >::kBlk, kRItemCap = RowCaps < ND >::kItem;
+  constexpr int kRBlkCap = G::kBlk, kRItemCap = G::kItem;
+  typedef RowBlkT < G::kPadBlk > RowBlk;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
   __shared__ uint16_t s_meta[kRBlkCap];         // slot | first item within the slot << 5
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
-  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[kRWCapOf < ND > + 32 + 128];      // + folded x pairs, folded y (edge class)
+  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[G::kWCap + 32 + 128];      // + folded x pairs, folded y (edge class)
   __shared__ int s_icnt[kRSlots];               // items of each slot
   __shared__ int s_nrim, s_wide;
 
@@ -648,20 +712,13 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
-  static_assert ((TH * kRAccWOf < ND >) % 4 == 0, "accumulator tile is cleared 16 bytes at a time");
-  for (int it = tid; it < TH * kRAccWOf < ND > / 4; it += kRThreads)
+  constexpr int kAccQuads = (TH * G::kAccW + 3) / 4;   // the accumulator tile is cleared 16 bytes at a time
+  for (int it = tid; it < kAccQuads; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
-#ifdef SCHRO_ROW_DBG_NOWT      // (scratch builds, wrong results: the set-up without its weight tables)
-  if (tid < 16)
-    s_wx[tid] = 8;
-  if (tid >= 64 && tid < 96)
-    s_wy[tid - 64] = 8;
-#else
   if (tid < job.xblen)
     s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
   if (tid >= 64 && tid - 64 < job.yblen)
     s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
-#endif
   if (tid >= 128 && tid < 128 + kRSlots)
     s_icnt[tid - 128] = 0;
   if (tid == 192) {
@@ -670,7 +727,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   }
 
   const int xblen = job.xblen, yblen = job.yblen;
-  const int par = job.xoff & 1;         // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
+  const int par = UV ? 0 : job.xoff & 1;        // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
   const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
   int nblk;
   {
@@ -695,15 +752,13 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
     __syncthreads ();           // ramps, counters
     // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
-    // 2 * ND words, zero beyond the block's width
-#ifdef SCHRO_ROW_DBG_NOWT
-    if (tid < kRWCapOf < ND >)
-      s_wp[tid] = 0x00400040u;
-    if (0)
-#endif
-    for (int i = tid; i < yblen * 2 * ND && i < kRWCapOf < ND >; i += kRThreads) {
+    // 2 * ND words, zero beyond the block's width.  UV: a word per pixel, its weight for both components
+    for (int i = tid; i < yblen * 2 * ND && i < G::kWCap; i += kRThreads) {
       const int r = i / (2 * ND), pr = i - r * (2 * ND);
-      s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
+      if constexpr (UV)
+        s_wp[i] = pr < xblen ? (uint32_t) (s_wx[pr] * s_wy[r]) * 0x00010001u : 0u;
+      else
+        s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
     }
     // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
     // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
@@ -721,11 +776,14 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       };
       if (tid < 32) {
         const int type = tid >> 3, pr = tid & 7;
-        s_wp[kRWCapOf < ND > + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
-            | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
+        if constexpr (UV)       // (rows of up to 8 pixels: 8 words per edge type, as for 16 pixels in pairs)
+          s_wp[G::kWCap + tid] = (uint32_t) folded (s_wx, pr, xblen, job.xbsep, job.xoff, type) * 0x00010001u;
+        else
+          s_wp[G::kWCap + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
+              | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
       } else {
         const int type = (tid - 32) >> 5, r = (tid - 32) & 31;
-        s_wp[kRWCapOf < ND > + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
+        s_wp[G::kWCap + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
       }
     }
     RSTAMP (1);
@@ -750,7 +808,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         // get_dc_block stores a uint8_t; block_acc_dc multiplies a 16-bit parameter
         return interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
       };
-      const int pdc = dc_of (job.comp), pdc_b = nplanes > 1 ? dc_of (job.comp_b) : 0;
+      const int pdc = dc_of (job.comp), pdc_b = (nplanes > 1 || UV) ? dc_of (job.comp_b) : 0;
       const int dcs = (int) (((uint32_t) pdc & 0xffffu) | ((uint32_t) pdc_b << 16));
       uint32_t bflags = (uint32_t) mode;
       int ry[2] = { 0, 0 };
@@ -766,15 +824,15 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         ry[r] = prec >= 2 ? fy & 1 : 0;
         const bool used = (mode & (r + 1)) != 0;
         // columns: get_block's clamp keeps every window inside the aprons (32 pixels either side); the
-        // test is a guard, not a case
-        const int xp = (hx >> 1) + kHpApron, px = hx & 1, py = hy & 1;
+        // test is a guard, not a case.  xp: the window's first byte column (UV: samples of two bytes)
+        const int xp = ((hx >> 1) + kHpApron) << ps, px = hx & 1, py = hy & 1;
         const bool in_h = xp >= 0 && (xp >> 4) < (job.ref_stride[r] >> 9) && (unsigned) (hy + 16384) < 32768u;
         // rows: both taps of every sample row of the block inside the image, else clamped row by row
         const bool in_v = hy >= 0 && hy + 2 * (yblen - 1) + 1 <= gh;
         off_h |= used && !in_h;
         clamped_v |= used && !in_v;
         const int colbase = in_h && used ? (xp >> 4) * 512 + (xp & 15) + px * 128 : 0;
-        const uint32_t dB = in_h && used && rx ? (uint32_t) (px ? 1 - 128 : 128) : 0u;
+        const uint32_t dB = in_h && used && rx ? (uint32_t) (px ? (1 << ps) - 128 : 128) : 0u;
         in_ref[r].base = colbase + (in_h && used ? py * 256 : 0);
         in_ref[r].ydb = (in_h && in_v && used ? (uint32_t) (hy >> 1) : 0u) | (dB << 16);
         in_ref[r].dci = in_h && used && ry[r] ? (py ? (int) (((uint32_t) -256 << 16) | 1u) : (int) (256u << 16)) : 0;
@@ -792,7 +850,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       if (wide_dc)
         s_wide = 1;
       int key;
-      if (off_h || wide_dc || yblen * 2 * ND > kRWCapOf < ND > || xblen > 16) {
+      if (off_h || wide_dc || yblen * 2 * ND > G::kWCap || xblen > (UV ? 8 : 16)) {
         key = kRRim;
         // the rim path works from the clamped fetch origins
         // (16 bits each: obmc_row_nd keeps planes whose origins do not fit away from this kernel)
@@ -874,18 +932,31 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     io.out = pl ? job.out_b : job.out;
     io.residual_stride = pl ? job.residual_stride_b : job.residual_stride;
     io.out_stride = pl ? job.out_stride_b : job.out_stride;
+    // UV: the V plane's residual and picture (the references are the pair images in io)
+    PlaneIO iov = io;
+    if constexpr (UV) {
+      iov.residual = job.residual_b;
+      iov.out = job.out_b;
+      iov.residual_stride = job.residual_stride_b;
+      iov.out_stride = job.out_stride_b;
+    }
     // The residual of the fast finish is asked for before the passes where the registers allow
     // (8 per lane, held through the passes): it streams from HBM, and fetched after the passes
     // its latency was the tile's to wait for.
-#ifndef SCHRO_ROW_EARLY_RES
-#define SCHRO_ROW_EARLY_RES 1
-#endif
-    constexpr bool kEarlyRes = SCHRO_ROW_EARLY_RES != 0 && (SCHRO_ROW_EARLY_RES > 1 || (ND >= 3 && NP == 1));
-    const bool fast = row_finish_is_fast (job, io, x_lo, x_hi);
-    u32x4 res[kRFinishRounds < TH >];
+    constexpr bool kEarlyRes = ND >= 3 && NP == 1;
+    const bool fast = row_finish_is_fast < G > (job, io, x_lo, x_hi) && (!UV || row_finish_is_fast < G > (job, iov, x_lo, x_hi));
+    constexpr int kRounds = kRFinishRounds < TH, G >;
+    u32x4 res[UV ? 2 * kRounds : kRounds];
+#define SCHRO_ROW_PREFETCH() do { \
+      if constexpr (UV) { \
+        row_finish_prefetch < TH, G, 2, 0 > (io, tid, x_lo, y_lo, y_hi, res); \
+        row_finish_prefetch < TH, G, 2, 1 > (iov, tid, x_lo, y_lo, y_hi, res); \
+      } else { \
+        row_finish_prefetch < TH, G, 1, 0 > (io, tid, x_lo, y_lo, y_hi, res); \
+      } } while (0)
     if constexpr (kEarlyRes) {
       if (fast)
-        row_finish_prefetch < TH > (io, tid, x_lo, y_lo, y_hi, res);
+        SCHRO_ROW_PREFETCH ();
       __builtin_amdgcn_sched_barrier (0);
     }
     int turn = 0;
@@ -897,11 +968,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       refs.rsrc[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[r], 0,
           (int) ((uint32_t) job.ref_stride[r] * (uint32_t) ((job.h + 3) >> 2)), 0x00020000);
     }
-#ifdef SCHRO_ROW_DBG_NOPASS     // (scratch builds: everything but the passes)
-    if (job.w < 0)
-#endif
-    {
-#define SCHRO_ROW_CLASS(C) row_class < ND, C > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
+#define SCHRO_ROW_CLASS(C) row_class < ND, UV, C > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
     ibase[C], ibase[C + 1], exact, &turn)
     SCHRO_ROW_CLASS (kRBoth);
     SCHRO_ROW_CLASS (kRRef0);
@@ -909,7 +976,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     SCHRO_ROW_CLASS (kRDc);
     SCHRO_ROW_CLASS (kREdge);
 #undef SCHRO_ROW_CLASS
-    }
     RSTAMP (4);
     // picture-rim blocks: exact clamp / fold path
     if (nrim > 0) {
@@ -925,24 +991,43 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
         if (y < y_lo || y >= y_hi || xs + 3 < x_lo || xs >= x_hi)
           continue;
         const int fx[2] = { (int) (int16_t) hb.r[0].base, (int) (int16_t) hb.r[1].base }, fy[2] = { hb.r[0].base >> 16, hb.r[1].base >> 16 };
-        const int md = (int) (blk_flags (hb) & 3u) | (blk_dc (hb, pl) << 8);      // (the DC part is read in mode 0 only)
-        if (job.prec == 1)
-          row_slow < 1, ND > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
-        else
-          row_slow < 2, ND > (job, io, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact);
+#define SCHRO_ROW_SLOW(cb, dcpl) do { \
+          const int md = (int) (blk_flags (hb) & 3u) | (blk_dc (hb, dcpl) << 8);       /* (the DC part is read in mode 0 only) */ \
+          if (job.prec == 1) \
+            row_slow < 1, G, UV > (job, io, cb, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact); \
+          else \
+            row_slow < 2, G, UV > (job, io, cb, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact); \
+        } while (0)
+        if constexpr (UV) {
+          SCHRO_ROW_SLOW (0, 0);
+          SCHRO_ROW_SLOW (1, 1);
+        } else {
+          SCHRO_ROW_SLOW (0, pl);
+        }
+#undef SCHRO_ROW_SLOW
       }
     }
     RSTAMP (5);
     if constexpr (!kEarlyRes) {
       if (fast)
-        row_finish_prefetch < TH > (io, tid, x_lo, y_lo, y_hi, res);
+        SCHRO_ROW_PREFETCH ();
     }
+#undef SCHRO_ROW_PREFETCH
     __syncthreads ();
     RSTAMP (6);
-    row_finish < TH, ND > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+    if constexpr (UV) {
+      if (fast) {
+        row_finish_uv < TH, G > (io, iov, acc, tid, x_lo, y_lo, y_hi, res);
+      } else {
+        row_finish_plain < TH, G, true > (job, io, 0, acc, par, tid, x_lo, y_lo, x_hi, y_hi);
+        row_finish_plain < TH, G, true > (job, iov, 1, acc, par, tid, x_lo, y_lo, x_hi, y_hi);
+      }
+    } else {
+      row_finish < TH, G > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+    }
     if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
       __syncthreads ();
-      for (int it = tid; it < TH * kRAccWOf < ND > / 4; it += kRThreads)
+      for (int it = tid; it < kAccQuads; it += kRThreads)
         reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
       __syncthreads ();
     }
@@ -961,56 +1046,37 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // ms per 8 x 2160p luma launch): 2 0.278, 3 0.211, 4 0.180, 5 0.162, 6 0.153, 7 0.148 -- a saturating
 // curve: the launch is no longer waiting for anything in particular (compiled-out stages: everything
 // but the passes 0.056, the passes' arithmetic 0.044, their loads 0.047, the LDS atomics 0.009 ms).
-// The 12-pixel-row kernel takes 69 registers: seven waves per SIMD at 19.3 KB of LDS; the
-// 6-pixel-row kernels (chroma: 344 blocks of 32 bytes, a 73-word accumulator pitch: 26.8 KB -- LDS is
-// handed out in 1280-byte granules, 27.1 KB still meant five) run six workgroups per CU:
-// 8 x 2160p OBMC 0.2705 -> 0.2667 ms per step.
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
-void obmc_row_kernel_2_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 2, 1 > (jobs, njobs, order);
+// The 12-pixel-row kernel takes 69 registers: seven waves per SIMD at 19.8 KB of LDS; the
+// 6-pixel-row kernels (chroma planes on their own: 344 blocks, a 73-word accumulator pitch) run five
+// or six workgroups per CU; the UV kernels are the 12-byte-row kernel on 64-pixel tiles.
+#define SCHRO_ROW_KERNEL(name, waves, ...) \
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (waves, waves))) \
+void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order) \
+{ \
+  obmc_row_body < __VA_ARGS__ > (jobs, njobs, order); \
 }
-
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (6, 6)))
-void obmc_row_kernel_2_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 2, 2 > (jobs, njobs, order);
-}
-
-#ifndef SCHRO_ROW_WPE_31
-#define SCHRO_ROW_WPE_31 7
-#endif
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (SCHRO_ROW_WPE_31, SCHRO_ROW_WPE_31)))
-void obmc_row_kernel_3_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 3, 1 > (jobs, njobs, order);
-}
-
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
-void obmc_row_kernel_3_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 3, 2 > (jobs, njobs, order);
-}
-
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
-void obmc_row_kernel_4_1 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 4, 1 > (jobs, njobs, order);
-}
-
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
-void obmc_row_kernel_4_2 (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
-{
-  obmc_row_body < 4, 2 > (jobs, njobs, order);
-}
+SCHRO_ROW_KERNEL (obmc_row_kernel_2_1, 6, 2, 1)
+SCHRO_ROW_KERNEL (obmc_row_kernel_2_2, 6, 2, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_3_1, 7, 3, 1)
+SCHRO_ROW_KERNEL (obmc_row_kernel_3_2, 5, 3, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_4_1, 4, 4, 1)
+SCHRO_ROW_KERNEL (obmc_row_kernel_4_2, 4, 4, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_uv_2, 5, 2, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_uv_3, 7, 3, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 4, 4, 1, true)
+#undef SCHRO_ROW_KERNEL
 
 typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *);
 
+// np: planes per job (1, 2); 3: (U, V) pairs from pair images
 int
 launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int np, const uint32_t * d_order)
 {
   RowKernel k = nullptr;
   switch (nd * 10 + np) {
+    case 23: k = obmc_row_kernel_uv_2; break;
+    case 33: k = obmc_row_kernel_uv_3; break;
+    case 43: k = obmc_row_kernel_uv_4; break;
     case 21: k = obmc_row_kernel_2_1; break;
     case 22: k = obmc_row_kernel_2_2; break;
     case 31: k = obmc_row_kernel_3_1; break;
@@ -1032,32 +1098,46 @@ launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 }                               // namespace
 
 // Prediction dwords per block row the row kernel runs this plane with; 0: not its case (plain or
-// eighth-pel references, blocks wider than 16, unaligned half-pel images) -> obmc.hip
+// eighth-pel references, blocks wider than 16, unaligned half-pel images) -> obmc.hip.
+// uv: as the U plane of a (U, V) pair from pair images (rows of up to 8 samples = 16 bytes, 64-pixel tiles)
 int
-obmc_row_nd (const ObmcJob & j)
+obmc_row_nd (const ObmcJob & j, bool uv)
 {
-  if (j.prec < 1 || j.prec > 2 || j.xblen > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
+  const int ps = uv ? 1 : 0;
+  if (j.ref_ps != ps)
+    return 0;
+  if (j.prec < 1 || j.prec > 2 || (j.xblen << ps) > 16 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
     return 0;
   // rim blocks keep their clamped fetch origins (get_block: at most (size + 32) << prec) in 16 bits
   if (((std::max (j.w, j.h) + 32) << j.prec) > 32767)
     return 0;
-  // the blocks that can meet a 128x32 tile and their rows inside it fit the kernel's tables
-  const int nbi = (kRTW - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
   if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1])) & 127)
     return 0;
-  if (((j.ref_stride[0] | j.ref_stride[1]) & 511) || j.ref_stride[0] < hp_chunks (j.w) * 512 || j.ref_stride[1] < hp_chunks (j.w) * 512)
+  if (((j.ref_stride[0] | j.ref_stride[1]) & 511) || j.ref_stride[0] < hp_chunks (j.w, ps) * 512 || j.ref_stride[1] < hp_chunks (j.w, ps) * 512)
     return 0;
-  const int need = (j.xblen + 3) / 4, nd = need <= 2 ? 2 : need;        // 2, 3 or 4
-  const int blk_cap = nd <= 2 ? RowCaps < 2 >::kBlk : RowCaps < 3 >::kBlk;
-  const int item_cap = nd <= 2 ? RowCaps < 2 >::kItem : RowCaps < 3 >::kItem;
+  const int need = ((j.xblen << ps) + 3) / 4, nd = need <= 2 ? 2 : need;        // 2, 3 or 4
+  // the blocks that can meet a tile and their rows inside it fit the kernel's tables
+  const int tw = uv ? RowGeo < 3, true >::kTW : RowGeo < 3, false >::kTW;
+  const int nbi = (tw - 1 + j.xblen - 1) / j.xbsep + 1, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
+  const int blk_cap = uv ? (nd <= 2 ? RowGeo < 2, true >::kBlk : RowGeo < 3, true >::kBlk)
+      : (nd <= 2 ? RowGeo < 2, false >::kBlk : RowGeo < 3, false >::kBlk);
+  const int item_cap = uv ? (nd <= 2 ? RowGeo < 2, true >::kItem : RowGeo < 3, true >::kItem)
+      : (nd <= 2 ? RowGeo < 2, false >::kItem : RowGeo < 3, false >::kItem);
   if (nbi * nbj > blk_cap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > item_cap)
     return 0;
   return nd;
 }
 
+// the row kernels' tile width (obmc_tiles): 128 pixels, (U, V) pairs 64
+int
+obmc_row_tile_width (bool uv)
+{
+  return uv ? RowGeo < 3, true >::kTW : RowGeo < 3, false >::kTW;
+}
+
 int
 launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int planes_per_job,
-    const uint32_t * d_order)
+    const uint32_t * d_order)        // planes_per_job 3: (U, V) pairs from pair images
 {
   return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order);
 }

@@ -25,6 +25,19 @@
 //     for "the frame of reference n on my device" (schro_hip_scheduler_reference_frame).
 // No data-path collective, no RCCL: pictures shard.
 //
+// r04 -- events, not drains (TODO-CUDA:5-7).  A picture's function only ENQUEUES on its context's queues.
+// When a reference picture's function has returned, the worker joins the context's queues behind ONE
+// event (`ready`) and the reference is complete: pictures of the same device follow it in the in-order
+// queues, a picture on another device makes its copy queue WAIT for the event (hipStreamWaitEvent), issues
+// the peer copy asynchronously and makes its kernel queues wait for the copy -- no host thread waits for a
+// device anywhere on the path, so a device can have any number of reference pictures in flight
+// (refs_in_flight_max counts them from the events).  r03 drained the whole device after every reference
+// picture and copied synchronously (the reference's precedent: schrogpuframe.c:480-609).
+// A reference whose function FAILED is complete too (nobody waits forever) but marked failed: its
+// dependents -- on this device and on others -- do not run their functions, they finish with
+// SCHRO_HIP_ESKIPPED, and a skipped reference fails in turn; the reference decoder does the same with
+// picture->error / picture->skip (schrodecoder.c:1308-1311, :1399-1418).
+//
 // Lifetime (r03).  The reference decoder retires a reference at PARSE time
 // (schro_decoder_reference_retire, schrodecoder.c:1302), i.e. possibly before pictures that
 // predict from it -- already submitted -- have run, and even before the reference itself has.  So
@@ -41,15 +54,25 @@
 #include <mutex>
 #include <thread>
 
-extern "C" SchroHipFrame *schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src);
-extern "C" void schro_hip_thread_bind (SchroHipContext * ctx);
+namespace schro {
+// api.cpp: queue 0 of the context waits for its other queues, then `ev` is recorded on it
+int context_join_queues (SchroHipContext * ctx, hipEvent_t ev);
+// api.cpp: a copy of `src` on dst_ctx's device, enqueued on its host-to-device copy queue behind `wait_for`;
+// `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  Nothing is waited for here.
+SchroHipFrame *frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done);
+// api.cpp: a context that does not become the calling thread's domain
+SchroHipContext *context_new_unbound (int device);
+}
 
 struct SchroHipScheduler {
   struct Ref {
     int number;
     int device;                 // index of the owner
-    bool complete = false;      // the owner's function has returned AND its device work has finished
+    bool complete = false;      // the owner's function has returned and `ready` is recorded behind its device work
+    bool failed = false;        // ... with an error (or was skipped): dependents are skipped
     bool retired = false;       // no longer in the lookup table
+    hipEvent_t ready = nullptr; // real devices: behind everything the owner's function enqueued
+    std::vector < hipEvent_t > copied;  // behind the peer copies made FROM its frame (waited for before the frame goes)
     int users = 0;              // submitted pictures that predict from it and have not finished
     void *frame = nullptr;      // what the owner published (a SchroHipFrame * on real devices)
     std::map < int, void * >copies;       // device index -> the frame moved there
@@ -68,7 +91,14 @@ struct SchroHipScheduler {
     std::deque < Task > queue;
     long submitted = 0, finished = 0;
     const Task *current = nullptr;      // the task whose function is running
-    std::vector < SchroHipFrame * >garbage;      // frames of this device's context to release on its thread
+    // frames of this device's context to release on its thread, and the events to wait for before
+    struct Garbage {
+      SchroHipFrame *frame;
+      std::vector < hipEvent_t > after;
+      hipEvent_t destroy;
+    };
+    std::vector < Garbage > garbage;
+    std::deque < hipEvent_t > in_flight;        // `ready` events of this device's reference pictures, oldest first
   };
   std::vector < Device > devs;
   std::mutex mutex;
@@ -77,7 +107,8 @@ struct SchroHipScheduler {
   bool quit = false;
   bool virtual_devices = false;
   int first_error = 0;
-  long moves = 0;
+  long moves = 0, skipped = 0;
+  int refs_in_flight_max = 0;   // most reference pictures of one device whose device work was still running
 };
 
 namespace {
@@ -91,19 +122,27 @@ release_if_unused (SchroHipScheduler * s, Ref * r)
   if (!r->retired || !r->complete || r->users > 0)
     return;
   if (!s->virtual_devices) {
-    if (r->frame)
-      s->devs[r->device].garbage.push_back ((SchroHipFrame *) r->frame);
+    // the published frame goes when the copies made from it have run; `ready` is destroyed with it
+    s->devs[r->device].garbage.push_back ({ (SchroHipFrame *) r->frame, r->copied, r->ready });
     for (auto & c:r->copies)
-      s->devs[c.first].garbage.push_back ((SchroHipFrame *) c.second);
+      s->devs[c.first].garbage.push_back ({ (SchroHipFrame *) c.second, {}, nullptr });
   }
   delete r;
 }
 
 void
-empty_garbage (std::vector < SchroHipFrame * >&g)
+empty_garbage (std::vector < SchroHipScheduler::Device::Garbage > &g)
 {
-  for (SchroHipFrame * f:g)
-    schro_hip_frame_unref (f);
+  for (auto & e:g) {
+    for (hipEvent_t ev:e.after) {
+      (void) hipEventSynchronize (ev);
+      (void) hipEventDestroy (ev);
+    }
+    if (e.frame)
+      schro_hip_frame_unref (e.frame);
+    if (e.destroy)
+      (void) hipEventDestroy (e.destroy);
+  }
   g.clear ();
 }
 
@@ -132,7 +171,7 @@ worker (SchroHipScheduler * s, int index)
           return s->quit || runnable (s, d, index) || !d.garbage.empty ();
         });
     if (!d.garbage.empty ()) {
-      std::vector < SchroHipFrame * >g;
+      std::vector < SchroHipScheduler::Device::Garbage > g;
       g.swap (d.garbage);
       lock.unlock ();
       empty_garbage (g);
@@ -146,49 +185,89 @@ worker (SchroHipScheduler * s, int index)
     }
     SchroHipScheduler::Task t = d.queue.front ();
     d.queue.pop_front ();
-    // references that live elsewhere: complete by now (runnable); bring their frames over
-    std::vector < std::pair < Ref *, void *> >to_move;
+    // a reference that failed (or was skipped): this picture is skipped, as picture->error does in the reference
+    bool skip = false;
     for (Ref * r:t.refs)
-      if (r->device != index && !r->copies.count (index))
-        to_move.push_back ({ r, r->frame });
+      skip |= r->failed;
+    // references that live elsewhere: complete by now (runnable); bring their frames over -- once each
+    // (refs = {n, n} is legal)
+    struct Move {
+      Ref *ref;
+      void *frame;
+      hipEvent_t ready;
+      void *moved;
+      hipEvent_t done;
+    };
+    std::vector < Move > to_move;
+    for (Ref * r:t.refs) {
+      bool listed = false;
+      for (auto & m:to_move)
+        listed |= m.ref == r;
+      if (!skip && !listed && r->device != index && !r->copies.count (index))
+        to_move.push_back ({ r, r->frame, r->ready, nullptr, nullptr });
+    }
     d.current = &t;
     lock.unlock ();
-    int rc = 0;
-    std::vector < void *>moved (to_move.size (), nullptr);
+    int rc = skip ? SCHRO_HIP_ESKIPPED : 0;
     for (size_t k = 0; k < to_move.size () && !rc; k++) {
-      if (!to_move[k].second)
+      Move & m = to_move[k];
+      if (!m.frame)
         continue;               // nothing published: the caller moves it (foreign_ref of submit)
       if (s->virtual_devices) {
-        moved[k] = to_move[k].second;
+        m.moved = m.frame;
       } else {
-        moved[k] = schro_hip_frame_copy_to (d.ctx, (SchroHipFrame *) to_move[k].second);
-        if (!moved[k])
+        // the copy waits for the owner's `ready` on this device's copy queue; this thread does not wait
+        if (hipEventCreateWithFlags (&m.done, hipEventDisableTiming) != hipSuccess)
+          m.done = nullptr;
+        m.moved = m.done ? schro::frame_copy_to_async (d.ctx, (SchroHipFrame *) m.frame, m.ready, m.done) : nullptr;
+        if (!m.moved)
           rc = SCHRO_HIP_EDEVICE;
       }
     }
     if (!to_move.empty ()) {
       lock.lock ();
-      for (size_t k = 0; k < to_move.size (); k++)
-        if (moved[k]) {
-          to_move[k].first->copies[index] = moved[k];
+      for (auto & m:to_move)
+        if (m.moved) {
+          m.ref->copies[index] = m.moved;
+          if (m.done)
+            m.ref->copied.push_back (m.done);
           s->moves++;
+        } else if (m.done) {
+          (void) hipEventDestroy (m.done);
         }
       lock.unlock ();
     }
     if (!rc)
       rc = t.func (d.ctx, index, t.priv);
-    // the function only ENQUEUES on the context's queues: a reference counts as complete -- readable
-    // from another device -- when that work has finished
+    // the function only ENQUEUES on the context's queues: a reference is complete -- usable by its
+    // dependents, here through the in-order queues, elsewhere through `ready` -- when an event stands
+    // behind that work.  Nothing is drained.
+    hipEvent_t ready = nullptr;
+    int in_flight = 0;
     if (d.ctx && t.self) {
-      const int rs = schro_hip_synchronize (d.ctx);
+      if (hipEventCreateWithFlags (&ready, hipEventDisableTiming) != hipSuccess)
+        ready = nullptr;
+      const int rs = ready ? schro::context_join_queues (d.ctx, ready) : SCHRO_HIP_EDEVICE;
       if (!rc)
         rc = rs;
+      // how many reference pictures of this device are in flight now (their events not yet reached)
+      while (!d.in_flight.empty () && hipEventQuery (d.in_flight.front ()) != hipErrorNotReady)
+        d.in_flight.pop_front ();
+      if (ready && !rs)
+        d.in_flight.push_back (ready);
+      in_flight = (int) d.in_flight.size ();
     }
     lock.lock ();
     d.current = nullptr;
-    if (rc && !s->first_error)
+    if (rc && rc != SCHRO_HIP_ESKIPPED && !s->first_error)
       s->first_error = rc;
+    if (rc == SCHRO_HIP_ESKIPPED)
+      s->skipped++;
+    if (in_flight > s->refs_in_flight_max)
+      s->refs_in_flight_max = in_flight;
     if (t.self) {
+      t.self->ready = ready;
+      t.self->failed = rc != 0;
       t.self->complete = true;
       release_if_unused (s, t.self);
     }
@@ -223,7 +302,8 @@ scheduler_new (const int *devices, int n_devices, bool virt)
   for (int k = 0; k < n_devices; k++) {
     s->devs[k].device = devices ? devices[k] : k;
     if (!virt) {
-      s->devs[k].ctx = schro_hip_context_new (s->devs[k].device);
+      // (not bound to this thread: the caller may own a context of its own; the workers bind theirs)
+      s->devs[k].ctx = schro::context_new_unbound (s->devs[k].device);
       if (!s->devs[k].ctx) {
         for (int j = 0; j < k; j++)
           schro_hip_context_free (s->devs[j].ctx);
@@ -289,6 +369,8 @@ schro_hip_scheduler_free (SchroHipScheduler * s)
   }
   for (auto & d:s->devs)
     d.thread.join ();
+  // (the caller's own domain binding, if it has one, is the caller's again afterwards)
+  SchroHipContext *mine = schro_hip_thread_bound ();
   for (auto & d:s->devs) {
     if (d.ctx) {
       (void) hipSetDevice (d.device);
@@ -297,7 +379,7 @@ schro_hip_scheduler_free (SchroHipScheduler * s)
       schro_hip_context_free (d.ctx);
     }
   }
-  schro_hip_thread_bind (nullptr);
+  schro_hip_thread_bind (mine);
   delete s;
 }
 
@@ -430,6 +512,24 @@ schro_hip_scheduler_moves (SchroHipScheduler * s)
     return 0;
   std::unique_lock < std::mutex > lock (s->mutex);
   return s->moves;
+}
+
+long
+schro_hip_scheduler_skipped (SchroHipScheduler * s)
+{
+  if (!s)
+    return 0;
+  std::unique_lock < std::mutex > lock (s->mutex);
+  return s->skipped;
+}
+
+int
+schro_hip_scheduler_refs_in_flight_max (SchroHipScheduler * s)
+{
+  if (!s)
+    return 0;
+  std::unique_lock < std::mutex > lock (s->mutex);
+  return s->refs_in_flight_max;
 }
 
 int

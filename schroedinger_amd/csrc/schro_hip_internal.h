@@ -88,6 +88,11 @@ struct UpsampleJob {
   int w, h;
   int tiles_x;
   int tile_base;
+  // r04: the V plane of a (U, V) pair whose half-pel samples are stored byte-interleaved (see the
+  // half-pel layout below); NULL: one plane
+  const uint8_t *src_b;
+  int src_b_stride;
+  int pad;
 };
 
 struct ObmcJob {
@@ -111,7 +116,11 @@ struct ObmcJob {
   // item kernel: everything that depends only on the plane's block geometry, worked out
   // on the host (obmc_item_geometry) instead of in every workgroup's prologue; m_* are
   // ceil (2^32 / d) for mdiv ()
-  int nseg, nch, lpi, item_bytes, ipw, chunk_cap;
+  // (ref_ps, ref_cb, r04: how a sample of this component lies in its half-pel planes -- a sample is
+  // 1 << ref_ps bytes wide and this component is byte ref_cb of it: 0, 0 one component per image; 1, c the
+  // U / V samples of a picture interleaved, see the half-pel layout below.  The struct stays 256 bytes: the
+  // kernels keep a copy in scalar registers.)
+  int nseg, ref_ps, lpi, ref_cb, ipw, chunk_cap;
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
   uint32_t m_xramp, m_yramp;    // ceil (2^32 / (2 * offset - 1)): get_ramp's division (schromotion.c:40-49)
   unsigned long long *stamps;   // scratch runs only (SCHRO_HIP_OBMC_STAMPS): per-workgroup phase stamps
@@ -125,6 +134,7 @@ struct ObmcJob {
   uint8_t *out_b;
   int residual_stride_b, out_stride_b;
 };
+static_assert (sizeof (ObmcJob) == 256, "ObmcJob: four 64-byte scalar loads");
 
 // One picture's slices (lowdelay.hip).
 struct SliceJob {
@@ -251,13 +261,22 @@ div_magic (int d)
 // 329-330) -- with the reference's sources (schroframe.c:2012-2029: planes 0 and 1 repeat plane
 // 0's edge, planes 2 and 3 plane 2's), which is the clamp of the half-pel column to [0, 2w - 2];
 // rows are clamped by the kernels.  `stride` = bytes per band of 4 rows = chunks * 512.
+//
+// r04 -- chroma as (U, V) pairs.  The U and V planes of a 4:2:0 / 4:2:2 picture have the same blocks,
+// vectors and sample windows; stored apart, every window was fetched twice (a 6 x 6 chroma window
+// touches 2.25 lines per tap and plane).  A PAIR image is the same layout over samples of two bytes
+// (U, V): byte column 2 * (column + kHpApron) + c of the plane row, chunks of 32 bytes = 16 byte
+// columns of advance = 8 samples, aprons of 2 * kHpApron bytes.  A block row of up to 8 samples plus
+// its X + 1 tap is a run of <= 18 bytes that starts at an even byte <= 14 of its chunk: the same one
+// load per tap as for a luma row, and it brings both components.  `ps` (sample shift: 0 plane, 1 pair)
+// and `cb` (byte of the sample) below select the form; widths in hp_chunks () are SAMPLES.
 constexpr int kHpApron = 32;
 constexpr int kHpBandRows = 4;
 
 __host__ __device__ __forceinline__ int
-hp_chunks (int w)
+hp_chunks (int w, int ps = 0)
 {
-  return (w + 2 * kHpApron + 15) / 16 + 1;
+  return (((w + 2 * kHpApron) << ps) + 15) / 16 + 1;
 }
 
 // padded column xp (= plane column + kHpApron) inside its band: chunk xp >> 4, byte xp & 15 (the
@@ -274,11 +293,12 @@ hp_row_offset (int y, int stride)
   return (size_t) (y >> 2) * (size_t) stride + (size_t) ((y & 3) * 32);
 }
 
-// byte offset of half-pel sample (X, Y), 0 <= X <= 2w - 1, 0 <= Y <= 2h - 1
+// byte offset of half-pel sample (X, Y), 0 <= X <= 2w - 1, 0 <= Y <= 2h - 1 (pair images: of its
+// component cb)
 __host__ __device__ __forceinline__ size_t
-hp_offset (int X, int Y, int stride)
+hp_offset (int X, int Y, int stride, int ps = 0, int cb = 0)
 {
-  return hp_row_offset (Y >> 1, stride) + hp_col_offset ((X >> 1) + kHpApron) + (size_t) (((X & 1) + 2 * (Y & 1)) * 128);
+  return hp_row_offset (Y >> 1, stride) + hp_col_offset ((((X >> 1) + kHpApron) << ps) + cb) + (size_t) (((X & 1) + 2 * (Y & 1)) * 128);
 }
 
 __device__ __forceinline__ int
@@ -367,7 +387,8 @@ void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t 
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order);
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
-int obmc_row_nd (const ObmcJob & job);
+int obmc_row_nd (const ObmcJob & job, bool uv);
+int obmc_row_tile_width (bool uv);
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
     int max_planes, const uint32_t * d_order);
 // fills the item-kernel geometry fields of a job (obmc.hip)
@@ -398,6 +419,7 @@ struct SchroHipContext {
   int cur;
   hipStream_t stream;
   hipEvent_t ev_begin, ev_end;
+  bool stage_complete;          // frame-layer stage calls wait for the selected queue before they return (default)
 
   // size-keyed allocation cache (schrodomain.c:58-137 semantics)
   struct Slot {

@@ -90,11 +90,16 @@ class DeviceFrame:
                   for k in range(3)]
         host = HostFrame(planes, f.format & 1, (f.format >> 1) & 1)
         if f.is_upsampled:      # copy the full half-pel images
-            for k in range(3):
+            for k in range(1 if f.is_upsampled == 2 else 3):
                 comp = f.components[k]
                 check(self.ctx.lib.schro_hip_upsampled_download(
                     self.ctx.h, planes[k].ctypes.data_as(C.c_void_p), planes[k].strides[0],
                     comp.data, comp.stride, comp.width, comp.height))
+            if f.is_upsampled == 2:     # the chroma components are one (U, V) pair image in components[1]
+                comp = f.components[1]
+                check(self.ctx.lib.schro_hip_upsampled_pair_download(
+                    self.ctx.h, planes[1].ctypes.data_as(C.c_void_p), planes[2].ctypes.data_as(C.c_void_p),
+                    planes[1].strides[0], comp.data, comp.stride, comp.width, comp.height))
             return planes
         check(self.ctx.lib.schro_hipframe_to_cpu(host.ptr(), self.p))
         return host.planes

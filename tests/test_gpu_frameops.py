@@ -127,3 +127,85 @@ def test_half_pel_planes_every_home_and_the_aprons(ctx, h, w):
             for c in range(nch):
                 got = raw[base + c * 512: base + c * 512 + 32]
                 assert np.array_equal(got, want[16 * c:16 * c + 32]), (p, y, c)
+
+
+# ---- r04: (U, V) pair images -------------------------------------------------------------------------
+
+def gpu_upsample_pair(ctx, pu, pv):
+    h, w = pu.shape
+    su, sv = ctx.upload(pu), ctx.upload(pv)
+    dst = ctx.hp_plane(h, w, pair=True).fill(0xa5)
+    ctx.upsample_batch([((su, sv), dst)])
+    hu, hv = dst.download()
+    for p in (su, sv, dst):
+        p.free()
+    return hu, hv
+
+
+def test_upsample_pair_small_sizes(ctx):
+    for h in list(range(1, 21)) + [33, 40]:
+        for w in (1, 2, 3, 7, 8, 9, 16, 20, 63, 64, 65, 96, 130):
+            pu = synth.picture_u8(h, w, seed=h * 97 + w, blur=False)
+            pv = synth.picture_u8(h, w, seed=h * 89 + w + 1, blur=False)
+            hu, hv = gpu_upsample_pair(ctx, pu, pv)
+            check_planes(hu, O.UpComp(pu))
+            check_planes(hv, O.UpComp(pv))
+
+
+@pytest.mark.parametrize("h,w", [(120, 160), (240, 160), (540, 960), (1080, 1920)])
+def test_upsample_pair_picture_sizes(ctx, h, w):
+    pu, pv = synth.picture_u8(h, w, seed=4), synth.picture_u8(h, w, seed=5)
+    hu, hv = gpu_upsample_pair(ctx, pu, pv)
+    check_planes(hu, O.UpComp(pu))
+    check_planes(hv, O.UpComp(pv))
+
+
+def test_upsample_pair_beside_single_planes(ctx):
+    # one launch with a luma plane and a chroma pair (what the frame layer sends), unaligned sources
+    big = synth.picture_u8(80, 200, seed=21, blur=False)
+    parent = ctx.upload(big)
+    y = synth.picture_u8(66, 140, seed=22)
+    sy, dy = ctx.upload(y), ctx.hp_plane(66, 140).fill(1)
+    su, sv = sa.SubPlane(parent, 1, 3, 33, 70), sa.SubPlane(parent, 40, 101, 33, 70)
+    dp = ctx.hp_plane(33, 70, pair=True).fill(2)
+    ctx.upsample_batch([(sy, dy), ((su, sv), dp)])
+    check_planes(dy.download(), O.UpComp(y))
+    hu, hv = dp.download()
+    check_planes(hu, O.UpComp(np.ascontiguousarray(big[1:34, 3:73])))
+    check_planes(hv, O.UpComp(np.ascontiguousarray(big[40:73, 101:171])))
+    for p in (parent, sy, dy, dp):
+        p.free()
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (5, 7), (16, 16), (33, 47), (64, 130), (135, 240), (270, 481)])
+def test_pair_images_every_home_and_the_aprons(ctx, h, w):
+    """The pair image byte by byte: the layout of test_half_pel_planes_every_home_and_the_aprons over samples of
+    two bytes (U, V) -- byte column 2 * (column + 32) + c, chunks of 32 bytes that advance by 16 byte columns,
+    aprons of 64 bytes either side (and to the end of the last chunk) that repeat the edge SAMPLE."""
+    pu, pv = synth.picture_u8(h, w, seed=h * 31 + w), synth.picture_u8(h, w, seed=h * 29 + w + 7)
+    su, sv, dst = ctx.upload(pu), ctx.upload(pv), ctx.hp_plane(h, w, pair=True).fill(0xa5)
+    ctx.upsample_batch([((su, sv), dst)])
+    ups = (O.UpComp(pu), O.UpComp(pv))
+    planes = [[up.plane(i) for i in range(4)] for up in ups]
+    raw = np.empty((1, dst.nbytes), np.uint8)
+    sa.check(ctx.lib.schro_hip_download_2d(ctx.h, raw.ctypes.data_as(C.c_void_p), dst.nbytes, dst.ptr, dst.nbytes,
+                                          dst.nbytes, 1))
+    raw = raw.reshape(-1)
+    stride = dst.stride
+    nch = stride // 512
+    assert nch == (2 * w + 128 + 15) // 16 + 1
+    for p in range(4):
+        for y in range(h):
+            cols = 16 * nch + 16
+            want = np.empty(cols, np.uint8)
+            for c in range(2):
+                edge_src = planes[c][0] if p < 2 else planes[c][2]
+                want[c:64:2] = edge_src[y, 0]
+                want[64 + c:64 + 2 * w:2] = planes[c][p][y]
+                want[64 + 2 * w + c::2] = edge_src[y, w - 1]
+            base = (y >> 2) * stride + p * 128 + (y & 3) * 32
+            for ch in range(nch):
+                got = raw[base + ch * 512: base + ch * 512 + 32]
+                assert np.array_equal(got, want[16 * ch:16 * ch + 32]), (p, y, ch)
+    for q in (su, sv, dst):
+        q.free()

@@ -23,36 +23,53 @@ def comp_size(w, h, k, chroma):
 
 
 def run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, mv_range, seed, res_dtype=np.int16,
-             modes=(0.05, 0.45, 0.15, 0.35), edit_mv=None):
+             modes=(0.05, 0.45, 0.15, 0.35), edit_mv=None, pair=False, only=None):
+    """pair: the chroma references are (U, V) PAIR images (include/schro_hip.h, r04) -- sub-pel precisions
+    of horizontally subsampled chroma only; only: the components whose planes are rendered (default all)."""
     P = synth.motion_params(w, h, xblen, xbsep, prec, weights, chroma)
     mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], mv_range, seed, modes)
     if edit_mv is not None:
         edit_mv(mv, P)
     op = O.MotionParams(**P)
     d_mv = ctx.upload_bytes(mv)
+    pair = pair and prec > 0 and chroma[0] == 1
     jobs, keep, want = [], [], []
+    refs_np = [[synth.picture_u8(*comp_size(w, h, k, chroma)[::-1], seed=seed + 10 * (r + 1) + k) for k in range(3)]
+               for r in range(2)]
+    pair_hp = []
+    if pair:
+        cw, ch = comp_size(w, h, 1, chroma)
+        for r in range(2):
+            pu, pv, g = ctx.upload(refs_np[r][1]), ctx.upload(refs_np[r][2]), ctx.hp_plane(ch, cw, pair=True)
+            ctx.upsample_batch([((pu, pv), g)])
+            pair_hp.append(g)
+            keep += [pu, pv, g]
     for k in range(3):
         cw, ch = comp_size(w, h, k, chroma)
-        r1 = synth.picture_u8(ch, cw, seed=seed + 10 + k)
-        r2 = synth.picture_u8(ch, cw, seed=seed + 20 + k)
+        r1, r2 = refs_np[0][k], refs_np[1][k]
         res = (synth.image_s(ch + 8, cw + 16, res_dtype, seed=seed + 30 + k).astype(np.int64) * 2
                ).astype(res_dtype)       # residual lives in the iwt-padded frame
+        if only is not None and k not in only:
+            continue
         u1, u2 = O.UpComp(r1, upsample=prec > 0), O.UpComp(r2, upsample=prec > 0)
         want.append(O.motion_render(mv, op, k, u1, u2, res, cw, ch))
         if prec == 0:
             g1, g2 = ctx.upload(r1), ctx.upload(r2)
+            keep += [g1, g2]
+        elif pair and k:
+            g1, g2 = pair_hp
         else:
             p1, p2 = ctx.upload(r1), ctx.upload(r2)
             g1, g2 = ctx.hp_plane(ch, cw), ctx.hp_plane(ch, cw)
             ctx.upsample_batch([(p1, g1), (p2, g2)])
-            keep += [p1, p2]
+            keep += [p1, p2, g1, g2]
         d_res = ctx.upload(res)
         out = ctx.plane(ch, cw, np.uint8).fill(0x33)
         jobs.append(sa.obmc_plane(d_mv, P, k, g1, g2, d_res, out))
-        keep += [g1, g2, d_res, out]
-        want[-1] = (want[-1], out)
+        keep += [d_res, out]
+        want[-1] = (want[-1], out, k)
     ctx.obmc_batch(jobs)
-    for k, (ref, out) in enumerate(want):
+    for ref, out, k in want:
         got = out.download()
         if not np.array_equal(got, ref):
             bad = np.argwhere(got != ref)
@@ -190,6 +207,79 @@ def test_rotating_references_in_a_batch(ctx):
             assert np.array_equal(out.download(), want), "rotation %d plane %d" % (rot, n)
 
 
+# ---- r04: chroma references as (U, V) pair images ---------------------------------------------------
+
+@pytest.mark.parametrize("chroma", [(1, 0), (1, 1)])
+@pytest.mark.parametrize("prec", [1, 2, 3])
+@pytest.mark.parametrize("blk", BLOCK_SETS)
+def test_pair_images_default_weights(ctx, blk, prec, chroma):
+    # half / quarter pel with chroma rows of up to 8 samples: the U and V planes as ONE job of the row kernel's
+    # UV form (one fetch per tap for both); 8/4 blocks (too many per tile), 24/16 (rows of 12 samples)
+    # and eighth pel: the item kernel reads each component out of the pair images
+    for mv_range, seed in ((3 << prec, 2), (80 << prec, 3)):
+        run_case(ctx, 96, 64, blk[0], blk[1], prec, (1, 1, 1), chroma, mv_range, seed, pair=True)
+
+
+@pytest.mark.parametrize("weights", [(3, 5, 3), (2, 3, 1), (3, -1, 1)])
+def test_pair_images_weighted_prediction(ctx, weights):
+    # other picture weights: the per-pixel kernel, per component out of the pair images
+    for prec in (2, 3):
+        run_case(ctx, 96, 64, 12, 8, prec, weights, (1, 1), 24 << prec, 5, pair=True)
+
+
+def test_pair_images_one_component_alone(ctx):
+    # a U or a V plane on its own (no partner next to it in the batch): read out of the pair images
+    for only in ((1,), (2,), (0, 2)):
+        for prec in (1, 2):
+            run_case(ctx, 160, 96, 12, 8, prec, (1, 1, 1), (1, 1), 24 << prec, 17, pair=True, only=only)
+
+
+def test_pair_images_edges_and_odd_cases(ctx):
+    # ragged picture sizes (tiles cut by the picture's right / bottom edge, chroma widths that are not a
+    # multiple of 8), DC values outside 8 bits (exact adds, per-sample rim path of the UV form), every single
+    # prediction mode, an s32 residual (plain finish), block geometries outside the standard sets
+    for (w, h) in [(100, 70), (97, 61), (64, 36), (130, 18), (72, 132), (260, 66)]:
+        run_case(ctx, w, h, 12, 8, 2, (1, 1, 1), (1, 1), 40, 7, pair=True)
+        run_case(ctx, w, h, 16, 12, 1, (1, 1, 1), (1, 0), 20, 8, pair=True)
+
+    def widen(mv, P):
+        dc_blocks = np.flatnonzero((mv["flags"] & 3) == 0)
+        vals = np.array([300, -400, 1000, -3000, 32767, -32768, 127 + 129, -129], np.int16)
+        for n, b in enumerate(dc_blocks[::5]):
+            mv["v"][b, :3] = vals[(n + np.arange(3)) % len(vals)]
+    for prec in (1, 2):
+        run_case(ctx, 320, 128, 12, 8, prec, (1, 1, 1), (1, 1), 8 << prec, 7, modes=(0.3, 0.3, 0.1, 0.3),
+                 edit_mv=widen, pair=True)
+    for modes in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)):
+        run_case(ctx, 96, 64, 12, 8, 2, (1, 1, 1), (1, 1), 64, 11, modes=modes, pair=True)
+    run_case(ctx, 96, 64, 12, 8, 2, (1, 1, 1), (1, 0), 64, 12, res_dtype=np.int32, pair=True)
+    for (blen, bsep) in [(32, 24), (20, 12), (8, 8), (16, 8), (24, 12), (4, 4), (16, 16)]:
+        for prec in (1, 2):
+            run_case(ctx, 192, 128, blen, bsep, prec, (1, 1, 1), (1, 1), 20 << prec, 13, pair=True)
+
+
+def test_pair_images_2160p_config(ctx):
+    # BASELINE config 3 as bench.py runs it: chroma from pair images
+    run_case(ctx, 3840, 2160, 12, 8, 2, (1, 1, 1), (1, 1), 64, 2, pair=True)
+
+
+def test_references_of_another_layout_are_refused(ctx):
+    # a plain plane or a one-component image where a pair image is declared (and the reverse) would be
+    # read out of bounds: the strides tell them apart
+    P = synth.motion_params(96, 64, 12, 8, 2, (1, 1, 1), (1, 1))
+    d_mv = ctx.upload_bytes(synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 8, 1))
+    res, out = ctx.plane(32, 48, np.int16), ctx.plane(32, 48, np.uint8)
+    single, pair_img, plain = ctx.hp_plane(32, 48), ctx.hp_plane(32, 48, pair=True), ctx.plane(32, 48, np.uint8)
+    job = sa.obmc_plane(d_mv, P, 1, single, single, res, out)
+    job.ref_pair = 1
+    with pytest.raises(sa.SchroHipError, match="not a half-pel image"):
+        ctx.obmc_batch([job])
+    with pytest.raises(sa.SchroHipError, match="not a half-pel image"):
+        ctx.obmc_batch([sa.obmc_plane(d_mv, P, 1, plain, plain, res, out)])
+    for p in (d_mv, res, out, single, pair_img, plain):
+        p.free()
+
+
 def test_item_kernel_parity_in_a_child_process():
     # obmc.hip's item kernel -- the second formulation of the default-weight case, the default for
     # plain and eighth-pel references only -- takes every case (SCHRO_HIP_OBMC_KERNEL=item, read
@@ -201,7 +291,8 @@ def test_item_kernel_parity_in_a_child_process():
     env = dict(os.environ, SCHRO_HIP_OBMC_KERNEL="item")
     here = os.path.abspath(__file__)
     p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
-                        "test_default_weights or test_dc_values or test_rotating"],
+                        "test_default_weights or test_dc_values or test_rotating or test_pair_images_default or "
+                        "test_pair_images_edges"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 

@@ -61,8 +61,12 @@ def test_inter_picture_through_stage_calls(ctx, hs, vs, prec, filt, depth):
             sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
             sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))   # second call is a no-op
             hp = u.download()
-            up0 = O.UpComp(refs_np[r][0])
-            assert np.array_equal(hp[0][1::2, 1::2], up0.plane(3))
+            # (chroma of 4:2:0 / 4:2:2 frames: one (U, V) pair image behind components[1], r04)
+            assert u.c.is_upsampled == (2 if hs else 1)
+            for k in range(3):
+                upk = O.UpComp(refs_np[r][k])
+                for pl in range(4):
+                    assert np.array_equal(hp[k][pl >> 1::2, pl & 1::2], upk.plane(pl)), (k, pl)
             refs.append(u)
         else:
             refs.append(d)

@@ -193,3 +193,84 @@ def test_a_reused_picture_number_is_a_new_reference():
     assert s.wait() == 0
     assert got == [0x51, 0x52]
     s.close()
+
+
+def test_a_failed_reference_skips_its_dependents_everywhere():
+    """r04: a reference whose function fails is complete -- nobody waits for it for
+    ever -- but FAILED: the pictures that predict from it, on its device and on others, and the pictures
+    that predict from those, do not run (SCHRO_HIP_ESKIPPED), as the reference decoder skips pictures whose
+    parse hit an error (picture->error, schrodecoder.c:1308-1311, :1399-1418).  Chains that do not touch the
+    failed picture are unaffected, and wait () reports the real error once."""
+    s = sa.Scheduler(2, virtual=True)
+    ran = []
+    lock = threading.Lock()
+
+    def ok(number):
+        def f(ctx, index):
+            with lock:
+                ran.append(number)
+            return 0
+        return f
+
+    def broken(ctx, index):
+        with lock:
+            ran.append("broken")
+        return -2                                       # SCHRO_HIP_EDEVICE
+
+    d0, _ = s.submit(0, [], True, broken)               # chain A's anchor fails
+    d1, _ = s.submit(100, [], True, ok(100))            # chain B is healthy
+    assert d0 != d1
+    s.submit(1, [0], True, ok(1))                       # P from the failed anchor: skipped, and fails in turn
+    s.submit(2, [0, 1], False, ok(2))                   # B between them: skipped
+    s.submit(3, [1], True, ok(3))                       # second generation: skipped
+    s.submit(101, [100], True, ok(101))
+    dev, foreign = s.submit(102, [100, 0], False, ok(102))      # across the chains, from the failed anchor: skipped
+    assert dev == d1 and foreign == 0
+    s.submit(103, [100, 101], False, ok(103))
+    assert s.wait() == -2
+    assert sorted(x for x in ran if x != "broken") == [100, 101, 103]
+    assert s.skipped() == 4
+    assert s.moves() == 0                               # nothing is moved for a picture that does not run
+    # a later, healthy chain on the same devices runs
+    s.submit(200, [], True, ok(200))
+    s.submit(201, [200], False, ok(201))
+    assert s.wait() == 0                                # (the error was reported once)
+    assert 201 in ran and s.skipped() == 4
+    s.close()
+
+
+def test_both_references_the_same_foreign_picture():
+    """refs = {n, n} is legal in Dirac: the foreign frame is moved ONCE (two copies were made and
+    the first leaked)."""
+    s = sa.Scheduler(2, virtual=True)
+    seen = {}
+
+    def ref(number):
+        def f(ctx, index):
+            s.publish_reference(index, 1000 + number)
+            return 0
+        return f
+
+    def twice(ctx, index):
+        seen["frames"] = (s.reference_frame(index, 7), s.reference_frame(index, 7))
+        return 0
+
+    d0, _ = s.submit(7, [], True, ref(7))
+    d1, _ = s.submit(50, [], True, ref(50))
+    assert d0 != d1
+    dev, foreign = s.submit(51, [50, 7], False, lambda c, i: 0)       # brings 7 over to d1 (one move)
+    assert dev == d1 and foreign == 7
+    s.wait()
+    assert s.moves() == 1
+    # a picture on d0's side whose two references are both picture 50
+    dev, foreign = s.submit(8, [7, 50], True, lambda c, i: 0)         # one more move: 50 -> d0
+    assert dev == d0
+    s.wait()
+    assert s.moves() == 2
+    dev, _ = s.submit(52, [50, 50], False, lambda c, i: 0)            # at home: nothing to move
+    s.wait()
+    assert s.moves() == 2
+    s.submit(9, [7], True, lambda c, i: 0)
+    s.retire(50)
+    s.wait()
+    s.close()
