@@ -422,6 +422,22 @@ class Context:
             a.codeblocks, a.ncodeblocks, a.is_intra = tab, len(cbs), 1 if intra else 0
         check(self.lib.schro_hip_dequant_batch(self.h, arr, n, jobs[0][0].dtype.itemsize, arith))
 
+    def _dequant_planes(self, jobs):
+        n = len(jobs)
+        arr = (_lib.DequantPlane * n)()
+        keep = []
+        for a, (dst, values, cbs, intra) in zip(arr, jobs):
+            tab = cbs if isinstance(cbs, C.Array) else self.codeblock_table(cbs)
+            keep.append(tab)
+            a.dst, a.values = dst.ptr, values.ptr if values is not None else None
+            a.codeblocks, a.ncodeblocks, a.is_intra = tab, len(cbs), 1 if intra else 0
+        return arr, keep
+
+    def dequant_plan(self, jobs, arith=0):
+        """schro_hip_dequant_plan_new over `jobs` (as dequant_batch takes them): the geometry of their codeblock
+        records, resident on the device.  plan.run(jobs) dequantises a batch with the same geometry."""
+        return DequantPlan(self, jobs, arith)
+
     def dc_predict_batch(self, planes):
         """In-place DC prediction of LL bands given as DevicePlanes (s16 / s32)."""
         n = len(planes)
@@ -473,13 +489,37 @@ def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
     p.ref1, p.ref1_stride = ref1.ptr, ref1.stride
     if ref2 is not None:
         p.ref2, p.ref2_stride = ref2.ptr, ref2.stride
-    p.residual, p.residual_stride = residual.ptr, residual.stride
-    p.residual_bpp = residual.dtype.itemsize
+    if residual is not None:        # None: nothing to add (a zero_residual picture)
+        p.residual, p.residual_stride = residual.ptr, residual.stride
+        p.residual_bpp = residual.dtype.itemsize
     p.out, p.out_stride = out.ptr, out.stride
     p.width, p.height = out.width, out.height
     p.ref_pair = 1 if getattr(ref1, "pair", False) else 0      # (U, V) pair images (HpPlane (pair=True))
     assert ref2 is None or bool(getattr(ref2, "pair", False)) == bool(p.ref_pair)
     return p
+
+
+class DequantPlan:
+    def __init__(self, ctx, jobs, arith=0):
+        self.ctx = ctx
+        arr, keep = ctx._dequant_planes(jobs)
+        self.h = ctx.lib.schro_hip_dequant_plan_new(ctx.h, arr, len(jobs), jobs[0][0].dtype.itemsize, arith)
+        if not self.h:
+            raise SchroHipError(ctx.lib.schro_hip_last_error().decode())
+
+    def planes(self, jobs):
+        """The C array of a batch (dst, values, C table, is_intra per component): build it once per frame pool."""
+        return self.ctx._dequant_planes(jobs)
+
+    def run(self, jobs=None, planes=None):
+        if planes is None:
+            planes = self.planes(jobs)
+        check(self.ctx.lib.schro_hip_dequant_plan_run(self.h, planes[0], len(planes[0])))
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.schro_hip_dequant_plan_free(self.h)
+            self.h = None
 
 
 class Scheduler:

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SCHRO_HIP_LIB") or os.path.join(_HERE, "libschro_hip.
 # every extern "C" symbol include/schro_hip.h declares
 EXPORTED_SYMBOLS = [
     "schro_hip_context_new", "schro_hip_context_free", "schro_hip_device_count",
-    "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind", "schro_hip_thread_bound", "schro_hip_context_set_stage_completion",
+    "schro_hip_last_error", "schro_hip_set_abort_on_error", "schro_hip_init", "schro_hip_thread_bind", "schro_hip_thread_bound", "schro_hip_context_set_stage_completion", "schro_hip_dequant_plan_new", "schro_hip_dequant_plan_run", "schro_hip_dequant_plan_free", "schro_hip_queue_mark_synchronize",
     "schro_hip_host_alloc", "schro_hip_host_free", "schro_hip_upload_2d_async", "schro_hip_download_2d_async",
     "schro_hip_queue_synchronize", "schro_hip_queue_set_cu_mask", "schro_memory_domain_new_hip_host", "schro_hip_codeblock_layout",
     "schro_frame_to_hip_async", "schro_hipframe_to_cpu_async", "schro_hip_frame_copy_to",
@@ -239,6 +239,14 @@ def load():
     L.schro_hip_thread_bind.restype = None
     L.schro_hip_thread_bound.argtypes = []
     L.schro_hip_thread_bound.restype = vp
+    L.schro_hip_dequant_plan_new.argtypes = [vp, vp, i, i, i]
+    L.schro_hip_dequant_plan_new.restype = vp
+    L.schro_hip_dequant_plan_run.argtypes = [vp, vp, i]
+    L.schro_hip_dequant_plan_run.restype = i
+    L.schro_hip_dequant_plan_free.argtypes = [vp]
+    L.schro_hip_dequant_plan_free.restype = None
+    L.schro_hip_queue_mark_synchronize.argtypes = [vp, i]
+    L.schro_hip_queue_mark_synchronize.restype = i
     L.schro_hip_context_set_stage_completion.argtypes = [vp, i]
     L.schro_hip_context_set_stage_completion.restype = i
     L.schro_hip_host_alloc.argtypes = [C.c_size_t]

@@ -84,8 +84,10 @@ push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
   return 0;
 }
 
+// ... in two steps, for a caller that builds the table in place: *host is the pinned mirror to fill with
+// `bytes` bytes, big_table_commit sends it
 int
-push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
+big_table_begin (SchroHipContext * ctx, size_t bytes, void **host, void **dev)
 {
   const int q = ctx->cur;
   ctx->big_turn[q] = (ctx->big_turn[q] + 1) % SchroHipContext::kBigTables;
@@ -108,16 +110,37 @@ push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **de
       SCHRO_HIP_CHECK (hipEventCreateWithFlags (&b.copied, hipEventDisableTiming));
     b.cap = cap;
   }
-  memcpy (b.h, host, bytes);
-  {
+  *host = b.h;
+  *dev = b.d;
+  return 0;
+}
+
+int
+big_table_commit (SchroHipContext * ctx, size_t bytes)
+{
+  SchroHipContext::BigTable & b = ctx->big_q[ctx->cur][ctx->big_turn[ctx->cur]];
+  static const bool dma = getenv ("SCHRO_HIP_TABLE_COPY") && !strcmp (getenv ("SCHRO_HIP_TABLE_COPY"), "dma");   // (experiment)
+  if (dma) {
+    SCHRO_HIP_CHECK (hipMemcpyAsync (b.d, b.h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
     const int r = launch_table_copy (ctx->stream, b.d, b.h, bytes);
     if (r)
       return r;
   }
   SCHRO_HIP_CHECK (hipEventRecord (b.copied, ctx->stream));
   b.pending = true;
-  *dev = b.d;
   return 0;
+}
+
+int
+push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
+{
+  void *mirror;
+  int r = big_table_begin (ctx, bytes, &mirror, dev);
+  if (r)
+    return r;
+  memcpy (mirror, host, bytes);
+  return big_table_commit (ctx, bytes);
 }
 
 int
@@ -808,6 +831,18 @@ schro_hip_queue_mark (SchroHipContext * ctx, int mark)
   if (!ctx->marks[mark])
     SCHRO_HIP_CHECK (hipEventCreateWithFlags (&ctx->marks[mark], hipEventDisableTiming));
   SCHRO_HIP_CHECK (hipEventRecord (ctx->marks[mark], ctx->stream));
+  return 0;
+}
+
+// the HOST waits for the latest recording of a mark (e.g. "picture k's download"): what a host that keeps
+// several pictures in flight calls before it hands picture k on, instead of draining a whole queue
+int
+schro_hip_queue_mark_synchronize (SchroHipContext * ctx, int mark)
+{
+  SCHRO_HIP_REQUIRE (ctx && mark >= 0 && mark < SchroHipContext::kMarks, "queue_mark_synchronize: mark %d out of range", mark);
+  if (!ctx->marks[mark])
+    return 0;                   // never recorded: nothing to wait for
+  SCHRO_HIP_CHECK (hipEventSynchronize (ctx->marks[mark]));
   return 0;
 }
 
@@ -1541,6 +1576,168 @@ schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * pla
     }
   }
   return flush ();
+}
+
+// ---- r04: dequantisation plans -- the host cost of a repeated picture geometry is O (planes) ----------
+// schro_hip_dequant_batch turns every codeblock record into a 48-byte job on the host, every call: 15 k records
+// per 8 x 2160p, 1.3 ms of a 2.3 ms PCIe-inclusive step (bench.py pcie_inclusive_quantised, r03).  But what a
+// decoder knows per picture GEOMETRY (schro_hip_codeblock_layout: rectangles, pitches -- and so the tiles of
+// the launch and which codeblock owns which) never changes; what its entropy decoder produces per PICTURE
+// (src_offset / src_bytes / quant_index of each record, the values) the kernel can read for itself.  A plan
+// is the first part, resident on the device; a run uploads the records as they are (24 bytes each, one copy
+// through a pinned mirror) and a line per plane.
+struct SchroHipDequantPlan {
+  SchroHipContext *ctx;
+  int bpp, arith;
+  int njobs, total_tiles;
+  size_t total_recs;
+  std::vector < int >ncb;       // records per plane
+  std::vector < SchroHipCodeblock > geo;        // the plan's copy of every record's geometry (checked per run)
+  void *d_geo;                  // DequantGeo[njobs] + the three first-tile index arrays
+};
+
+SchroHipDequantPlan *
+schro_hip_dequant_plan_new (SchroHipContext * ctx, const SchroHipDequantPlane * planes, int nplanes, int bytes_per_sample, int arith)
+{
+  if (!ctx || !planes || nplanes <= 0 || nplanes > 4096 || (bytes_per_sample != 2 && bytes_per_sample != 4)
+      || !(arith == 0 || (arith == 1 && bytes_per_sample == 2))) {
+    set_error (SCHRO_HIP_EINVAL, "dequant_plan_new: bad arguments");
+    return nullptr;
+  }
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  dequant_tile_geometry (&tw, &th);
+  SchroHipDequantPlan *plan = new SchroHipDequantPlan ();
+  plan->ctx = ctx;
+  plan->bpp = bytes_per_sample;
+  plan->arith = arith;
+  plan->d_geo = nullptr;
+  std::vector < DequantGeo > jobs;
+  int tile_base = 0;
+  size_t rec = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipDequantPlane & pl = planes[p];
+    if (!pl.codeblocks || pl.ncodeblocks <= 0) {
+      set_error (SCHRO_HIP_EINVAL, "dequant_plan_new: plane %d has no codeblock records", p);
+      delete plan;
+      return nullptr;
+    }
+    plan->ncb.push_back (pl.ncodeblocks);
+    for (int c = 0; c < pl.ncodeblocks; c++, rec++) {
+      const SchroHipCodeblock & cb = pl.codeblocks[c];
+      plan->geo.push_back (cb);
+      if (cb.width == 0 || cb.height == 0)
+        continue;               // (a sub-band narrower than its codeblock count: schrodecoder.c:3572-3588)
+      if (cb.width < 0 || cb.height < 0 || cb.dst_offset < 0 || cb.dst_offset % bytes_per_sample
+          || cb.dst_stride % bytes_per_sample || cb.dst_stride < cb.width * bytes_per_sample) {
+        set_error (SCHRO_HIP_EINVAL, "dequant_plan_new: plane %d codeblock %d: bad geometry", p, c);
+        delete plan;
+        return nullptr;
+      }
+      DequantGeo g;
+      g.dst_offset = cb.dst_offset;
+      g.dst_stride = cb.dst_stride;
+      g.w = cb.width;
+      g.h = cb.height;
+      g.tiles_x = div_up (cb.width, tw);
+      g.tile_base = tile_base;
+      g.plane = p;
+      g.rec = (int) rec;
+      tile_base += g.tiles_x * div_up (cb.height, th);
+      jobs.push_back (g);
+    }
+  }
+  plan->total_recs = rec;
+  plan->njobs = (int) jobs.size ();
+  plan->total_tiles = tile_base;
+  if (jobs.empty () || jobs.size () > ((size_t) 1 << 18)) {
+    set_error (SCHRO_HIP_EINVAL, "dequant_plan_new: %zu codeblocks (1 .. 2^18 per plan)", jobs.size ());
+    delete plan;
+    return nullptr;
+  }
+  // behind the jobs: their first tiles, every 64th and every 4096th of them (find_dequant_job's probes)
+  const size_t n = jobs.size (), n64 = (n + 63) / 64, n4096 = (n + 4095) / 4096;
+  const size_t bytes = sizeof (DequantGeo) * n + sizeof (int) * (n + n64 + n4096);
+  std::vector < char >table (bytes);
+  memcpy (table.data (), jobs.data (), sizeof (DequantGeo) * n);
+  int *index = (int *) (table.data () + sizeof (DequantGeo) * n);
+  for (size_t k = 0; k < n; k++)
+    index[k] = jobs[k].tile_base;
+  for (size_t k = 0; k < n64; k++)
+    index[n + k] = jobs[64 * k].tile_base;
+  for (size_t k = 0; k < n4096; k++)
+    index[n + n64 + k] = jobs[4096 * k].tile_base;
+  if (hipMalloc (&plan->d_geo, bytes) != hipSuccess
+      || hipMemcpy (plan->d_geo, table.data (), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    set_error (SCHRO_HIP_ENOMEM, "dequant_plan_new: %zu bytes of plan", bytes);
+    if (plan->d_geo)
+      (void) hipFree (plan->d_geo);
+    delete plan;
+    return nullptr;
+  }
+  return plan;
+}
+
+void
+schro_hip_dequant_plan_free (SchroHipDequantPlan * plan)
+{
+  if (!plan)
+    return;
+  (void) hipSetDevice (plan->ctx->device);
+  for (int q = 0; q < SchroHipContext::kQueues; q++)     // launches that still read the plan
+    (void) hipStreamSynchronize (plan->ctx->streams[q]);
+  (void) hipFree (plan->d_geo);
+  delete plan;
+}
+
+// planes: as given to schro_hip_dequant_plan_new, with this picture batch's dst / values pointers and
+// records -- the records' src_offset, src_bytes and quant_index are read (by the device); their geometry
+// must be the plan's
+int
+schro_hip_dequant_plan_run (SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes)
+{
+  SCHRO_HIP_REQUIRE (plan && planes && nplanes == (int) plan->ncb.size (), "dequant_plan_run: bad arguments");
+  SchroHipContext *ctx = plan->ctx;
+  (void) hipSetDevice (ctx->device);
+  const size_t rec_bytes = (plan->total_recs * sizeof (SchroHipCodeblock) + 15) & ~(size_t) 15;
+  const size_t bytes = rec_bytes + sizeof (DequantPlaneDyn) * (size_t) nplanes;
+  void *h, *d;
+  int r = big_table_begin (ctx, bytes, &h, &d);
+  if (r)
+    return r;
+  SchroHipCodeblock *recs = (SchroHipCodeblock *) h;
+  DequantPlaneDyn *dyn = (DequantPlaneDyn *) ((char *) h + rec_bytes);
+  size_t rec = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipDequantPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.dst && pl.codeblocks && pl.ncodeblocks == plan->ncb[p] && (uintptr_t) pl.dst % plan->bpp == 0,
+        "dequant_plan_run: plane %d does not match the plan", p);
+    memcpy (recs + rec, pl.codeblocks, sizeof (SchroHipCodeblock) * (size_t) pl.ncodeblocks);
+    // what the device will trust: geometry = the plan's, values addressable, quantiser in the tables
+    const SchroHipCodeblock *g = plan->geo.data () + rec, *c = pl.codeblocks;
+    unsigned bad = 0;
+    for (int k = 0; k < pl.ncodeblocks; k++) {
+      bad |= (unsigned) (c[k].dst_offset ^ g[k].dst_offset) | (unsigned) (c[k].dst_stride ^ g[k].dst_stride)
+          | (unsigned) (c[k].width ^ g[k].width) | (unsigned) (c[k].height ^ g[k].height);
+      const bool has = c[k].src_offset >= 0 && c[k].width > 0 && c[k].height > 0;
+      const unsigned sb = c[k].src_bytes;
+      bad |= has && !(pl.values && (sb == 1 || sb == 2 || sb == 4) && c[k].src_offset % (int) sb == 0);
+      bad |= c[k].quant_index > 60;
+    }
+    SCHRO_HIP_REQUIRE (!bad, "dequant_plan_run: plane %d: a record's geometry differs from the plan's, or its values are "
+        "not 1 / 2 / 4 bytes each and aligned, or its quant_index is above 60", p);
+    dyn[p].dst = pl.dst;
+    dyn[p].values = pl.values;
+    dyn[p].is_intra = pl.is_intra;
+    dyn[p].pad = 0;
+    rec += (size_t) pl.ncodeblocks;
+  }
+  r = big_table_commit (ctx, bytes);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_DEQUANT);
+  return launch_dequant_plan (ctx->stream, (const DequantGeo *) plan->d_geo, plan->njobs, plan->total_tiles,
+      (const SchroHipCodeblock *) d, (const DequantPlaneDyn *) ((const char *) d + rec_bytes), plan->bpp, plan->arith);
 }
 
 // The codeblock records of one component in the decoder's order: sub-band index 0 .. 3 * depth

@@ -46,6 +46,7 @@ make_quant_tables3 ()
   return t;
 }
 constexpr QuantTables3 kHostQuant = make_quant_tables3 ();
+static __device__ __constant__ QuantTables3 kDevQuant = make_quant_tables3 ();     // (plans: the kernel looks the quantiser up)
 
 template < typename T, int ARITH >
 __device__ __forceinline__ T
@@ -70,8 +71,9 @@ dequant_one (int32_t q, uint32_t factor, uint32_t offset)
 
 // which job owns tile `bid`: three probes of 64 lanes in the dense arrays of first tiles behind the
 // jobs (every 4096th job, every 64th of that run, the 64 of that run)
+template < typename JOB >
 __device__ __forceinline__ int
-find_dequant_job (const DequantJob * jobs, int njobs, int bid)
+find_dequant_job (const JOB * jobs, int njobs, int bid)
 {
   const int lane = threadIdx.x & 63;
   const int *first = reinterpret_cast < const int *>(jobs + njobs);
@@ -121,13 +123,11 @@ load_quads (const void *src, size_t s, int n, int32_t * q)
   }
 }
 
+// one tile of one codeblock (job: where it lies and what dequantises it)
 template < typename T, int ARITH >
-__global__ __launch_bounds__ (kDqThreads)
-void dequant_kernel (const DequantJob * __restrict__ jobs, int njobs)
+__device__ __forceinline__ void
+dequant_tile (const DequantJob & job, int t)
 {
-  const int bid = blockIdx.x;
-  const DequantJob job = jobs[find_dequant_job (jobs, njobs, bid)];
-  const int t = bid - job.tile_base;
   const int ty = t / job.tiles_x, tx = t - ty * job.tiles_x;
   const int x = tx * kDqTW + 4 * (threadIdx.x & 15), y0 = ty * kDqTH + (threadIdx.x >> 4);
   if (x >= job.w)
@@ -180,6 +180,41 @@ void dequant_kernel (const DequantJob * __restrict__ jobs, int njobs)
   }
 }
 
+template < typename T, int ARITH >
+__global__ __launch_bounds__ (kDqThreads)
+void dequant_kernel (const DequantJob * __restrict__ jobs, int njobs)
+{
+  const int bid = blockIdx.x;
+  const DequantJob job = jobs[find_dequant_job (jobs, njobs, bid)];
+  dequant_tile < T, ARITH > (job, bid - job.tile_base);
+}
+
+// r04 -- plans: the geometry comes from the plan's resident table, the per-picture part (does the codeblock
+// have values, where, how wide, which quantiser) from the decoder's own records as they were uploaded
+template < typename T, int ARITH >
+__global__ __launch_bounds__ (kDqThreads)
+void dequant_plan_kernel (const DequantGeo * __restrict__ geo, int njobs, const SchroHipCodeblock * __restrict__ recs,
+    const DequantPlaneDyn * __restrict__ planes)
+{
+  const int bid = blockIdx.x;
+  const DequantGeo g = geo[find_dequant_job (geo, njobs, bid)];
+  const DequantPlaneDyn pd = planes[g.plane];
+  const SchroHipCodeblock cb = recs[g.rec];
+  DequantJob job;
+  job.dst = (char *) pd.dst + g.dst_offset;
+  job.src = cb.src_offset < 0 ? nullptr : (const char *) pd.values + cb.src_offset;
+  job.dst_stride = g.dst_stride;
+  job.w = g.w;
+  job.h = g.h;
+  job.src_bytes = cb.src_bytes;
+  const int q = min ((int) cb.quant_index, 60);
+  job.factor = kDevQuant.factor[q];
+  job.offset = pd.is_intra ? kDevQuant.off12[q] : kDevQuant.off38[q];
+  job.tiles_x = g.tiles_x;
+  job.tile_base = g.tile_base;
+  dequant_tile < T, ARITH > (job, bid - g.tile_base);
+}
+
 }                               // namespace
 
 void
@@ -217,6 +252,22 @@ launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes)
   const hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "table copy launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+int
+launch_dequant_plan (hipStream_t stream, const DequantGeo * d_geo, int njobs, int total_tiles, const SchroHipCodeblock * d_recs,
+    const DequantPlaneDyn * d_planes, int bpp, int arith)
+{
+  if (bpp == 2 && arith == 1)
+    SCHRO_LAUNCH ((dequant_plan_kernel < int16_t, 1 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_geo, njobs, d_recs, d_planes);
+  else if (bpp == 2)
+    SCHRO_LAUNCH ((dequant_plan_kernel < int16_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_geo, njobs, d_recs, d_planes);
+  else
+    SCHRO_LAUNCH ((dequant_plan_kernel < int32_t, 0 >), dim3 (total_tiles), dim3 (kDqThreads), 0, stream, d_geo, njobs, d_recs, d_planes);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "dequant (plan) launch: %s", hipGetErrorString (e));
   return 0;
 }
 

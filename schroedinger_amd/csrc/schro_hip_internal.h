@@ -175,6 +175,24 @@ struct DequantJob {
   int tile_base;
 };
 
+// r04, dequantisation plans: what is fixed per picture geometry (device-resident) ...
+struct DequantGeo {
+  int dst_offset;               // bytes from the plane's base to the codeblock's first sample
+  int dst_stride;
+  int w, h;
+  int tiles_x;
+  int tile_base;
+  int plane;                    // index into the run's DequantPlaneDyn table
+  int rec;                      // index into the run's SchroHipCodeblock records
+};
+// ... and per run and plane (the records themselves go up as they are)
+struct DequantPlaneDyn {
+  void *dst;
+  const void *values;
+  int is_intra;
+  int pad;
+};
+
 constexpr int kMaxJobs = 256;
 
 // XCD-aware workgroup order.  The dispatcher deals workgroups round-robin over
@@ -380,6 +398,8 @@ int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsi
 // non-zero (the launch's epoch) once a dc_skew_kernel strip has given up waiting: reported by the next call
 int dc_gave_up (SchroHipContext * ctx);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
+int launch_dequant_plan (hipStream_t stream, const DequantGeo * d_geo, int njobs, int total_tiles,
+    const SchroHipCodeblock * d_recs, const DequantPlaneDyn * d_planes, int bpp, int arith);
 void dequant_tile_geometry (int *tw, int *th);
 int launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes);
 // schro_table_quant[i] and schro_table_offset_1_2[i] (intra) / _3_8[i] (inter)
@@ -507,6 +527,9 @@ int ensure_scratch (SchroHipContext * ctx, size_t bytes);
 // a device copy of a job table of any size, valid for the launches enqueued on the context's stream
 // before the fourth call from now on this queue
 int push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void **dev);
+// ... built in place: *host is the pinned mirror to fill, big_table_commit sends it
+int big_table_begin (SchroHipContext * ctx, size_t bytes, void **host, void **dev);
+int big_table_commit (SchroHipContext * ctx, size_t bytes);
 // the launches made while a scope is open are timed under its kernel class (when profiling is on)
 struct ProfileScope {
   ProfileScope (SchroHipContext * c, int cls);

@@ -36,7 +36,12 @@ def step(k):
     c.select_queue(k % 2)
     timed("wait_mark", c.queue_wait_mark, i)
     timed("wait_mark", c.queue_wait_mark, 12 + i)
-    timed("dequant", c.dequant_batch, [(dst, dev, tab, False) for dst, dev, tab in h.hand], 0)
+    if os.environ.get("SKIP_DEQUANT") == "1":
+        pass
+    elif os.environ.get("SCHRO_BENCH_DEQUANT_PLAN", "1") != "0":
+        timed("dequant (plan)", lambda: wl.dq_plan.run(planes=h.dq_planes))
+    else:
+        timed("dequant", c.dequant_batch, [(dst, dev, tab, False) for dst, dev, tab in h.hand], 0)
     timed("upsample", c.upsample_batch, b.up_pairs)
     timed("iiwt", c.iiwt_batch, b.iwt_pairs, bench.DEPTH, bench.FILTER)
     timed("obmc", c.obmc_batch, b.obmc_jobs)

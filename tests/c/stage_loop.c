@@ -1,0 +1,347 @@
+/* A C caller of the frame layer (include/schro_hip.h) that decodes a SEQUENCE of inter pictures the way a
+ * patched schrodecoder.c would, twice:
+ *
+ *   (i)  the reference's contract (schroasync-pthread.c:320-328): one picture at a time, one stage per call,
+ *        every call complete when it returns -- x_wavelet_transform (schrodecoder.c:1855-1886) ->
+ *        schro_frame_inverse_iwt_transform_hip with the HOST transform frame, x_upsample (:2120-2141) once per
+ *        reference, x_render_motion (:1697-1792) -> schro_motion_render_hip with the HOST vector array,
+ *        x_combine (:1888-2118) -> schro_hipframe_to_cpu;
+ *   (ii) INTEGRATION.md 3a: the same stage calls with stage completion OFF
+ *        (schro_hip_context_set_stage_completion), frames that cross the boundary in the pinned host domain
+ *        (schro_memory_domain_new_hip_host), three pictures in flight, each with its copies and stages in
+ *        order on a queue of its own; the host waits only for the download of the picture it hands on.
+ *
+ * Pictures: W x H 4:2:0, 3-level DD(9,7) residual, 12x12/8x8 quarter-pel OBMC from two references that change
+ * every 8 pictures (BASELINE config 3's shape; bench.py's workload).  Inputs are synthetic (an LCG, below);
+ * with DUMP = 1 the inputs and every decoded picture of both passes go to DIR for tests/test_gpu_c_harness.py
+ * to compare with the oracle.  Prints one JSON line.
+ *
+ *   stage_loop DIR W H NPICTURES DUMP */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+#include "schro_hip.h"
+
+#define CHECK(e) do { int r_ = (e); if (r_) { fprintf (stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #e, r_, schro_hip_last_error ()); exit (1); } } while (0)
+#define NSETS 4                 /* distinct coefficient frames / vector fields, used in turn */
+#define GROUP 8                 /* pictures that share a pair of references */
+#define DEPTH 3
+#define SLOTS 3                 /* pictures in flight in pass (ii) */
+
+static uint32_t lcg_state;
+static uint32_t
+lcg (void)
+{
+  lcg_state = lcg_state * 1103515245u + 12345u;
+  return lcg_state >> 16;
+}
+
+static double
+now_ms (void)
+{
+  struct timespec t;
+  clock_gettime (CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static void
+write_file (const char *dir, const char *name, int n, const void *p, size_t bytes)
+{
+  char path[1024];
+  snprintf (path, sizeof (path), name, dir, n);
+  FILE *f = fopen (path, "wb");
+  if (!f || fwrite (p, 1, bytes, f) != bytes) {
+    fprintf (stderr, "cannot write %s\n", path);
+    exit (2);
+  }
+  fclose (f);
+}
+
+/* schro_frame_new_and_alloc (domain, format, width, height) as the REFERENCE does it (schroframe.c:60-191,
+ * extension 0): strides ROUND_UP_16 (width * bytes), the three components back to back in ONE block from
+ * the domain's alloc table -- device frames from the HIP domain, pinned host frames from the host domain */
+static SchroHipFrame *
+domain_frame (SchroHipMemoryDomain * domain, int format, int bpp, int w, int h)
+{
+  SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+  const int hs = SCHRO_HIP_FORMAT_H_SHIFT (format), vs = SCHRO_HIP_FORMAT_V_SHIFT (format);
+  const int cw = (w + (1 << hs) - 1) >> hs, ch = (h + (1 << vs) - 1) >> vs;
+  int total = 0;
+  f->refcount = 1;
+  f->domain = (domain->flags & SCHRO_MEMORY_DOMAIN_HIP) ? domain : NULL;      /* host frames: domain NULL to this library */
+  f->format = format;
+  f->width = w;
+  f->height = h;
+  for (int k = 0; k < 3; k++) {
+    SchroHipFrameData *c = &f->components[k];
+    c->format = format;
+    c->width = k ? cw : w;
+    c->height = k ? ch : h;
+    c->stride = ((c->width * bpp) + 15) & ~15;
+    c->length = c->stride * c->height;
+    c->h_shift = k ? hs : 0;
+    c->v_shift = k ? vs : 0;
+    total += c->length;
+  }
+  f->regions[0] = domain->alloc (total);
+  if (!f->regions[0]) {
+    fprintf (stderr, "domain->alloc (%d) failed: %s\n", total, schro_hip_last_error ());
+    exit (1);
+  }
+  char *p = (char *) f->regions[0];
+  for (int k = 0; k < 3; k++) {
+    f->components[k].data = p;
+    p += f->components[k].length;
+  }
+  return f;
+}
+
+static size_t
+frame_bytes (const SchroHipFrame * f)
+{
+  return (size_t) f->components[0].length + f->components[1].length + f->components[2].length;
+}
+
+static uint32_t
+checksum (const SchroHipFrame * f)
+{
+  uint32_t h = 2166136261u;
+  for (int k = 0; k < 3; k++) {
+    const SchroHipFrameData *c = &f->components[k];
+    for (int y = 0; y < c->height; y++) {
+      const uint8_t *row = (const uint8_t *) c->data + (size_t) y * c->stride;
+      for (int x = 0; x < c->width; x += 7)     /* (a sample of the columns: the check is the test's, this is a tripwire) */
+        h = (h ^ row[x]) * 16777619u;
+    }
+  }
+  return h;
+}
+
+int
+main (int argc, char **argv)
+{
+  if (argc != 6) {
+    fprintf (stderr, "usage: %s DIR W H NPICTURES DUMP\n", argv[0]);
+    return 2;
+  }
+  const char *dir = argv[1];
+  const int w = atoi (argv[2]), h = atoi (argv[3]), npic = atoi (argv[4]), dump = atoi (argv[5]);
+  const int fmt8 = SCHRO_HIP_FORMAT_DEPTH_U8 | 3, fmt16 = SCHRO_HIP_FORMAT_DEPTH_S16 | 3;      /* 4:2:0 */
+  const int cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+  const int ngroups = (npic + GROUP - 1) / GROUP;
+  SchroHipParams params;
+  memset (&params, 0, sizeof (params));
+  /* schro_params_calculate_iwt_sizes (schroparams.c:75-92), schro_params_calculate_mc_sizes (:165-190) */
+  params.transform_depth = DEPTH;
+  params.wavelet_filter_index = 0;
+  params.iwt_luma_width = (w + 7) & ~7;
+  params.iwt_luma_height = (h + 7) & ~7;
+  params.iwt_chroma_width = (cw + 7) & ~7;
+  params.iwt_chroma_height = (ch + 7) & ~7;
+  params.num_refs = 2;
+  params.mv_precision = 2;
+  params.xblen_luma = params.yblen_luma = 12;
+  params.xbsep_luma = params.ybsep_luma = 8;
+  params.x_num_blocks = 4 * ((w + 4 * 8 - 1) / (4 * 8));
+  params.y_num_blocks = 4 * ((h + 4 * 8 - 1) / (4 * 8));
+  params.picture_weight_bits = 1;
+  params.picture_weight_1 = params.picture_weight_2 = 1;
+  const size_t nmv = (size_t) params.x_num_blocks * params.y_num_blocks;
+
+  schro_hip_init ();
+  SchroHipMemoryDomain *domain = schro_memory_domain_new_hip (0);
+  SchroHipMemoryDomain *host_domain = schro_memory_domain_new_hip_host ();
+  if (!domain || !host_domain) {
+    fprintf (stderr, "no HIP domain: %s\n", schro_hip_last_error ());
+    return 1;
+  }
+  SchroHipContext *ctx = schro_hip_domain_context (domain);
+
+  /* ---- inputs, in pinned host frames (pass (i) would work from pageable memory as well) ---- */
+  SchroHipFrame *h_coeffs[NSETS], *h_refs[2 * 64];
+  uint8_t *h_mvs[NSETS];
+  lcg_state = 1;
+  for (int s = 0; s < NSETS; s++) {
+    h_coeffs[s] = domain_frame (host_domain, fmt16, 2, params.iwt_luma_width, params.iwt_luma_height);
+    for (int k = 0; k < 3; k++) {
+      SchroHipFrameData *c = &h_coeffs[s]->components[k];
+      for (int y = 0; y < c->height; y++) {
+        int16_t *row = (int16_t *) ((char *) c->data + (size_t) y * c->stride);
+        for (int x = 0; x < c->width; x++) {
+          const uint32_t v = lcg ();
+          /* small detail coefficients, larger ones in the depth-3 LL band */
+          row[x] = (y % 8 == 0 && x < c->width / 8) ? (int16_t) (((v >> 6) & 0x3ff) - 512) : (int16_t) ((v & 0x3f) - 32);
+        }
+      }
+    }
+    /* SchroMotionVector records (schromotion.h:20-37): flags @0 (pred_mode in bits 0-1); @12 the union of
+     * dx[2], dy[2] and dc[3]; modes 5 / 45 / 15 / 35 %, vectors uniform in +-64 quarter pels */
+    h_mvs[s] = (uint8_t *) host_domain->alloc ((int) (20 * nmv));
+    memset (h_mvs[s], 0, 20 * nmv);
+    for (size_t b = 0; b < nmv; b++) {
+      const uint32_t r = lcg () % 100;
+      const uint32_t mode = r < 5 ? 0 : r < 50 ? 1 : r < 65 ? 2 : 3;
+      int16_t v[4];
+      for (int k = 0; k < 4; k++)
+        v[k] = mode ? (int16_t) ((int) (lcg () % 129) - 64) : (int16_t) ((int) (lcg () % 256) - 128);
+      memcpy (h_mvs[s] + 20 * b, &mode, 4);
+      memcpy (h_mvs[s] + 20 * b + 12, v, 8);
+    }
+  }
+  if (ngroups > 64)
+    return 2;
+  for (int r = 0; r < 2 * ngroups; r++) {
+    h_refs[r] = domain_frame (host_domain, fmt8, 1, w, h);
+    for (int k = 0; k < 3; k++) {
+      SchroHipFrameData *c = &h_refs[r]->components[k];
+      for (int y = 0; y < c->height; y++) {
+        uint8_t *row = (uint8_t *) c->data + (size_t) y * c->stride;
+        for (int x = 0; x < c->width; x++)
+          row[x] = (uint8_t) ((lcg () & 0x7f) + ((x + y + 16 * r) & 0x7f));     /* noise on a ramp */
+      }
+    }
+  }
+  if (dump) {
+    for (int s = 0; s < NSETS; s++) {
+      write_file (dir, "%s/coeffs%d.bin", s, h_coeffs[s]->regions[0], frame_bytes (h_coeffs[s]));
+      write_file (dir, "%s/mvs%d.bin", s, h_mvs[s], 20 * nmv);
+    }
+    for (int r = 0; r < 2 * ngroups; r++)
+      write_file (dir, "%s/ref%d.bin", r, h_refs[r]->regions[0], frame_bytes (h_refs[r]));
+  }
+
+  /* ---- device frames: SLOTS pictures' worth + two reference sets ---- */
+  SchroHipFrame *d_transform[SLOTS], *d_frame[SLOTS], *d_out[SLOTS], *h_out[SLOTS], *d_ref[2][2], *d_up[2][2];
+  void *d_mv[SLOTS];
+  for (int s = 0; s < SLOTS; s++) {
+    d_transform[s] = domain_frame (domain, fmt16, 2, params.iwt_luma_width, params.iwt_luma_height);
+    d_frame[s] = domain_frame (domain, fmt16, 2, params.iwt_luma_width, params.iwt_luma_height);
+    d_out[s] = domain_frame (domain, fmt8, 1, w, h);
+    h_out[s] = domain_frame (host_domain, fmt8, 1, w, h);
+    d_mv[s] = domain->alloc ((int) (20 * nmv));
+  }
+  for (int g = 0; g < 2; g++)
+    for (int r = 0; r < 2; r++) {
+      d_ref[g][r] = domain_frame (domain, fmt8, 1, w, h);
+      d_up[g][r] = schro_hip_frame_new_and_alloc (ctx, fmt8, w, h, 1);   /* (this library's tiled half-pel layout) */
+      if (!d_up[g][r])
+        return 1;
+    }
+  uint32_t *sums[2];
+  sums[0] = (uint32_t *) calloc (npic, 4);
+  sums[1] = (uint32_t *) calloc (npic, 4);
+  double ms[2];
+
+  /* ---- pass (i): the reference's contract ---- */
+  for (int rep = 0; rep < 2; rep++) {           /* (first repetition, untimed: warm-up -- job tables, allocator -- and the checks) */
+    CHECK (schro_hip_synchronize (ctx));
+    const double t0 = now_ms ();
+    for (int k = 0; k < npic; k++) {
+      const int g = k / GROUP, set = k % NSETS;
+      if (k % GROUP == 0)
+        for (int r = 0; r < 2; r++) {
+          /* a reference picture's ref_output_frame is on the device already in a decoder; here it comes from the host */
+          CHECK (schro_frame_to_hip (d_ref[g & 1][r], h_refs[2 * g + r]));
+          d_up[g & 1][r]->upsample_done = 0;
+          CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));        /* x_upsample */
+        }
+      CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[0], h_coeffs[set], &params));      /* x_wavelet_transform */
+      SchroHipMotion motion;
+      memset (&motion, 0, sizeof (motion));
+      motion.src1 = d_up[g & 1][0];
+      motion.src2 = d_up[g & 1][1];
+      motion.motion_vectors = h_mvs[set];
+      motion.params = &params;
+      CHECK (schro_motion_render_hip (&motion, NULL, d_frame[0], 1, d_out[0]));                /* x_render_motion */
+      CHECK (schro_hipframe_to_cpu (h_out[0], d_out[0]));                                      /* x_combine */
+      if (rep == 0) {
+        sums[0][k] = checksum (h_out[0]);
+        if (dump)
+          write_file (dir, "%s/out_contract%d.bin", k, h_out[0]->regions[0], frame_bytes (h_out[0]));
+      }
+    }
+    ms[0] = (now_ms () - t0) / npic;
+  }
+
+  /* ---- pass (ii): three pictures in flight, nothing waits but the hand-over of a finished picture ----
+   * One QUEUE per picture in flight: a picture's copies up, its stage calls and its copy down are enqueued
+   * in order on queue k % 3, so nothing of it depends on another queue (measured on this runtime: a
+   * hipMemcpyAsync whose queue waits for an event of ANOTHER queue blocks the calling thread until that
+   * event -- 0.68 ms per 2160p picture, the whole pipeline in lockstep).  Only the references
+   * cross queues: a mark, once per group of 8 pictures. */
+  enum { REFS = 0, DOWN = 12 };                 /* marks: REFS + (g & 1), DOWN + slot */
+  CHECK (schro_hip_context_set_stage_completion (ctx, 0));
+  double waited = 0, t_up = 0, t_stage = 0, t_down = 0;      /* where the host's time goes in the timed repetition */
+  for (int rep = 0; rep < 2; rep++) {
+    CHECK (schro_hip_synchronize (ctx));
+    waited = t_up = t_stage = t_down = 0;
+    const double t0 = now_ms ();
+    for (int k = 0; k < npic + SLOTS; k++) {
+      const int s = k % SLOTS;
+      if (k >= SLOTS) {
+        /* picture k - SLOTS leaves: the host waits for ITS download only */
+        const double tw = now_ms ();
+        CHECK (schro_hip_queue_mark_synchronize (ctx, DOWN + s));
+        waited += now_ms () - tw;
+        if (rep == 0) {
+          sums[1][k - SLOTS] = checksum (h_out[s]);
+          if (dump)
+            write_file (dir, "%s/out_pipelined%d.bin", k - SLOTS, h_out[s]->regions[0], frame_bytes (h_out[s]));
+        }
+      }
+      if (k >= npic)
+        continue;
+      const int g = k / GROUP, set = k % NSETS;
+      const double ta = now_ms ();
+      CHECK (schro_hip_context_select_queue (ctx, s));
+      if (k % GROUP == 0) {
+        /* new references (a decoder has them on the device already): up and upsampled on this picture's queue,
+         * behind the pictures of two groups back that read this reference set (all queues meet: no host wait) */
+        for (int o = 0; o < SLOTS; o++)
+          if (o != s)
+            CHECK (schro_hip_queue_wait (ctx, s, o));
+        for (int r = 0; r < 2; r++) {
+          CHECK (schro_frame_to_hip_async (d_ref[g & 1][r], h_refs[2 * g + r]));
+          d_up[g & 1][r]->upsample_done = 0;
+          CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));       /* x_upsample */
+        }
+        CHECK (schro_hip_queue_mark (ctx, REFS + (g & 1)));
+      } else if (k % GROUP < SLOTS) {
+        CHECK (schro_hip_queue_wait_mark (ctx, REFS + (g & 1)));       /* the other queues' first picture of the group */
+      }
+      /* the transform frame and the vectors up (pinned host memory), in order in front of the stages */
+      CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
+      CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
+      const double tb = now_ms ();
+      t_up += tb - ta;
+      CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[s], d_transform[s], &params));    /* x_wavelet_transform */
+      SchroHipMotion motion;
+      memset (&motion, 0, sizeof (motion));
+      motion.src1 = d_up[g & 1][0];
+      motion.src2 = d_up[g & 1][1];
+      motion.motion_vectors = d_mv[s];          /* already on the device */
+      motion.params = &params;
+      CHECK (schro_motion_render_hip (&motion, NULL, d_frame[s], 1, d_out[s]));               /* x_render_motion */
+      const double tc = now_ms ();
+      t_stage += tc - tb;
+      CHECK (schro_hipframe_to_cpu_async (h_out[s], d_out[s]));                               /* x_combine */
+      CHECK (schro_hip_queue_mark (ctx, DOWN + s));
+      t_down += now_ms () - tc;
+    }
+    CHECK (schro_hip_context_select_queue (ctx, 0));
+    CHECK (schro_hip_synchronize (ctx));
+    ms[1] = (now_ms () - t0) / npic;
+  }
+  int same = 1;
+  for (int k = 0; k < npic; k++)
+    same &= sums[0][k] == sums[1][k];
+  printf ("{\"width\": %d, \"height\": %d, \"pictures\": %d, \"contract_ms_per_picture\": %.4f, \"pipelined_ms_per_picture\": %.4f, "
+      "\"contract_Mpix_per_s\": %.1f, \"pipelined_Mpix_per_s\": %.1f, \"pictures_in_flight\": %d, \"passes_agree\": %s, "
+      "\"pipelined_host_ms_per_picture\": {\"waiting_for_a_finished_picture\": %.4f, \"enqueue_uploads\": %.4f, "
+      "\"enqueue_stages\": %.4f, \"enqueue_download\": %.4f}}\n", w, h, npic,
+      ms[0], ms[1], (double) w * h / ms[0] / 1e3, (double) w * h / ms[1] / 1e3, SLOTS, same ? "true" : "false",
+      waited / npic, t_up / npic, t_stage / npic, t_down / npic);
+  return same ? 0 : 3;
+}

@@ -63,3 +63,45 @@ def test_c_caller_decodes_an_inter_picture(tmp_path, w, h, chroma, prec, blk, fi
         got = out[o:o + ph * pw].reshape(ph, pw)
         o += ph * pw
         assert np.array_equal(got, want), "component %d picture" % k
+
+
+def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
+    """tests/c/stage_loop.c: a sequence of inter pictures through the frame layer (i) under the reference's
+    contract -- one picture at a time, every stage call complete on return, host frames and vectors -- and
+    (ii) pipelined as INTEGRATION.md 3a describes (stage completion off, pinned host frames, copy queues,
+    three pictures in flight, marks).  Every picture of both passes equals the oracle's.  (bench.py runs the
+    same program at 2160p for its frame_layer_2160p figures.)"""
+    import json
+    import schroedinger_amd as sa
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "c")])
+    exe = os.path.join(ROOT, "tests", "c", "_build", "stage_loop")
+    w, h, npic, depth, filt = 320, 192, 19, 3, 0
+    p = subprocess.run([exe, str(tmp_path), str(w), str(h), str(npic), "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["passes_agree"] and line["pictures"] == npic and line["pictures_in_flight"] == 3
+    P = synth.motion_params(w, h, 12, 8, 2, (1, 1, 1), (1, 1))
+    dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+
+    def planes(name, dtype):
+        a = np.fromfile(tmp_path / name, dtype)
+        out, o = [], 0
+        for (ph, pw) in dims:
+            out.append(a[o:o + ph * pw].reshape(ph, pw))
+            o += ph * pw
+        assert o == a.size
+        return out
+    coeffs = [planes("coeffs%d.bin" % s, np.int16) for s in range(4)]
+    mvs = [np.fromfile(tmp_path / ("mvs%d.bin" % s), sa.MV_DTYPE) for s in range(4)]
+    assert mvs[0].size == P["x_num_blocks"] * P["y_num_blocks"]
+    res = [[O.inverse_iwt(c, depth, filt) for c in cs] for cs in coeffs]
+    ngroups = -(-npic // 8)
+    ups = [[O.UpComp(pl) for pl in planes("ref%d.bin" % r, np.uint8)] for r in range(2 * ngroups)]
+    for k in range(npic):
+        g, s = k // 8, k % 4
+        want = [O.motion_render(mvs[s], O.MotionParams(**P), c, ups[2 * g][c], ups[2 * g + 1][c], res[s][c], dims[c][1], dims[c][0])
+                for c in range(3)]
+        for mode in ("contract", "pipelined"):
+            got = planes("out_%s%d.bin" % (mode, k), np.uint8)
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), (mode, k, c)

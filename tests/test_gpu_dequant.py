@@ -190,3 +190,74 @@ def test_whole_stream_from_quantised_values(ctx):
     # what crossed the host boundary instead of dense s16 coefficient frames
     print("quantised hand-over: %.1f %% of the dense coefficient bytes" % (100.0 * sent / dense))
     assert sent < dense / 2
+
+
+def test_a_plan_reused_over_different_pictures(ctx):
+    """r04: schro_hip_dequant_plan_* -- the codeblock GEOMETRY of a picture format lives on the device; a run
+    uploads the decoder's records as they are and the device reads src_offset / src_bytes / quant_index itself.
+    One plan, four pictures with different zero codeblocks, value widths, quantisers and values: each equals the
+    oracle (and schro_hip_dequant_batch); records whose geometry is not the plan's are refused."""
+    w, h, depth = 360, 208, 3
+    hc, vc = [1, 3, 4, 5], [1, 2, 3, 4]
+    for dtype, arith in ((np.int16, 0), (np.int16, 1), (np.int32, 0)):
+        itemsize = np.dtype(dtype).itemsize
+        planes = [ctx.plane(h, w, dtype).fill(0x5b) for _ in range(2)]
+        layout = ctx.codeblock_layout(w, h, depth, hc, vc, planes[0].stride, itemsize)
+        geo = [(t.dst_offset, t.dst_stride, t.width, t.height) for t in layout]
+
+        def picture(seed):
+            rng = np.random.default_rng(seed)
+            jobs, wants, keep = [], [], []
+            for pl, intra in zip(planes, (True, False)):
+                blob, cbs, off = [], [], 0
+                want = np.zeros((h, w), dtype)
+                for (dst_off, stride, cw, chh) in geo:
+                    if cw == 0 or chh == 0 or rng.random() < 0.3:
+                        cbs.append((dst_off, stride, cw, chh, -1, 0, int(rng.integers(0, 61))))
+                        continue
+                    sb = int(rng.choice([1, 2, 4]))
+                    qi = int(rng.integers(0, 40))
+                    lim = 100 if sb == 1 else 3000
+                    q = rng.integers(-lim, lim + 1, (chh, cw)).astype({1: np.int8, 2: np.int16, 4: np.int32}[sb])
+                    off = (off + 3) // 4 * 4
+                    cbs.append((dst_off, stride, cw, chh, off, sb, qi))
+                    blob.append((off, q))
+                    off += q.nbytes
+                    y0, xb = divmod(dst_off, pl.stride)
+                    step = stride // pl.stride          # the sub-band's rows lie 2^level frame rows apart
+                    O.dequant_codeblock(want[y0:y0 + chh * step:step, xb // itemsize:xb // itemsize + cw], q, qi, intra, arith)
+                raw = np.zeros((1, max(off, 4)), np.uint8)
+                for o, q in blob:
+                    raw[0, o:o + q.nbytes] = q.view(np.uint8).reshape(-1)
+                dev = ctx.upload(raw)
+                keep.append(dev)
+                jobs.append((pl, dev, cbs, intra))
+                wants.append(want)
+            return jobs, wants, keep
+        first, _, keep0 = picture(1)
+        plan = ctx.dequant_plan(first, arith)
+        for seed in (1, 2, 3, 4):
+            jobs, wants, keep = picture(seed)
+            for pl in planes:
+                pl.fill(0x5b)
+            plan.run(jobs)
+            got = [pl.download() for pl in planes]
+            for pl in planes:
+                pl.fill(0x3c)
+            ctx.dequant_batch(jobs, arith)
+            for k, pl in enumerate(planes):
+                assert np.array_equal(got[k], pl.download()), (dtype, arith, seed, k)
+            # (the oracle wrote only where codeblocks lie: compare there -- everything, the planes are covered)
+            for k in range(2):
+                assert np.array_equal(got[k], wants[k]), (dtype, arith, seed, k)
+            for d in keep:
+                d.free()
+        # a record with another geometry, a wild quantiser
+        jobs, _, keep = picture(9)
+        bad = list(jobs[0][2])
+        bad[3] = (bad[3][0], bad[3][1], bad[3][2] + 1) + tuple(bad[3][3:])
+        with pytest.raises(sa.SchroHipError, match="differs from the plan"):
+            plan.run([(jobs[0][0], jobs[0][1], bad, True), jobs[1]])
+        plan.free()
+        for p in planes + keep + keep0:
+            p.free()

@@ -182,3 +182,58 @@ def test_copy_out_of_deep_frames(ctx):
                 assert np.array_equal(out.download(), want), (dtype, hex(fmt), W, H)
                 out.unref()
             dev.unref()
+
+
+@pytest.mark.parametrize("hs,vs,prec", [(1, 1, 2), (1, 0, 1), (0, 0, 0), (1, 1, 3)])
+def test_zero_residual_picture_has_no_frame_to_add(ctx, hs, vs, prec):
+    """schrodecoder.c:1800, :1861, :1904-1906: a zero_residual picture runs no wavelet stage and its GPU paths
+    take the prediction as the combined frame.  schro_motion_render_hip (motion, NULL, NULL, TRUE, out) and a
+    plane-layer job without a residual: the prediction alone, clamped = the oracle's with a residual of zeros.
+    (r03 required a frame of zeros: 2 bytes per pixel uploaded and read for nothing.)"""
+    w, h = 208, 112
+    lib = ctx.lib
+    pd = dims(w, h, hs, vs)
+    P = synth.motion_params(w, h, 12, 8, prec, (1, 1, 1), (hs, vs))
+    params = frames.make_params(num_refs=2, **{k: P[k] for k in (
+        "xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma", "mv_precision", "picture_weight_bits",
+        "picture_weight_1", "picture_weight_2", "x_num_blocks", "y_num_blocks")})
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, seed=31)
+    fmt8 = frames.frame_format(np.uint8, hs, vs)
+    refs_np = [[synth.picture_u8(ph, pw, seed=70 + 10 * r + k) for k, (ph, pw) in enumerate(pd)] for r in range(2)]
+    refs = []
+    for r in range(2):
+        d = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(refs_np[r], hs, vs))
+        if prec > 0:
+            u = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+            sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
+            refs.append(u)
+        else:
+            refs.append(d)
+    out = frames.DeviceFrame(ctx, fmt8, w, h)
+    motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
+    sa.check(lib.schro_motion_render_hip(C.byref(motion), None, None, 1, out.ptr()))
+    got = out.download()
+    wants = []
+    for k, (ph, pw) in enumerate(pd):
+        wants.append(O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                                     O.UpComp(refs_np[1][k], upsample=prec > 0), np.zeros((ph, pw), np.int16), pw, ph))
+        assert np.array_equal(got[k], wants[k]), k
+    # the plane layer: residual NULL, with each of the kernels the precision / geometry selects
+    d_mv = ctx.upload_bytes(mv)
+    c = refs[0].c.components
+    jobs, outs = [], []
+    for k, (ph, pw) in enumerate(pd):
+        class V:
+            pass
+        views = []
+        for fr in refs:
+            v = V()
+            v.ptr, v.stride = fr.c.components[k].data, fr.c.components[k].stride
+            v.pair = k > 0 and fr.c.is_upsampled == 2
+            views.append(v)
+        o = ctx.plane(ph, pw, np.uint8).fill(9)
+        jobs.append(sa.obmc_plane(d_mv, P, k, views[0], views[1], None, o))
+        outs.append(o)
+    ctx.obmc_batch(jobs)
+    for k in range(3):
+        assert np.array_equal(outs[k].download(), wants[k]), k
