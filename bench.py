@@ -798,6 +798,8 @@ def main():
         alg_step = dict(alg_bytes)
         for k in ("iiwt_finest", "iiwt_coarse", "convert"):
             alg_step[k] = alg_bytes[k] * per_step.get(k, 1)
+        if not prof["iiwt_coarse"][1]:      # r04, the chain form: every level is in the one "iiwt_finest" launch
+            alg_step["iiwt_finest"] = int(4 * samples * (1 + 0.25 + 0.0625))
         kernels = {}
         for k, (ms, n) in prof.items():
             if n and k in alg_step:

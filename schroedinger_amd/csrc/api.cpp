@@ -119,7 +119,7 @@ int
 big_table_commit (SchroHipContext * ctx, size_t bytes)
 {
   SchroHipContext::BigTable & b = ctx->big_q[ctx->cur][ctx->big_turn[ctx->cur]];
-  static const bool dma = getenv ("SCHRO_HIP_TABLE_COPY") && !strcmp (getenv ("SCHRO_HIP_TABLE_COPY"), "dma");   // (experiment)
+  static const bool dma = SCHRO_ENV ("SCHRO_HIP_TABLE_COPY") && !strcmp (SCHRO_ENV ("SCHRO_HIP_TABLE_COPY"), "dma");   // (experiment)
   if (dma) {
     SCHRO_HIP_CHECK (hipMemcpyAsync (b.d, b.h, bytes, hipMemcpyHostToDevice, ctx->stream));
   } else {
@@ -173,6 +173,12 @@ dc_gave_up (SchroHipContext * ctx)
     return set_error (SCHRO_HIP_EDEVICE, "DC prediction launch %u: a strip gave up waiting for the strip above it (its band is incomplete)",
         epoch);
   }
+  if (ctx->dc_gave_up && ((volatile uint32_t *) ctx->dc_gave_up)[1]) {
+    const uint32_t epoch = ((volatile uint32_t *) ctx->dc_gave_up)[1];
+    ((volatile uint32_t *) ctx->dc_gave_up)[1] = 0;
+    return set_error (SCHRO_HIP_EDEVICE, "inverse wavelet launch %u: a tile gave up waiting for the level above it (its picture is incomplete)",
+        epoch);
+  }
   return 0;
 }
 
@@ -182,7 +188,7 @@ dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned
 {
   if (!ctx->dc_gave_up) {
     SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
-    *ctx->dc_gave_up = 0;
+    memset (ctx->dc_gave_up, 0, 64);
   }
   {
     const int r = dc_gave_up (ctx);
@@ -501,6 +507,11 @@ context_new_unbound (int device)
   }
   ctx->cur = 0;
   ctx->stage_complete = true;
+  memset (ctx->chain_slots, 0, sizeof (ctx->chain_slots));
+  memset (ctx->chain_ctrl, 0, sizeof (ctx->chain_ctrl));
+  memset (ctx->chain_ctrl_words, 0, sizeof (ctx->chain_ctrl_words));
+  memset (ctx->chain_ctrl_hash, 0, sizeof (ctx->chain_ctrl_hash));
+  memset (ctx->chain_runs, 0, sizeof (ctx->chain_runs));
   memset (ctx->marks, 0, sizeof (ctx->marks));
   ctx->arg_clock = 0;
   memset (ctx->arg_slots, 0, sizeof (ctx->arg_slots));
@@ -625,6 +636,12 @@ schro_hip_context_free (SchroHipContext * ctx)
     if (ctx->order_slots[k].copied)
       (void) hipEventDestroy (ctx->order_slots[k].copied);
   }
+  for (int k = 0; k < SchroHipContext::kChainSlots; k++)
+    if (ctx->chain_slots[k].d)
+      (void) hipFree (ctx->chain_slots[k].d);
+  for (int q = 0; q < SchroHipContext::kQueues; q++)
+    if (ctx->chain_ctrl[q])
+      (void) hipFree (ctx->chain_ctrl[q]);
   for (int k = 0; k < SchroHipContext::kArgSlots; k++)
     if (ctx->arg_slots[k].copied)
       (void) hipEventDestroy (ctx->arg_slots[k].copied);
@@ -978,6 +995,221 @@ iiwt_fused_group (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int np
   return launch_iiwt_fused (ctx->stream, d_jobs, nplanes, tile_base, filter, bpp, nl);
 }
 
+}                               // extern "C"
+
+// ---- r04: the chain form of the register wavelet: one launch for all levels (iiwt_reg.hip) -----------------
+// Builds the jobs (plane, level) with their producer / consumer links and counters, and the ONE order in which
+// the launch's workgroups take the tiles of all levels:
+//   * key of a tile = the first picture row (in level-0 pixels) of its output + a lag per level; a consumer's
+//     key is never below its producers' (the lag of level l - 1 is level l's plus the input rows a consumer tile
+//     reaches ahead, (RP - H) 2^l pixels), and inside a band of 64 pixel rows coarser levels come first: a
+//     topological order in which the coarse rows run just ahead of the finer rows they feed;
+//   * planes are dealt to eight lists (largest first to the shortest list) that are merged four tiles at a
+//     time: workgroup b -- XCD b mod 8 by the dispatcher's round robin -- mostly takes tiles of "its" planes,
+//     so the rows neighbouring tiles share (lifting halos) meet in one L2, and nothing depends across lists.
+// The order depends on the batch's geometry only: cached on the device by a hash of it (four slots per queue).
+template < typename JOBFN, typename SMALLFN >
+static int
+iiwt_chain (SchroHipContext * ctx, int nplanes, int depth, int filter, JOBFN level_job, SMALLFN level_is_small, int *done)
+{
+  *done = 0;
+  std::vector < IwtJob > jobs ((size_t) nplanes * depth);
+  std::vector < int >small (depth), RP (depth), UR (depth), Hh (depth);
+  for (int l = 0; l < depth; l++) {
+    int uc, ur, rmin;
+    small[l] = level_is_small (l) ? 1 : 0;
+    iiwt_reg_geometry (filter, small[l], &uc, &ur, &rmin);
+    UR[l] = ur;
+    Hh[l] = rmin - ur;
+    RP[l] = rmin + Hh[l];
+  }
+  int uc0, ur0, rmin0;
+  iiwt_reg_geometry (filter, 0, &uc0, &ur0, &rmin0);   // (the column geometry is the same for both forms)
+  int n_ctr = 0;
+  long n_tiles = 0;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h] (uint64_t v) {
+    for (int k = 0; k < 8; k++) {
+      h ^= (v >> (8 * k)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  mix ((uint64_t) filter | ((uint64_t) depth << 8) | ((uint64_t) nplanes << 16));
+  for (int p = 0; p < nplanes; p++)
+    for (int l = depth - 1; l >= 0; l--) {
+      bool src_al, dst_al;
+      IwtJob & j = jobs[(size_t) p * depth + l];
+      j = level_job (p, l, &src_al, &dst_al);
+      const int nc = j.w / 2, nr = j.h / 2;
+      if (!(src_al && dst_al && nc % 4 == 0 && nr >= RP[l] - Hh[l]))
+        return 0;               // some level of some plane needs another kernel: a launch per level
+      j.tiles_x = div_up (nc, uc0);
+      const int tiles_y = div_up (nr, UR[l]);
+      if ((long) j.tiles_x * tiles_y > 0xffff)
+        return 0;
+      j.tile_base = tiles_y;    // (no tile bases in this form: the field carries the job's tile rows to the order builder)
+      j.small = small[l];
+      if (l > 0) {
+        j.ctr = n_ctr;
+        n_ctr += tiles_y;
+      }
+      mix ((uint64_t) j.tiles_x);
+      if (l < depth - 1) {
+        const IwtJob & prod = jobs[(size_t) p * depth + l + 1];
+        j.dep_rows2 = 2 * UR[l + 1];
+        j.dep_tiles_y = prod.tile_base;
+        j.dep_tiles_x = prod.tiles_x;
+        j.dep_ctr = prod.ctr;
+      }
+      n_tiles += (long) j.tiles_x * tiles_y;
+      mix ((uint64_t) j.w | ((uint64_t) j.h << 20) | ((uint64_t) small[l] << 40));
+    }
+  if (jobs.size () > 0xffff || n_tiles > (1L << 24))
+    return 0;
+  (void) hipSetDevice (ctx->device);
+
+  // ---- the order, cached by geometry ----
+  constexpr int per_queue = SchroHipContext::kChainSlots / SchroHipContext::kQueues;
+  const int k0 = ctx->cur * per_queue;
+  SchroHipContext::ChainSlot * slot = nullptr, *lru = &ctx->chain_slots[k0];
+  for (int k = k0; k < k0 + per_queue; k++) {
+    SchroHipContext::ChainSlot & o = ctx->chain_slots[k];
+    if (o.d && o.hash == h && o.count == (size_t) n_tiles)
+      slot = &o;
+    if (o.last_use < lru->last_use)
+      lru = &o;
+  }
+  if (!slot) {
+    std::vector < long >lag (depth, 0);
+    for (int l = depth - 1; l >= 1; l--)
+      lag[l - 1] = lag[l] + (long) (RP[l - 1] - Hh[l - 1]) * (1L << l);
+    struct Key {
+      long band;
+      int level;
+      uint32_t entry;
+    };
+    // planes to lists: largest first to the shortest list
+    constexpr int kLists = 8;
+    std::vector < int >by_size (nplanes);
+    std::vector < long >plane_tiles (nplanes, 0);
+    for (int p = 0; p < nplanes; p++) {
+      by_size[p] = p;
+      for (int l = 0; l < depth; l++)
+        plane_tiles[p] += (long) jobs[(size_t) p * depth + l].tiles_x * jobs[(size_t) p * depth + l].tile_base;
+    }
+    std::stable_sort (by_size.begin (), by_size.end (),[&](int a, int b) { return plane_tiles[a] > plane_tiles[b]; });
+    std::vector < Key > lists[kLists];
+    long load[kLists] = { 0 };
+    for (int p : by_size) {
+      int best = 0;
+      for (int k = 1; k < kLists; k++)
+        if (load[k] < load[best])
+          best = k;
+      load[best] += plane_tiles[p];
+      for (int l = 0; l < depth; l++) {
+        const size_t ji = (size_t) p * depth + l;
+        const IwtJob & j = jobs[ji];
+        const int nr = j.h / 2, tiles_y = j.tile_base;
+        for (int ty = 0; ty < tiles_y; ty++) {
+          int r0 = ty * UR[l] - Hh[l];
+          if (r0 + Hh[l] + UR[l] > nr)
+            r0 = nr - UR[l] - Hh[l];
+          const long key = ((long) (2 * (r0 + Hh[l])) << l) + lag[l];
+          for (int tx = 0; tx < j.tiles_x; tx++)
+            lists[best].push_back (Key { key / 64, l, (uint32_t) (ji << 16) | (uint32_t) (ty * j.tiles_x + tx) });
+        }
+      }
+    }
+    // (experiments: SCHRO_HIP_IIWT_CHAIN_ORDER=band interleaves the levels band by band -- consumers right behind
+    // their producers: 8 x 2160p 0.218 ms against 0.104 for a launch per level, the waves in flight are mostly
+    // consumers polling; level-major hands out a level's tiles when the level above is long under way)
+    static const bool by_band = SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN_ORDER") && !strcmp (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN_ORDER"), "band");
+    for (auto & L : lists)
+      std::stable_sort (L.begin (), L.end (),[](const Key & a, const Key & b) {
+            if (by_band)
+              return a.band != b.band ? a.band < b.band : a.level > b.level;
+            return a.level != b.level ? a.level > b.level : a.band < b.band;
+          });
+    std::vector < uint32_t > order;
+    order.reserve ((size_t) n_tiles);
+    size_t at[kLists] = { 0 };
+    while (order.size () < (size_t) n_tiles)
+      for (int k = 0; k < kLists; k++)
+        for (int n = 0; n < 4 && at[k] < lists[k].size (); n++)
+          order.push_back (lists[k][at[k]++].entry);
+    slot = lru;
+    // (a slot's old table may still be read by launches in flight on this queue)
+    SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+    if (slot->cap < order.size ()) {
+      if (slot->d)
+        SCHRO_HIP_CHECK (hipFree (slot->d));
+      slot->d = nullptr;
+      slot->cap = 0;
+      const size_t cap = order.size () + order.size () / 4;
+      SCHRO_HIP_CHECK (hipMalloc ((void **) &slot->d, cap * sizeof (uint32_t)));
+      slot->cap = cap;
+    }
+    SCHRO_HIP_CHECK (hipMemcpy (slot->d, order.data (), order.size () * sizeof (uint32_t), hipMemcpyHostToDevice));
+    slot->hash = h;
+    slot->count = order.size ();
+  }
+  slot->last_use = ++ctx->arg_clock;
+
+  // ---- the give-up word; the counters of this queue: they count on from launch to launch of one geometry ----
+  if (!ctx->dc_gave_up) {
+    SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
+    memset (ctx->dc_gave_up, 0, 64);
+  }
+  const bool gave_up_before = ((volatile uint32_t *) ctx->dc_gave_up)[1] != 0;
+  {
+    const int r = dc_gave_up (ctx);
+    if (r) {
+      ctx->chain_ctrl_hash[ctx->cur] = 0;       // (the counters of the launch that gave up are short)
+      return r;
+    }
+  }
+  const size_t ctrl_words = (size_t) std::max (n_ctr, 1);
+  const int q = ctx->cur;
+  if (ctx->chain_ctrl_words[q] < ctrl_words) {
+    if (ctx->chain_ctrl[q]) {
+      SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+      SCHRO_HIP_CHECK (hipFree (ctx->chain_ctrl[q]));
+      ctx->chain_ctrl[q] = nullptr;
+      ctx->chain_ctrl_words[q] = 0;
+    }
+    const size_t cap = ctrl_words + ctrl_words / 2 + 64;
+    SCHRO_HIP_CHECK (hipMalloc ((void **) &ctx->chain_ctrl[q], cap * sizeof (uint32_t)));
+    ctx->chain_ctrl_words[q] = cap;
+    ctx->chain_ctrl_hash[q] = 0;
+  }
+  int max_tx = 1;
+  for (const auto & j : jobs)
+    max_tx = std::max (max_tx, j.tiles_x);
+  if (ctx->chain_ctrl_hash[q] != h || (uint64_t) (ctx->chain_runs[q] + 2) * (uint64_t) max_tx > 0x7fffffffull || gave_up_before) {
+    SCHRO_HIP_CHECK (hipMemsetAsync (ctx->chain_ctrl[q], 0, ctx->chain_ctrl_words[q] * sizeof (uint32_t), ctx->stream));
+    ctx->chain_ctrl_hash[q] = h;
+    ctx->chain_runs[q] = 0;
+  }
+  const uint32_t run = ++ctx->chain_runs[q];
+  if (++ctx->dc_epoch == 0)
+    ctx->dc_epoch = 1;          // (0 = "nothing gave up"; the DC kernel's tags are its own business: dc_edge_for)
+  for (auto & j : jobs)
+    j.tile_base = 0;
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (IwtJob) * jobs.size (), &d_jobs);
+  if (r)
+    return r;
+  {
+    ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
+    r = launch_iiwt_chain (ctx->stream, (const IwtJob *) d_jobs, slot->d, (int) n_tiles, ctx->chain_ctrl[q], run,
+        ctx->dc_gave_up + 1, ctx->dc_epoch, filter);
+  }
+  *done = 1;
+  return r;
+}
+
+extern "C" {
+
 int
 schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes,
     int depth, int filter, int bpp)
@@ -1009,7 +1241,9 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     }
     for (int l = 1; l < depth; l++) {
       int w = pl.width >> l, h = pl.height >> l;
-      int stride = (int) round_up ((size_t) w * bpp, 64);
+      // (whole 128-byte lines per row: in the chain form of the register kernels a consumer tile must never bring a
+      // line into its XCD's L2 that also holds samples of a row its producer has not written yet)
+      int stride = (int) round_up ((size_t) w * bpp, 128);
       scratch_off[(size_t) p * depth + l] = total;
       scratch_stride[(size_t) p * depth + l] = stride;
       total += round_up ((size_t) stride * h, 256);
@@ -1027,7 +1261,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   // per level: planes that allow it run the register form (iiwt_reg.hip), the rest the
   // LDS tile kernel; SCHRO_HIP_IIWT_REG=0 keeps everything on the LDS kernel
   const bool use_reg = iiwt_reg_supported (filter, bpp)
-      && !(getenv ("SCHRO_HIP_IIWT_REG") && atoi (getenv ("SCHRO_HIP_IIWT_REG")) == 0);
+      && !(SCHRO_ENV ("SCHRO_HIP_IIWT_REG") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_REG")) == 0);
   int ruc = 0, rur = 0, rmin = 0;
   if (use_reg)
     iiwt_reg_geometry (filter, 0, &ruc, &rur, &rmin);
@@ -1040,7 +1274,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   // register kernel), so nothing is fused by default.
   int fb = 0, nl = 0;
   {
-    const char *env = getenv ("SCHRO_HIP_IIWT_FUSE"), *envb = getenv ("SCHRO_HIP_IIWT_FUSE_BASE");
+    const char *env = SCHRO_ENV ("SCHRO_HIP_IIWT_FUSE"), *envb = SCHRO_ENV ("SCHRO_HIP_IIWT_FUSE_BASE");
     fb = envb ? atoi (envb) : (use_reg ? 1 : 0);
     fb = std::max (0, std::min (fb, depth - 1));
     int want = env ? atoi (env) : 0;
@@ -1059,7 +1293,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
 
   // s32 Haar levels (the low-delay 10-bit configurations): the element-wise form of iiwt_haar.hip
   const bool use_haar = iiwt_haar_supported (filter, bpp)
-      && !(getenv ("SCHRO_HIP_IIWT_HAAR") && atoi (getenv ("SCHRO_HIP_IIWT_HAAR")) == 0);
+      && !(SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR")) == 0);
   int hcols = 1, hrows = 1;
   if (use_haar)
     iiwt_haar_geometry (&hcols, &hrows);
@@ -1067,7 +1301,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   // r03: a depth-3 s32 Haar transform (the low-delay 10-bit configurations) is ONE pass over the
   // coefficient frame when every plane allows it (iiwt_haar.hip, iiwt_haar3_s32_kernel);
   // SCHRO_HIP_IIWT_HAAR3=0 keeps a launch per level
-  if (use_haar && depth == 3 && !nl && !(getenv ("SCHRO_HIP_IIWT_HAAR3") && atoi (getenv ("SCHRO_HIP_IIWT_HAAR3")) == 0)) {
+  if (use_haar && depth == 3 && !nl && !(SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3")) == 0)) {
     bool all_ok = true;
     for (int p = 0; p < nplanes && all_ok; p++)
       all_ok = iiwt_haar3_job_ok (planes[p].src, planes[p].src_stride, planes[p].dst, planes[p].dst_stride, planes[p].width,
@@ -1099,6 +1333,75 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     }
   }
 
+  // the job of (plane, level): the level view of the coefficient frame {w, h, stride << level}
+  // (schrodecoder.c:1834-1845), sub-band positions schroparams.c:319-352, LL from / output to the scratch
+  auto level_job = [&](int p, int level, bool * src_al_out, bool * dst_al_out) {
+    const SchroHipIwtPlane & pl = planes[p];
+    IwtJob j;
+    memset (&j, 0, sizeof (j));
+    int w = pl.width >> level, h = pl.height >> level;
+    const char *base = (const char *) pl.src;
+    int vstride = pl.src_stride << level;
+    const char *ll = base;
+    int ll_stride = vstride * 2;
+    if (level < depth - 1) {
+      ll = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level + 1];
+      ll_stride = scratch_stride[(size_t) p * depth + level + 1];
+    }
+    j.sb[0] = ll;
+    j.sb_stride[0] = ll_stride;
+    j.sb[1] = base + (size_t) (w / 2) * bpp;
+    j.sb_stride[1] = vstride * 2;
+    j.sb[2] = base + vstride;
+    j.sb_stride[2] = vstride * 2;
+    j.sb[3] = base + vstride + (size_t) (w / 2) * bpp;
+    j.sb_stride[3] = vstride * 2;
+    if (level == 0) {
+      j.dst = pl.dst;
+      j.dst_stride = pl.dst_stride;
+    } else {
+      j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level];
+      j.dst_stride = scratch_stride[(size_t) p * depth + level];
+    }
+    j.w = w;
+    j.h = h;
+    int nc = w / 2;
+    int vl = 8 / bpp;
+    bool src_al = (nc % vl) == 0 && nc >= vl;
+    for (int s = 0; s < 4; s++)
+      src_al = src_al && (((uintptr_t) j.sb[s] | (uintptr_t) j.sb_stride[s]) & 7) == 0;
+    bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
+    j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
+    j.ctr = -1;
+    *src_al_out = src_al;
+    *dst_al_out = dst_al;
+    return j;
+  };
+  // which tile form a level takes in the register kernels: a level of fewer tiles than the chip has SIMDs
+  // twice over is latency, not bandwidth -- the small form (4 useful row pairs per wave)
+  auto level_is_small = [&](int level) {
+    long tiles = 0;
+    for (int p = 0; p < nplanes; p++)
+      tiles += (long) div_up ((planes[p].width >> level) / 2, ruc) * div_up ((planes[p].height >> level) / 2, rur);
+    const char *env = SCHRO_ENV ("SCHRO_HIP_IIWT_SMALL");
+    const char *envb = SCHRO_ENV ("SCHRO_HIP_IIWT_SMALL_BELOW");
+    // (r03, SCHRO_HIP_IIWT_SMALL_BELOW: with 4096 the 3264-tile level -- 8 x 1080p's finest, 8 x 2160p's
+    // middle one -- takes the small form: alone 0.0381 -> 0.0351 ms, but 0.0263 -> 0.0322 with two batches in
+    // flight, and 0.002 ms of a 2160p step: left at 2048)
+    return env ? atoi (env) != 0 : tiles < (envb ? atol (envb) : 2048);
+  };
+
+  // r04: every level in ONE launch where all of them can take the register form (iiwt_reg.hip, chain form).
+  // Built as VERDICT r03 asked and measured: 8 x 2160p 0.135 ms against 0.103 for a launch per level (8 x 1080p
+  // 0.058 against 0.038) -- a tile's extra round trip to its producers' counters and the written-through LL
+  // stores cost more than the launch gaps they remove -- so it is opt-in: SCHRO_HIP_IIWT_CHAIN=1
+  if (use_reg && depth >= 2 && !nl && SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN")) != 0) {
+    int done = 0;
+    const int r = iiwt_chain (ctx, nplanes, depth, filter, level_job, level_is_small, &done);
+    if (r || done)
+      return r;
+  }
+
   std::vector < IwtJob > jobs, rjobs, hjobs;
   for (int level = depth - 1; level >= 0; level--) {
     if (nl && level >= fb && level < fb + nl) {
@@ -1113,61 +1416,16 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     jobs.clear ();
     rjobs.clear ();
     hjobs.clear ();
-    // a level of fewer register tiles than the chip has SIMDs twice over is latency, not
-    // bandwidth: use the small form (4 useful row pairs per wave)
     int lruc = ruc, lrur = rur, lrmin = rmin, small = 0;
     if (use_reg) {
-      long tiles = 0;
-      for (int p = 0; p < nplanes; p++)
-        tiles += (long) div_up ((planes[p].width >> level) / 2, ruc) * div_up ((planes[p].height >> level) / 2, rur);
-      const char *env = getenv ("SCHRO_HIP_IIWT_SMALL");
-      const char *envb = getenv ("SCHRO_HIP_IIWT_SMALL_BELOW");
-      // (r03, SCHRO_HIP_IIWT_SMALL_BELOW: with 4096 the 3264-tile level -- 8 x 1080p's finest, 8 x 2160p's
-      // middle one -- takes the small form: alone 0.0381 -> 0.0351 ms, but 0.0263 -> 0.0322 with two batches in
-      // flight, and 0.002 ms of a 2160p step: left at 2048)
-      small = env ? atoi (env) != 0 : tiles < (envb ? atol (envb) : 2048);
+      small = level_is_small (level);
       if (small)
         iiwt_reg_geometry (filter, 1, &lruc, &lrur, &lrmin);
     }
     for (int p = 0; p < nplanes; p++) {
-      const SchroHipIwtPlane & pl = planes[p];
-      IwtJob j;
-      int w = pl.width >> level, h = pl.height >> level;
-      // level view of the coefficient frame: {w, h, stride << level}
-      // (schrodecoder.c:1834-1845); sub-band positions schroparams.c:319-352
-      const char *base = (const char *) pl.src;
-      int vstride = pl.src_stride << level;
-      const char *ll = base;
-      int ll_stride = vstride * 2;
-      if (level < depth - 1) {
-        ll = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level + 1];
-        ll_stride = scratch_stride[(size_t) p * depth + level + 1];
-      }
-      j.sb[0] = ll;
-      j.sb_stride[0] = ll_stride;
-      j.sb[1] = base + (size_t) (w / 2) * bpp;
-      j.sb_stride[1] = vstride * 2;
-      j.sb[2] = base + vstride;
-      j.sb_stride[2] = vstride * 2;
-      j.sb[3] = base + vstride + (size_t) (w / 2) * bpp;
-      j.sb_stride[3] = vstride * 2;
-      if (level == 0) {
-        j.dst = pl.dst;
-        j.dst_stride = pl.dst_stride;
-      } else {
-        j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level];
-        j.dst_stride = scratch_stride[(size_t) p * depth + level];
-      }
-      j.w = w;
-      j.h = h;
-      int nc = w / 2, nr = h / 2;
-      int vl = 8 / bpp;
-      bool src_al = (nc % vl) == 0 && nc >= vl;
-      for (int s = 0; s < 4; s++)
-        src_al = src_al && (((uintptr_t) j.sb[s] | (uintptr_t) j.sb_stride[s]) & 7) == 0;
-      bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
-      j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
-      j.pad = 0;
+      bool src_al, dst_al;
+      IwtJob j = level_job (p, level, &src_al, &dst_al);
+      const int nc = j.w / 2, nr = j.h / 2;
       if (use_haar && iiwt_haar_job_ok (j)) {
         j.tiles_x = div_up (nc, hcols);
         j.tile_base = htile_base;
@@ -1506,7 +1764,7 @@ schro_hip_dequant_batch (SchroHipContext * ctx, const SchroHipDequantPlane * pla
   // pictures goes up as one copy (r03; through the 64 KB table slots it was a launch per 1365
   // codeblocks -- eleven launches of 20 us for 8 x 2160p)
   // (SCHRO_HIP_DEQUANT_PER_LAUNCH=1300: tables that fit the slots again, for A/B runs)
-  const char *env = getenv ("SCHRO_HIP_DEQUANT_PER_LAUNCH");
+  const char *env = SCHRO_ENV ("SCHRO_HIP_DEQUANT_PER_LAUNCH");
   const size_t kPerLaunch = env && atoi (env) > 0 ? std::min ((size_t) atoi (env), (size_t) 1 << 18) : (size_t) 1 << 18;
   std::vector < DequantJob > jobs;
   std::vector < char > table;
@@ -1951,7 +2209,7 @@ static int
 obmc_row_merge_mode ()
 {
   // 0: never, 1: where it pays (default), 2: always (the tests run the pair kernels on small pictures)
-  static const int mode = getenv ("SCHRO_HIP_OBMC_MERGE") ? atoi (getenv ("SCHRO_HIP_OBMC_MERGE")) : 1;
+  static const int mode = SCHRO_ENV ("SCHRO_HIP_OBMC_MERGE") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_MERGE")) : 1;
   return mode;
 }
 
@@ -1959,7 +2217,7 @@ static unsigned long long *g_stamps;
 static unsigned long long *
 obmc_stamp_buffer ()
 {
-  static const bool on = getenv ("SCHRO_HIP_OBMC_STAMPS") != nullptr;
+  static const bool on = SCHRO_ENV ("SCHRO_HIP_OBMC_STAMPS") != nullptr;
   if (on && !g_stamps) {
     if (hipMalloc ((void **) &g_stamps, 16384 * 16 * 8) != hipSuccess)
       g_stamps = nullptr;
@@ -2040,7 +2298,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     const uint32_t ** d_order)
 {
   *d_order = nullptr;
-  static const bool enabled = !getenv ("SCHRO_HIP_OBMC_ORDER") || atoi (getenv ("SCHRO_HIP_OBMC_ORDER")) != 0;
+  static const bool enabled = !SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER") || atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER")) != 0;
   if (!enabled || variant < 1 || jobs.empty () || jobs.size () > 0xffff)
     return 0;
   uint64_t h = 1469598103934665603ull;
@@ -2092,8 +2350,8 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     keys.reserve ((size_t) total);
     // (late r03: 4 x 4 tiles; with the residual and the picture streamed, 8 x 4 is 1 % behind -- 0.4106 against
     // 0.4056 ms per 8 x 2160p step --, 8 x 8 and 16 x 4 3 - 4 %)
-    static const int sup_x = getenv ("SCHRO_HIP_OBMC_SUPER_X") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_X"))) : 4;
-    static const int sup_y = getenv ("SCHRO_HIP_OBMC_SUPER_Y") ? std::max (1, atoi (getenv ("SCHRO_HIP_OBMC_SUPER_Y"))) : 4;
+    static const int sup_x = SCHRO_ENV ("SCHRO_HIP_OBMC_SUPER_X") ? std::max (1, atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_SUPER_X"))) : 4;
+    static const int sup_y = SCHRO_ENV ("SCHRO_HIP_OBMC_SUPER_Y") ? std::max (1, atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_SUPER_Y"))) : 4;
     for (size_t j = 0; j < jobs.size (); j++) {
       // (a U + V pair reads two planes of each reference: half the width; pairs from pair images -- variant 4,
       // tiles of 64 x 32 chroma pixels -- cover the picture area of a luma tile twice as high: half the height)
@@ -2196,7 +2454,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   // default weights, half- / quarter-pel references and blocks up to 16 wide: the row kernel
   // (obmc_row.hip); SCHRO_HIP_OBMC_KERNEL=item sends them to obmc.hip's item kernel (A/B runs: the
   // second formulation the parity tests compare)
-  static const bool use_row = !getenv ("SCHRO_HIP_OBMC_KERNEL") || strcmp (getenv ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
+  static const bool use_row = !SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL") || strcmp (SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
   std::vector < ObmcJob > all (nplanes);
   std::vector < int >key (nplanes), row_nd (nplanes);
   for (int p = 0; p < nplanes; p++) {

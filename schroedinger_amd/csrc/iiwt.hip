@@ -818,10 +818,17 @@ iiwt_fused_job_size (void)
   return sizeof (IwtFusedJob);
 }
 
+// (the LDS-fused group is a measured-slower form: built into the experiments library only, schro_hip_internal.h)
 int
 iiwt_fused_max_levels (int filter, int bpp)
 {
+#ifdef SCHRO_HIP_EXPERIMENTS
   return bpp == 2 ? fused_levels_of < int16_t > (filter) : fused_levels_of < int32_t > (filter);
+#else
+  (void) filter;
+  (void) bpp;
+  return 0;
+#endif
 }
 
 // fills one fused job (host side); levels 0 .. nl-1 of `src` are fused, `ll` is the LL
@@ -857,9 +864,14 @@ int
 launch_iiwt_fused (hipStream_t stream, const void *d_jobs, int njobs, int total_tiles, int filter,
     int bpp, int nl)
 {
+#ifdef SCHRO_HIP_EXPERIMENTS
   if (bpp == 2)
     return launch_fused_filter < int16_t > (stream, d_jobs, njobs, total_tiles, filter, nl);
   return launch_fused_filter < int32_t > (stream, d_jobs, njobs, total_tiles, filter, nl);
+#else
+  (void) stream, (void) d_jobs, (void) njobs, (void) total_tiles, (void) filter, (void) bpp, (void) nl;
+  return set_error (SCHRO_HIP_EUNSUPPORTED, "the LDS-fused wavelet group is built into the experiments library only");
+#endif
 }
 
 }                               // namespace schro

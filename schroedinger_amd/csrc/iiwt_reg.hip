@@ -41,11 +41,23 @@
 namespace schro {
 namespace {
 
-#ifdef SCHRO_IIWT_NT_LOAD         // (scratch builds: the coefficients, read once (+ halo), as streaming loads)
-#define IWT_LOAD8(p) __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x2 *) (p))
-#else
 #define IWT_LOAD8(p) gload < u32x2 > (p)
-#endif
+
+
+// r04, the chain form (below): the intermediate LL images are written by one workgroup and read by others
+// of the SAME launch, possibly on another XCD (each XCD has its own L2).  The STORES are agent-scope atomics
+// (relaxed: global_store ... sc1, written through to the memory side); the loads are ordinary: a consumer reads
+// a line of an LL image only after the whole producer tile rows that hold it have counted themselves done --
+// the images' rows are whole 128-byte lines (api.cpp) -- so no cache of its XCD can hold an older copy from
+// this launch, and every launch starts with clean caches.
+// (Loads as agent-scope atomics too -- no argument needed -- cost the transform of 8 x 2160p 0.03 ms.)
+
+__device__ __forceinline__ void
+coh_store16 (char *p, u32x4 o)
+{
+  __hip_atomic_store ((SCHRO_GLOBAL uint64_t *) p, (uint64_t) o.x | ((uint64_t) o.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store ((SCHRO_GLOBAL uint64_t *) (p + 8), (uint64_t) o.z | ((uint64_t) o.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 typedef short s16x2 __attribute__ ((ext_vector_type (2)));
 typedef uint32_t P;             // two packed s16 samples
@@ -254,7 +266,8 @@ out_round_pk (P x)
 }
 
 // all horizontal steps of one row, then round + interleave + one 16-byte store
-template < int F, bool HEDGE >
+// (COH bit 1: the row belongs to an intermediate LL image of the chain form)
+template < int F, bool HEDGE, int COH >
 __device__ __forceinline__ void
 finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst)
 {
@@ -272,18 +285,25 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
   o.y = __builtin_amdgcn_perm (b0, a0, 0x07060302u);
   o.z = __builtin_amdgcn_perm (b1, a1, 0x05040100u);
   o.w = __builtin_amdgcn_perm (b1, a1, 0x07060302u);
-  if (store_lane)
-#ifdef SCHRO_IIWT_NT_STORE        // (scratch builds: streaming stores for the transform's output)
-    __builtin_nontemporal_store (o, (SCHRO_GLOBAL u32x4 *) dst);
-#else
-    gstore < u32x4 > (dst, o);
-#endif
+  if (store_lane) {
+    if constexpr ((COH & 2) != 0)
+      coh_store16 (dst, o);
+    else
+      gstore < u32x4 > (dst, o);
+  }
 }
 
 // LO..HI: region row pairs that exist in the picture (compile-time: see the header)
-template < int F, int RP, int LO, int HI, bool HEDGE >
+// COH (chain form): bit 0 the LL band is another tile's output of this launch, bit 1 so is this tile's output
+struct NoWait {
+  struct Seen { };
+  __device__ __forceinline__ Seen ask () const { return Seen (); }
+  __device__ __forceinline__ void settle (Seen) const { }
+};
+
+template < int F, int RP, int LO, int HI, bool HEDGE, int COH = 0, typename WAIT = NoWait >
 __device__ __forceinline__ void
-reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
+reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane, WAIT wait = WAIT ())
 {
   constexpr int H = filter_halo (F);
   P E[RP][4], O[RP][4];
@@ -291,14 +311,15 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
   const int cl = c0 + 4 * lane;
   const uint32_t voff = (uint32_t) clampi (cl, 0, nc - 4) * 2u;
   constexpr Rng le = load_rows < F, RP, LO, HI > (0), lo = load_rows < F, RP, LO, HI > (1);
+  // (chain form) ask how far the tiles that produce this tile's LL rows are, then load the detail bands -- they
+  // come from the coefficient frame whatever the level above is doing --, then look at the answer (loads return
+  // in order: it is there while the ~36 detail loads are still in flight), then load LL
+  const auto seen = wait.ask ();
 #pragma unroll
   for (int k = 0; k < RP; k++) {
     const int r = clampi (r0 + k, 0, nr - 1);
     if (k >= le.lo && k <= le.hi) {
-      const u32x2 ll = IWT_LOAD8 ((const char *) job.sb[0] + (size_t) r * job.sb_stride[0] + voff);
       const u32x2 hl = IWT_LOAD8 ((const char *) job.sb[1] + (size_t) r * job.sb_stride[1] + voff);
-      E[k][0] = ll.x;
-      E[k][1] = ll.y;
       E[k][2] = hl.x;
       E[k][3] = hl.y;
     }
@@ -309,6 +330,16 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
       O[k][1] = lh.y;
       O[k][2] = hh.x;
       O[k][3] = hh.y;
+    }
+  }
+  wait.settle (seen);
+#pragma unroll
+  for (int k = 0; k < RP; k++) {
+    const int r = clampi (r0 + k, 0, nr - 1);
+    if (k >= le.lo && k <= le.hi) {
+      const u32x2 ll = IWT_LOAD8 ((const char *) job.sb[0] + (size_t) r * job.sb_stride[0] + voff);
+      E[k][0] = ll.x;
+      E[k][1] = ll.y;
     }
   }
 
@@ -326,22 +357,59 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
   char *dst = (char *) job.dst + (size_t) (2 * (r0 + H)) * job.dst_stride + (size_t) cl * 4;
 #pragma unroll
   for (int i = H; i < RP - H; i++) {
-    finish_row < F, HEDGE > (E[i], is_first, is_last, store_lane, dst);
-    finish_row < F, HEDGE > (O[i], is_first, is_last, store_lane, dst + job.dst_stride);
+    finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst);
+    finish_row < F, HEDGE, COH > (O[i], is_first, is_last, store_lane, dst + job.dst_stride);
     dst += 2 * (size_t) job.dst_stride;
   }
 }
 
 // tiles whose last N region row pairs lie below the picture
-template < int F, int RP, int N >
+template < int F, int RP, int N, int COH, typename WAIT >
 __device__ __forceinline__ void
-reg_tile_bottom (int nout, const IwtJob & job, int r0, int c0, int nr, int nc, int lane)
+reg_tile_bottom (int nout, const IwtJob & job, int r0, int c0, int nr, int nc, int lane, WAIT wait)
 {
   if constexpr (N >= 1) {
     if (nout == N)
-      reg_tile < F, RP, 0, RP - 1 - N, true > (job, r0, c0, nr, nc, lane);
+      reg_tile < F, RP, 0, RP - 1 - N, true, COH, WAIT > (job, r0, c0, nr, nc, lane, wait);
     else
-      reg_tile_bottom < F, RP, N - 1 > (nout, job, r0, c0, nr, nc, lane);
+      reg_tile_bottom < F, RP, N - 1, COH, WAIT > (nout, job, r0, c0, nr, nc, lane, wait);
+  }
+}
+
+// Row placement of tile (tx, ty): it produces row pairs [ty UR, ty UR + UR); the last one is moved up
+// to end at the picture's last row pair (it recomputes rows of the tile above: same values).  The top
+// tile has its H halo row pairs above the picture; a tile near the bottom has nout = 0 .. H of its row
+// pairs below it.  Both are compile-time cases.
+template < int F, int RP >
+__device__ __forceinline__ int
+reg_tile_r0 (int ty, int nr)
+{
+  constexpr int H = filter_halo (F), UR = RP - 2 * H;
+  int r0 = ty * UR - H;
+  if (r0 + H + UR > nr)
+    r0 = nr - UR - H;           // nr >= UR + H (host side)
+  return r0;
+}
+
+template < int F, int RP, int COH, typename WAIT = NoWait >
+__device__ __forceinline__ void
+reg_tile_at (const IwtJob & job, int tx, int ty, int lane, WAIT wait = WAIT ())
+{
+  constexpr int H = filter_halo (F);
+  const int nr = job.h >> 1, nc = job.w >> 1;
+  const int r0 = reg_tile_r0 < F, RP > (ty, nr);
+  const int nout = max (0, r0 + RP - nr);
+  const int c0 = tx * kRegUC - 4;
+  const bool hedge = c0 < 0 || c0 + 256 > nc;
+  if (r0 < 0) {
+    reg_tile < F, RP, H, RP - 1, true, COH, WAIT > (job, r0, c0, nr, nc, lane, wait);
+  } else if (nout == 0) {
+    if (!hedge)
+      reg_tile < F, RP, 0, RP - 1, false, COH, WAIT > (job, r0, c0, nr, nc, lane, wait);
+    else
+      reg_tile < F, RP, 0, RP - 1, true, COH, WAIT > (job, r0, c0, nr, nc, lane, wait);
+  } else {
+    reg_tile_bottom < F, RP, H, COH, WAIT > (nout, job, r0, c0, nr, nc, lane, wait);
   }
 }
 
@@ -358,7 +426,6 @@ template < int F, int RP >
 __global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES (F, RP), IIWT_REG_WAVES (F, RP))))
 void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)
 {
-  constexpr int H = filter_halo (F), UR = RP - 2 * H;
   const int wg = xcd_tile_id (blockIdx.x, gridDim.x);
   // the wave index is uniform, but only readfirstlane tells the compiler: with it the tile
   // origin, row addresses and edge tests live in SGPRs and branch on SCC
@@ -368,28 +435,7 @@ void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_til
   const int lane = threadIdx.x & 63;
   const IwtJob job = jobs[find_job (jobs, njobs, tile)];
   const int t = tile - job.tile_base;
-  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
-  const int nr = job.h >> 1, nc = job.w >> 1;     // nr >= UR + H (host side)
-  // Row placement: tile ty produces row pairs [ty UR, ty UR + UR); the last one is moved up
-  // to end at the picture's last row pair (it recomputes rows of the tile above: same
-  // values).  The top tile has its H halo row pairs above the picture; a tile near the
-  // bottom has nout = 0 .. H of its row pairs below it.  Both are compile-time cases.
-  int r0 = ty * UR - H;
-  if (r0 + H + UR > nr)
-    r0 = nr - UR - H;
-  const int nout = max (0, r0 + RP - nr);
-  const int c0 = tx * kRegUC - 4;
-  const bool hedge = c0 < 0 || c0 + 256 > nc;
-  if (r0 < 0) {
-    reg_tile < F, RP, H, RP - 1, true > (job, r0, c0, nr, nc, lane);
-  } else if (nout == 0) {
-    if (!hedge)
-      reg_tile < F, RP, 0, RP - 1, false > (job, r0, c0, nr, nc, lane);
-    else
-      reg_tile < F, RP, 0, RP - 1, true > (job, r0, c0, nr, nc, lane);
-  } else {
-    reg_tile_bottom < F, RP, H > (nout, job, r0, c0, nr, nc, lane);
-  }
+  reg_tile_at < F, RP, 0 > (job, t % job.tiles_x, t / job.tiles_x, lane);
 }
 
 // rows per wave of the small form: 4 useful row pairs whatever the halo
@@ -397,6 +443,127 @@ constexpr int
 small_rp (int f)
 {
   return 4 + 2 * filter_halo (f);
+}
+
+// ---- r04: the chain form -- every level of every plane of a batch in ONE launch ------------------------
+// A launch per level runs the levels one after the other: the coarse ones (25 + 100 MB of a 523 MB transform
+// of 8 x 2160p) are two launches of their own whose waves all start together, load, compute and store in
+// phases, and leave the chip idle between them (8 x 1080p: 21.8 + 7.8 + 7.8 us, 33 % of the HBM roofline
+// where the finest level alone runs at 57 %).  Here a tile of level l starts as soon as the tiles of level
+// l + 1 that produce its LL rows have finished:
+//   * the host hands out the tiles of all levels in ONE order (iiwt_chain_order): sorted so that a producer
+//     always precedes its consumers and follows them closely (coarse rows run just ahead of the finer rows
+//     they feed), plane by plane to the XCDs;
+//   * workgroup b takes tiles 4 b .. 4 b + 3 of that order.  The order is topological and the dispatcher starts
+//     the workgroups of an XCD in index order, so the lowest unfinished workgroup always runs and waits for
+//     nobody: no deadlock.  (A ticket counter -- "the next four tiles" by an atomic, which needs no assumption
+//     about the dispatcher -- was built first: 4.6 k atomics on ONE address per 8 x 2160p launch serialise,
+//     0.177 ms against 0.139 without; the same for a counter of finished workgroups.)
+//   * a finished tile of a level > 0 counts itself in its (job, tile row) counter; a tile with a producer
+//     polls the one to three counters of the producer rows it reads -- bounded: after 2^22 polls it gives up,
+//     writes the launch's epoch to a pinned host word (the next call reports it) and runs on;
+//   * the counters are never reset: launch number n of a geometry on a queue waits for n times the row's tiles
+//     (the host zeroes them when the geometry changes or a launch gave up);
+//   * the intermediate LL images are written through (coh_store16 above) and read with ordinary loads.
+constexpr int kChainPolls = 1 << 22;
+
+// the wait of a tile for the producer tile rows it reads: called by reg_tile between its detail-band loads and
+// its LL loads.  The counters are asked for together; a tile whose producers are long done (every tile of the
+// finest level, in the level-major order) pays one round trip that overlaps the loads in flight.
+struct ChainWait {
+  const uint32_t *c;
+  int n;
+  uint32_t want;
+  uint32_t *gave_up;
+  uint32_t epoch;
+  struct Seen {
+    uint32_t v0, v1, v2;
+  };
+  __device__ __forceinline__ Seen ask () const
+  {
+    Seen s = { want, want, want };
+    if (n > 0)
+      s.v0 = __hip_atomic_load (c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n > 1)
+      s.v1 = __hip_atomic_load (c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n > 2)
+      s.v2 = __hip_atomic_load (c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
+  }
+  __device__ __forceinline__ void settle (Seen s) const
+  {
+    int polls = 0;
+    while (min (s.v0, min (s.v1, s.v2)) < want) {
+      __builtin_amdgcn_s_sleep (2);
+      if (++polls > kChainPolls) {
+        if ((threadIdx.x & 63) == 0)
+          __hip_atomic_store (gave_up, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      s = ask ();
+    }
+    asm volatile ("":::"memory");       // (the LL loads stay behind the wait)
+  }
+};
+
+template < int F >
+__global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES (F, kRegRP), IIWT_REG_WAVES (F, kRegRP))))
+void iiwt_chain_kernel (const IwtJob * __restrict__ jobs, const uint32_t * __restrict__ order, int n_tiles,
+    uint32_t * __restrict__ ctrl, uint32_t run, uint32_t * __restrict__ gave_up, uint32_t epoch)
+{
+  const int lane = threadIdx.x & 63;
+  const int pos = __builtin_amdgcn_readfirstlane ((int) blockIdx.x * (kRegThreads / 64) + (int) (threadIdx.x >> 6));
+  if (pos >= n_tiles)
+    return;
+  const uint32_t entry = __builtin_amdgcn_readfirstlane (gload < uint32_t > (order + pos));
+  const IwtJob job = jobs[entry >> 16];
+  const int t = (int) (entry & 0xffffu);
+  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  // the producer rows this tile reads: its LL rows = output rows of the producer job, whose tile row r covers
+  // rows [r dep_rows2, (r + 1) dep_rows2) (its last one, moved up, the rest): one to three counters
+  ChainWait wait;
+  wait.n = 0;
+  if (job.dep_rows2 > 0) {
+    const int nr = job.h >> 1;
+    const int r0 = job.small ? reg_tile_r0 < F, small_rp (F) > (ty, nr) : reg_tile_r0 < F, kRegRP > (ty, nr);
+    const int rp = job.small ? small_rp (F) : kRegRP;
+    const int a = max (r0, 0), b = min (r0 + rp, nr);
+    const int lo = min (a / job.dep_rows2, job.dep_tiles_y - 1), hi = min ((b - 1) / job.dep_rows2, job.dep_tiles_y - 1);
+    wait.c = ctrl + job.dep_ctr + lo;
+    wait.n = min (hi - lo + 1, 3);      // (12 LL rows over tile rows of >= 8)
+    wait.want = run * (uint32_t) job.dep_tiles_x;
+    wait.gave_up = gave_up;
+    wait.epoch = epoch;
+  }
+  if (job.ctr >= 0) {           // an intermediate level: its output is read by tiles of this launch
+    if (job.small)
+      reg_tile_at < F, small_rp (F), 2, ChainWait > (job, tx, ty, lane, wait);
+    else
+      reg_tile_at < F, kRegRP, 2, ChainWait > (job, tx, ty, lane, wait);
+    // every store of the wave has gone through before the tile counts as done
+    __builtin_amdgcn_s_waitcnt (0x0f70);        // vmcnt (0)
+    if (lane == 0)
+      __hip_atomic_fetch_add (&ctrl[job.ctr + ty], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (job.small)
+      reg_tile_at < F, small_rp (F), 0, ChainWait > (job, tx, ty, lane, wait);
+    else
+      reg_tile_at < F, kRegRP, 0, ChainWait > (job, tx, ty, lane, wait);
+  }
+}
+
+template < int F >
+int
+launch_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d_order, int n_tiles, uint32_t * ctrl, uint32_t run,
+    uint32_t * gave_up, uint32_t epoch)
+{
+  const int wgs = (n_tiles + kRegThreads / 64 - 1) / (kRegThreads / 64);
+  SCHRO_LAUNCH ((iiwt_chain_kernel < F >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs, d_order, n_tiles, ctrl, run,
+      gave_up, epoch);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "iiwt (chain form) launch: %s", hipGetErrorString (e));
+  return 0;
 }
 
 template < int F >
@@ -436,6 +603,27 @@ iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pair
   *useful_cols = kRegUC;
   *useful_row_pairs = rp - 2 * filter_halo (filter);
   *min_row_pairs = rp - filter_halo (filter);
+}
+
+// (the chain form is a measured-slower form: built into the experiments library only, schro_hip_internal.h)
+int
+launch_iiwt_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d_order, int n_tiles, uint32_t * ctrl,
+    uint32_t run, uint32_t * gave_up, uint32_t epoch, int filter)
+{
+#ifdef SCHRO_HIP_EXPERIMENTS
+  switch (filter) {
+    case 0: return launch_chain < 0 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+    case 1: return launch_chain < 1 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+    case 2: return launch_chain < 2 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+    case 3: return launch_chain < 3 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+    case 4: return launch_chain < 4 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+    case 6: return launch_chain < 6 > (stream, d_jobs, d_order, n_tiles, ctrl, run, gave_up, epoch);
+  }
+  return set_error (SCHRO_HIP_EINVAL, "iiwt (chain form): filter %d not built", filter);
+#else
+  (void) stream, (void) d_jobs, (void) d_order, (void) n_tiles, (void) ctrl, (void) run, (void) gave_up, (void) epoch, (void) filter;
+  return set_error (SCHRO_HIP_EUNSUPPORTED, "the chain form of the register wavelet is built into the experiments library only");
+#endif
 }
 
 int

@@ -954,8 +954,8 @@ launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const Sli
   SliceParams P = P0;
   // (SCHRO_HIP_SLICE_SPLIT=0: one workgroup decodes both strings of its slices;
   //  SCHRO_HIP_SLICE_RUNS=0: slice_kernel -- a step per value -- for every geometry)
-  static const bool split = !getenv ("SCHRO_HIP_SLICE_SPLIT") || atoi (getenv ("SCHRO_HIP_SLICE_SPLIT")) != 0;
-  const char *env = getenv ("SCHRO_HIP_SLICE_RUNS");
+  static const bool split = !SCHRO_ENV ("SCHRO_HIP_SLICE_SPLIT") || atoi (SCHRO_ENV ("SCHRO_HIP_SLICE_SPLIT")) != 0;
+  const char *env = SCHRO_ENV ("SCHRO_HIP_SLICE_RUNS");
   P.run_cap = aligned16 && !(env && atoi (env) == 0) ? slice_run_cap (P) : 0;
   const bool runs = P.run_cap != 0;
   const size_t lds = 64 * (size_t) (P.run_cap + 1) * sizeof (int32_t);
@@ -1326,7 +1326,7 @@ void dc_skew_kernel (const DcJob * __restrict__ jobs, unsigned long long *edge, 
 bool
 dc_skew_ok (const DcJob * jobs, int njobs, int bpp)
 {
-  const char *env = getenv ("SCHRO_HIP_DC_SKEW");
+  const char *env = SCHRO_ENV ("SCHRO_HIP_DC_SKEW");
   if (env && atoi (env) == 0)
     return false;
   for (int p = 0; p < njobs; p++)

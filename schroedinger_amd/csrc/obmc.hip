@@ -868,7 +868,7 @@ launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
 {
   // SCHRO_HIP_OBMC_LDS_PAD (bytes of unused dynamic LDS): fewer workgroups per CU than the
   // five that fit, to leave registers for a kernel on the other queue (experiments)
-  static const int lds_pad = getenv ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (getenv ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
+  static const int lds_pad = SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
   if (variant == 1)
     SCHRO_LAUNCH ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), lds_pad, stream,
         d_jobs, njobs, d_order);

@@ -1087,7 +1087,7 @@ launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
   if (!k)
     return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row x %d planes unsupported", nd, np);
   // scratch runs: SCHRO_HIP_OBMC_LDS_PAD = bytes of unused dynamic LDS per workgroup (fewer workgroups per CU)
-  static const int lds_pad = getenv ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (getenv ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
+  static const int lds_pad = SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
   SCHRO_LAUNCH (k, dim3 (total_tiles), dim3 (kRThreads), (size_t) lds_pad, stream, d_jobs, njobs, d_order);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)

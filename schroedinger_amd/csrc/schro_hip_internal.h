@@ -9,6 +9,16 @@
 
 #include "schro_hip.h"
 
+// Switches that force one of the library's kernels where another would be chosen (the tests' second
+// formulations, A/B runs) and the measured-slower forms they select live in the EXPERIMENTS build only
+// (libschro_hip_exp.so: make exp, -DSCHRO_HIP_EXPERIMENTS; tests/test_gpu_experiments.py runs it in child
+// processes).  The product library reads no SCHRO_HIP_* variable but SCHRO_HIP_DEBUG.
+#ifdef SCHRO_HIP_EXPERIMENTS
+#define SCHRO_ENV(name) getenv (name)
+#else
+#define SCHRO_ENV(name) ((const char *) nullptr)
+#endif
+
 namespace schro {
 
 int set_error (int code, const char *fmt, ...);
@@ -56,6 +66,11 @@ struct IwtJob {
   int tile_base;                // first block id of this job
   int flags;                    // bit0: all sources 8-byte aligned, bit1: dst 16-byte aligned
   int pad;
+  // chain form (iiwt_reg.hip, r04): the job whose output is this job's LL band -- rows of output per tile row
+  // (0: none, the coarsest level), its tile grid, its first counter -- this job's own first counter (-1: nobody
+  // reads its output in the launch: level 0), and its tile form
+  int dep_rows2, dep_tiles_y, dep_tiles_x, dep_ctr;
+  int ctr, small;
 };
 
 struct ConvertJob {
@@ -374,6 +389,8 @@ void iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row
     int *min_row_pairs);
 int launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles,
     int filter, int small);
+int launch_iiwt_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d_order, int n_tiles, uint32_t * ctrl,
+    uint32_t run, uint32_t * gave_up, uint32_t epoch, int filter);
 void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
     int *useful_row_pairs);
 int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,
@@ -491,6 +508,21 @@ struct SchroHipContext {
   };
   static constexpr int kOrderSlots = 16;        // kOrderSlots / kQueues per queue
   OrderSlot order_slots[kOrderSlots];
+
+  // the register wavelet's chain form (api.cpp iiwt_chain): tile orders cached by the batch's geometry, and per
+  // queue the ticket + counters its launches synchronise through (left zero by every launch)
+  struct ChainSlot {
+    uint64_t hash;
+    uint32_t *d;
+    size_t cap, count;
+    uint64_t last_use;
+  };
+  static constexpr int kChainSlots = 16;        // kChainSlots / kQueues per queue
+  ChainSlot chain_slots[kChainSlots];
+  uint32_t *chain_ctrl[kQueues];
+  size_t chain_ctrl_words[kQueues];
+  uint64_t chain_ctrl_hash[kQueues];    // the geometry the counters count for ...
+  uint32_t chain_runs[kQueues];         // ... and how many launches of it they have counted
 
   // grow-only scratch for intermediate LL bands, one per queue
   void *scratch_q[kQueues];

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round profile artefacts (run on the GPU box from the repo root; ROUND=r03 by default):
+# Round profile artefacts (run on the GPU box from the repo root; ROUND=r04 by default):
 #   gpurun_out/kt/     rocprofv3 --kernel-trace --stats of the default bench command
 #   gpurun_out/pmc_*   FETCH_SIZE / WRITE_SIZE, cache and instruction counters, one pass each
 #                      (counters are never combined with a trace domain)
