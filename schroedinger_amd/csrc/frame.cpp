@@ -1,0 +1,597 @@
+// frame.cpp -- the C ABI of libschro_hip.so (include/schro_hip.h), third part: the frame layer -- the reference's
+// own objects (SchroFrame / SchroParams / SchroMotion-shaped) and the stage calls a patched schrodecoder.c makes
+// (schro_frame_inverse_iwt_transform_hip, schro_upsampled_hipframe_upsample, schro_motion_render_hip,
+// schro_hipframe_convert ...), built on the plane layer (plane.cpp).
+
+#include "schro_hip_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+using namespace schro;
+
+static SchroHipContext *
+frame_ctx (const SchroHipFrame * f)
+{
+  if (!f || !f->domain || !(f->domain->flags & SCHRO_MEMORY_DOMAIN_HIP))
+    return nullptr;
+  return f->domain->ctx;
+}
+
+extern "C" {
+
+// ---- frame layer -----------------------------------------------------------------
+
+// How a stage call ends.  The reference's scheduler expects a stage complete when its function returns
+// (schroasync-pthread.c:320-328): the default -- the selected queue is waited for (that queue only: r03
+// drained all four).  A host that pipelines pictures itself turns that off
+// (schro_hip_context_set_stage_completion (ctx, 0)): the same calls then only enqueue on the selected
+// queue, and marks / schro_hip_queue_synchronize order and end them.
+static int
+stage_done (SchroHipContext * ctx, int r)
+{
+  if (r || !ctx->stage_complete)
+    return r;
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return dc_gave_up (ctx);
+}
+
+int
+schro_hip_context_set_stage_completion (SchroHipContext * ctx, int complete_on_return)
+{
+  SCHRO_HIP_REQUIRE (ctx, "set_stage_completion: no context");
+  ctx->stage_complete = complete_on_return != 0;
+  return 0;
+}
+
+static int
+format_bpp (int format)
+{
+  switch (SCHRO_HIP_FORMAT_DEPTH (format)) {
+    case SCHRO_HIP_FORMAT_DEPTH_U8:
+      return 1;
+    case SCHRO_HIP_FORMAT_DEPTH_S16:
+      return 2;
+    case SCHRO_HIP_FORMAT_DEPTH_S32:
+      return 4;
+  }
+  return 0;
+}
+
+SchroHipFrame *
+schro_hip_frame_new_and_alloc (SchroHipContext * ctx, int format, int width, int height,
+    int upsampled)
+{
+  if (ctx && width > 0 && height > 0 && !upsampled && (format == SCHRO_HIP_FORMAT_YUYV
+          || format == SCHRO_HIP_FORMAT_UYVY || format == SCHRO_HIP_FORMAT_AYUV || format == SCHRO_HIP_FORMAT_v210
+          || is_wide_format (format))) {
+    // packed output frame: one component (schroframe.c:81-99)
+    SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+    f->refcount = 1;
+    f->domain = ctx->domain;
+    f->format = format;
+    f->width = width;
+    f->height = height;
+    SchroHipFrameData *c = &f->components[0];
+    c->format = format;
+    c->width = width;
+    c->height = height;
+    const size_t row = format == SCHRO_HIP_FORMAT_AYUV || format == SCHRO_HIP_FORMAT_ARGB ? (size_t) width * 4
+        : format == SCHRO_HIP_FORMAT_AY64 ? (size_t) width * 8
+        : format == SCHRO_HIP_FORMAT_v216 ? (size_t) ((width + 1) & ~1) * 4
+        : format == SCHRO_HIP_FORMAT_v210 ? (size_t) 16 * div_up (width, 6) : (size_t) ((width + 1) & ~1) * 2;
+    c->stride = (int) round_up (row, 64);
+    c->length = c->stride * height;
+    c->data = schro_hip_domain_alloc (ctx, round_up ((size_t) c->length, 256));
+    if (!c->data) {
+      free (f);
+      return nullptr;
+    }
+    f->regions[0] = c->data;
+    return f;
+  }
+  int bpp = format_bpp (format);
+  if (!ctx || !bpp || width <= 0 || height <= 0 || (format & 0x100) || (upsampled && bpp != 1)) {
+    set_error (SCHRO_HIP_EINVAL, "frame_new_and_alloc: bad arguments");
+    return nullptr;
+  }
+  SchroHipFrame *f = (SchroHipFrame *) calloc (1, sizeof (SchroHipFrame));
+  f->refcount = 1;
+  f->domain = ctx->domain;
+  f->format = format;
+  f->width = width;
+  f->height = height;
+  int h_shift = SCHRO_HIP_FORMAT_H_SHIFT (format), v_shift = SCHRO_HIP_FORMAT_V_SHIFT (format);
+  // r04: the chroma of a horizontally subsampled upsampled frame is ONE pair image (is_upsampled == 2):
+  // components[1] holds it, components[2] points at the same bytes (length 0: nothing of its own)
+  const bool pair = upsampled && h_shift == 1;
+  f->is_upsampled = pair ? 2 : upsampled ? 1 : 0;
+  // chroma size rounds up, schroframe.c:95-96
+  int cw = (width + (1 << h_shift) - 1) >> h_shift, ch = (height + (1 << v_shift) - 1) >> v_shift;
+  size_t total = 0;
+  for (int k = 0; k < 3; k++) {
+    SchroHipFrameData *c = &f->components[k];
+    c->format = format;
+    c->width = k ? cw : width;
+    c->height = k ? ch : height;
+    c->h_shift = k ? h_shift : 0;
+    c->v_shift = k ? v_shift : 0;
+    c->stride = (int) round_up ((size_t) c->width * bpp, 64);
+    c->length = c->stride * c->height;
+    if (upsampled) {            // the four half-pel planes, tiled (include/schro_hip.h): stride = bytes per band of 4 rows
+      int st = 0;
+      c->length = (int) (pair && k ? schro_hip_upsampled_pair_bytes (c->width, c->height, &st)
+          : schro_hip_upsampled_bytes (c->width, c->height, &st));
+      c->stride = st;
+      if (pair && k == 2)
+        c->length = 0;
+    }
+    total += round_up ((size_t) c->length, 256);
+  }
+  void *base = schro_hip_domain_alloc (ctx, total);
+  if (!base) {
+    free (f);
+    return nullptr;
+  }
+  f->regions[0] = base;
+  size_t off = 0;
+  for (int k = 0; k < 3; k++) {
+    f->components[k].data = (char *) base + off;
+    off += round_up ((size_t) f->components[k].length, 256);
+  }
+  if (pair)
+    f->components[2].data = f->components[1].data;
+  return f;
+}
+
+SchroHipFrame *
+schro_hip_frame_ref (SchroHipFrame * frame)
+{
+  if (frame)
+    frame->refcount++;
+  return frame;
+}
+
+void
+schro_hip_frame_unref (SchroHipFrame * frame)
+{
+  if (!frame)
+    return;
+  if (--frame->refcount > 0)
+    return;
+  if (frame_ctx (frame) && frame->regions[0])
+    schro_hip_domain_free (frame_ctx (frame), frame->regions[0]);
+  free (frame);
+}
+
+// all components of a frame, host <-> device or device -> device, on the selected queue; no wait
+static int
+copy_frame_async (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src, hipMemcpyKind kind)
+{
+  if ((src->format & 0x100) || (dest->format & 0x100)) {
+    SCHRO_HIP_REQUIRE (src->format == dest->format, "frame copy: packed format mismatch");
+    const SchroHipFrameData *s = &src->components[0];
+    SchroHipFrameData *d = &dest->components[0];
+    int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
+    const int f = src->format;
+    size_t row = f == SCHRO_HIP_FORMAT_AYUV || f == SCHRO_HIP_FORMAT_ARGB ? (size_t) w * 4
+        : f == SCHRO_HIP_FORMAT_AY64 ? (size_t) w * 8 : f == SCHRO_HIP_FORMAT_v216 ? (size_t) (w / 2) * 8
+        : f == SCHRO_HIP_FORMAT_v210 ? (size_t) 16 * div_up (w, 6) : (size_t) (w / 2) * 4;
+    if (row && h > 0)
+      return copy_2d_async (ctx, d->data, d->stride, s->data, s->stride, (int) row, h, kind);
+    return 0;
+  }
+  int bpp = format_bpp (src->format);
+  SCHRO_HIP_REQUIRE (bpp && format_bpp (dest->format) == bpp, "frame copy: depth mismatch");
+  for (int k = 0; k < 3; k++) {
+    const SchroHipFrameData *s = &src->components[k];
+    SchroHipFrameData *d = &dest->components[k];
+    int w = std::min (s->width, d->width), h = std::min (s->height, d->height);
+    if (w <= 0 || h <= 0)
+      continue;
+    int r = copy_2d_async (ctx, d->data, d->stride, s->data, s->stride, w * bpp, h, kind);
+    if (r)
+      return r;
+  }
+  return 0;
+}
+
+static int
+copy_frame (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFrame * src, hipMemcpyKind kind)
+{
+  int r = copy_frame_async (ctx, dest, src, kind);
+  if (r)
+    return r;
+  SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+int
+schro_frame_to_hip (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && !frame_ctx (src),
+      "frame_to_hip: dest must be a device frame and src a host frame");
+  return copy_frame (frame_ctx (dest), dest, src, hipMemcpyHostToDevice);
+}
+
+int
+schro_hipframe_to_cpu (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (src) && !frame_ctx (dest),
+      "hipframe_to_cpu: src must be a device frame and dest a host frame");
+  return copy_frame (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
+}
+
+// r03 -- the asynchronous twins (TODO-CUDA:5-7 "make gpu stuff completely asynchronous"; the
+// synchronous pattern they replace: schrogpuframe.c:480-609): enqueued on the context's selected
+// queue -- SCHRO_HIP_QUEUE_H2D / _D2H by convention -- and not waited for.  The host frame should live in
+// pinned memory (schro_memory_domain_new_hip_host): then picture k's copies run on the DMA engines
+// beside picture k - 1's kernels; order them against the stages with marks and end with
+// schro_hip_queue_synchronize.
+int
+schro_frame_to_hip_async (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && !frame_ctx (src),
+      "frame_to_hip_async: dest must be a device frame and src a host frame");
+  (void) hipSetDevice (frame_ctx (dest)->device);
+  return copy_frame_async (frame_ctx (dest), dest, src, hipMemcpyHostToDevice);
+}
+
+int
+schro_hipframe_to_cpu_async (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (src) && !frame_ctx (dest),
+      "hipframe_to_cpu_async: src must be a device frame and dest a host frame");
+  (void) hipSetDevice (frame_ctx (src)->device);
+  return copy_frame_async (frame_ctx (src), dest, src, hipMemcpyDeviceToHost);
+}
+
+}                               // extern "C"
+
+namespace schro {
+// A copy of a device frame on another context's device (the scheduler moves a reference across two
+// chains with it): same format, size and layout -- plain or upsampled --, one
+// hipMemcpyPeerAsync per component on the destination context's host-to-device COPY queue, behind
+// `wait_for` (the owner's event: all the work that writes `src`); `done` is recorded behind the copies
+// and the destination's kernel queues wait for it.  Nothing is waited for on the host (r04).
+SchroHipFrame *
+frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done)
+{
+  SchroHipContext *src_ctx = frame_ctx (src);
+  if (!dst_ctx || !src_ctx) {
+    set_error (SCHRO_HIP_EINVAL, "frame_copy_to: needs a destination context and a device frame");
+    return nullptr;
+  }
+  SchroHipFrame *dst = schro_hip_frame_new_and_alloc (dst_ctx, src->format, src->width, src->height, src->is_upsampled ? 1 : 0);
+  if (!dst)
+    return nullptr;
+  (void) hipSetDevice (dst_ctx->device);
+  hipStream_t q = dst_ctx->streams[SCHRO_HIP_QUEUE_H2D];
+  const int ncomp = (src->format & 0x100) ? 1 : 3;
+  bool ok = dst->is_upsampled == src->is_upsampled && (!wait_for || hipStreamWaitEvent (q, wait_for, 0) == hipSuccess);
+  for (int k = 0; ok && k < ncomp; k++) {
+    const SchroHipFrameData *s = &src->components[k];
+    SchroHipFrameData *d = &dst->components[k];
+    ok = d->length == s->length && d->stride == s->stride
+        && (s->length == 0        // (the V component of a pair image: components[1] carries it)
+        || hipMemcpyPeerAsync (d->data, dst_ctx->device, s->data, src_ctx->device, (size_t) s->length, q) == hipSuccess);
+  }
+  if (ok && done) {
+    ok = hipEventRecord (done, q) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+      ok = hipStreamWaitEvent (dst_ctx->streams[k], done, 0) == hipSuccess;
+  }
+  if (!ok) {
+    set_error (SCHRO_HIP_EDEVICE, "frame_copy_to: peer copy device %d -> %d failed", src_ctx->device, dst_ctx->device);
+    (void) hipStreamSynchronize (q);
+    schro_hip_frame_unref (dst);
+    return nullptr;
+  }
+  dst->upsample_done = src->upsample_done;
+  return dst;
+}
+}                               // namespace schro
+
+extern "C" {
+
+// the synchronous form: complete on return
+SchroHipFrame *
+schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src)
+{
+  SchroHipFrame *dst = schro::frame_copy_to_async (dst_ctx, src, nullptr, nullptr);
+  if (dst && hipStreamSynchronize (dst_ctx->streams[SCHRO_HIP_QUEUE_H2D]) != hipSuccess) {
+    set_error (SCHRO_HIP_EDEVICE, "frame_copy_to: the copy queue of device %d failed", dst_ctx->device);
+    schro_hip_frame_unref (dst);
+    return nullptr;
+  }
+  return dst;
+}
+
+int
+schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
+    SchroHipFrame * transform_frame, SchroHipParams * params)
+{
+  SCHRO_HIP_REQUIRE (frame && transform_frame && params && frame_ctx (frame),
+      "inverse_iwt_transform: bad arguments");
+  SchroHipContext *ctx = frame_ctx (frame);
+  int bpp = format_bpp (frame->format);
+  SCHRO_HIP_REQUIRE ((bpp == 2 || bpp == 4) && format_bpp (transform_frame->format) == bpp,
+      "inverse_iwt_transform: frames must both be s16 or both s32");
+
+  // host coefficients are staged on the device first (the H2D step of
+  // schro_frame_inverse_iwt_transform_cuda, schrogpuframe.c:584-599)
+  SchroHipFrame *staged = nullptr;
+  SchroHipFrame *src = transform_frame;
+  SCHRO_HIP_REQUIRE (ctx->stage_complete || frame_ctx (transform_frame),
+      "inverse_iwt_transform: with stage completion off the transform frame must be on the device "
+      "(schro_frame_to_hip_async on the copy queue)");
+  if (!frame_ctx (transform_frame)) {
+    staged = schro_hip_frame_new_and_alloc (ctx, transform_frame->format, transform_frame->width,
+        transform_frame->height, 0);
+    if (!staged)
+      return SCHRO_HIP_ENOMEM;
+    int r = schro_frame_to_hip (staged, transform_frame);
+    if (r) {
+      schro_hip_frame_unref (staged);
+      return r;
+    }
+    src = staged;
+  }
+  SchroHipIwtPlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    planes[k].src = src->components[k].data;
+    planes[k].src_stride = src->components[k].stride;
+    planes[k].dst = frame->components[k].data;
+    planes[k].dst_stride = frame->components[k].stride;
+    planes[k].width = k ? params->iwt_chroma_width : params->iwt_luma_width;
+    planes[k].height = k ? params->iwt_chroma_height : params->iwt_luma_height;
+    if (planes[k].width > frame->components[k].width || planes[k].height > frame->components[k].height
+        || planes[k].width > src->components[k].width || planes[k].height > src->components[k].height) {
+      if (staged)
+        schro_hip_frame_unref (staged);
+      return set_error (SCHRO_HIP_EINVAL, "inverse_iwt_transform: component %d smaller than the iwt size", k);
+    }
+  }
+  int r = schro_hip_iiwt_batch (ctx, planes, 3, params->transform_depth,
+      params->wavelet_filter_index, bpp);
+  r = stage_done (ctx, r);
+  if (staged)
+    schro_hip_frame_unref (staged);
+  return r;
+}
+
+int
+schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const void *slices,
+    size_t slices_bytes, const SchroHipLowDelayParams * params)
+{
+  SCHRO_HIP_REQUIRE (transform_frame && frame_ctx (transform_frame) && slices && params,
+      "decode_lowdelay_transform_data: bad arguments");
+  SchroHipContext *ctx = frame_ctx (transform_frame);
+  const int bpp = format_bpp (transform_frame->format);
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "decode_lowdelay_transform_data: the frame must be s16 or s32");
+  for (int k = 0; k < 3; k++)
+    SCHRO_HIP_REQUIRE ((k ? params->iwt_chroma_width : params->iwt_luma_width) <= transform_frame->components[k].width
+        && (k ? params->iwt_chroma_height : params->iwt_luma_height) <= transform_frame->components[k].height,
+        "decode_lowdelay_transform_data: component %d smaller than the iwt size", k);
+  // picture->lowdelay_buffer goes to the device as it is: compressed
+  void *d_slices = schro_hip_domain_alloc (ctx, slices_bytes ? slices_bytes : 1);
+  if (!d_slices)
+    return SCHRO_HIP_ENOMEM;
+  int r = 0;
+  if (hipMemcpyAsync (d_slices, slices, slices_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    r = set_error (SCHRO_HIP_EDEVICE, "decode_lowdelay_transform_data: copy of %zu bytes failed", slices_bytes);
+  if (!r) {
+    SchroHipLowDelayPicture pic;
+    pic.slices = (const uint8_t *) d_slices;
+    pic.slices_bytes = slices_bytes;
+    for (int k = 0; k < 3; k++) {
+      pic.comp[k] = transform_frame->components[k].data;
+      pic.stride[k] = transform_frame->components[k].stride;
+    }
+    r = schro_hip_lowdelay_batch (ctx, &pic, 1, params, bpp);
+  }
+  const int rs = schro_hip_synchronize (ctx);   // the host buffer and d_slices are free again
+  schro_hip_domain_free (ctx, d_slices);
+  return r ? r : rs;
+}
+
+int
+schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && src->domain == dest->domain
+      && dest->is_upsampled && !src->is_upsampled && format_bpp (src->format) == 1,
+      "upsampled_hipframe_upsample: bad arguments");
+  if (dest->upsample_done)      // schroframe.c:2006-2009
+    return 0;
+  SchroHipUpsamplePlane planes[3];
+  const bool pair = dest->is_upsampled == 2;    // chroma as one pair image
+  for (int k = 0; k < 3; k++) {
+    SCHRO_HIP_REQUIRE (dest->components[k].width == src->components[k].width
+        && dest->components[k].height == src->components[k].height,
+        "upsampled_hipframe_upsample: size mismatch");
+    planes[k].src = (const uint8_t *) src->components[k].data;
+    planes[k].src_stride = src->components[k].stride;
+    planes[k].dst = (uint8_t *) dest->components[k].data;
+    planes[k].dst_stride = dest->components[k].stride;
+    planes[k].width = src->components[k].width;
+    planes[k].height = src->components[k].height;
+    planes[k].src_v = nullptr;
+    planes[k].src_v_stride = 0;
+  }
+  if (pair) {
+    planes[1].src_v = planes[2].src;
+    planes[1].src_v_stride = planes[2].src_stride;
+  }
+  int r = stage_done (frame_ctx (dest), schro_hip_upsample_batch (frame_ctx (dest), planes, pair ? 2 : 3));
+  if (!r)
+    dest->upsample_done = 1;
+  return r;
+}
+
+// schro_upsampled_gpuframe_upsample (SchroFrame *) (schrogpuframe.h:29): one argument, the upsampled
+// frame, whose integer-pel source is the frame it keeps in virt_frame1
+int
+schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame)
+{
+  SCHRO_HIP_REQUIRE (frame && frame->is_upsampled && frame->virt_frame1,
+      "upsampled_hipframe_upsample_inplace: needs an upsampled frame with its source frame in virt_frame1");
+  return schro_upsampled_hipframe_upsample (frame, frame->virt_frame1);
+}
+
+int
+schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHipFrame * addframe, int add,
+    SchroHipFrame * output_frame)
+{
+  (void) dest;                  // the CPU path's s16 scratch frame: the accumulator lives in LDS here
+  // addframe NULL: nothing to add -- a zero_residual picture has no frame (schrodecoder.c:1800, :1861,
+  // :1904-1906: the GPU paths take mc_tmp_frame as the combined frame); the prediction alone is clamped
+  SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors
+      && output_frame && frame_ctx (output_frame) && (!addframe || addframe->domain == output_frame->domain),
+      "motion_render: bad arguments");
+  SCHRO_HIP_REQUIRE (add, "motion_render: only the fused form (add = TRUE, output_frame) is exact on this domain");
+  const SchroHipParams *p = motion->params;
+  if (p->have_global_motion)    // schromotion.c:113-118 routes this to another renderer
+    return set_error (SCHRO_HIP_EUNSUPPORTED, "motion_render: global motion is not supported");
+  SchroHipContext *ctx = frame_ctx (output_frame);
+  const int upsampled = p->mv_precision > 0;
+  SCHRO_HIP_REQUIRE ((motion->src1->is_upsampled != 0) == upsampled
+      && (!motion->src2 || motion->src2->is_upsampled == motion->src1->is_upsampled),
+      "motion_render: references must be %s for mv_precision %d",
+      upsampled ? "upsampled frames" : "plain frames", p->mv_precision);
+  if (p->num_refs == 1)         // schromotion8.c:711-713
+    SCHRO_HIP_REQUIRE (p->picture_weight_2 == 1, "motion_render: one reference needs picture_weight_2 == 1");
+
+  // SchroMotionVector array -> device (schrogpumotion.c:68-120 did a repack; the kernel reads the
+  // 20-byte records as they are).  r04: through the context's pinned table mirrors (push_big_table: one
+  // memcpy into pinned memory + an asynchronous copy on the queue, buffers used in turn) -- no allocation,
+  // no pageable-memory copy and no wait per call; a motion whose vectors are ALREADY on the device (a
+  // host that uploaded them on the copy queue) is used where it is.
+  (void) hipSetDevice (ctx->device);
+  size_t mv_bytes = (size_t) 20 * p->x_num_blocks * p->y_num_blocks;
+  void *d_mvs = nullptr;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes (&attr, motion->motion_vectors) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+      d_mvs = motion->motion_vectors;
+    } else {
+      (void) hipGetLastError ();        // (an ordinary host pointer is "invalid value" to the query)
+      int r = push_big_table (ctx, motion->motion_vectors, mv_bytes, &d_mvs);
+      if (r)
+        return r;
+    }
+  }
+  SchroHipObmcPlane planes[3];
+  const int res_bpp = addframe ? format_bpp (addframe->format) : 2;
+  for (int k = 0; k < 3; k++) {
+    SchroHipObmcPlane & pl = planes[k];
+    memset (&pl, 0, sizeof (pl));
+    pl.mvs = d_mvs;
+    pl.x_num_blocks = p->x_num_blocks;
+    pl.y_num_blocks = p->y_num_blocks;
+    pl.xblen_luma = p->xblen_luma;
+    pl.yblen_luma = p->yblen_luma;
+    pl.xbsep_luma = p->xbsep_luma;
+    pl.ybsep_luma = p->ybsep_luma;
+    pl.mv_precision = p->mv_precision;
+    pl.picture_weight_bits = p->picture_weight_bits;
+    pl.picture_weight_1 = p->picture_weight_1;
+    pl.picture_weight_2 = p->picture_weight_2;
+    pl.chroma_h_shift = SCHRO_HIP_FORMAT_H_SHIFT (output_frame->format);
+    pl.chroma_v_shift = SCHRO_HIP_FORMAT_V_SHIFT (output_frame->format);
+    pl.component = k;
+    pl.ref1 = (const uint8_t *) motion->src1->components[k].data;
+    pl.ref1_stride = motion->src1->components[k].stride;
+    if (motion->src2) {
+      pl.ref2 = (const uint8_t *) motion->src2->components[k].data;
+      pl.ref2_stride = motion->src2->components[k].stride;
+    }
+    if (addframe) {
+      pl.residual = addframe->components[k].data;
+      pl.residual_stride = addframe->components[k].stride;
+    }
+    pl.residual_bpp = res_bpp;
+    pl.out = (uint8_t *) output_frame->components[k].data;
+    pl.out_stride = output_frame->components[k].stride;
+    pl.width = output_frame->components[k].width;
+    pl.height = output_frame->components[k].height;
+    pl.ref_pair = k && motion->src1->is_upsampled == 2;
+  }
+  return stage_done (ctx, schro_hip_obmc_batch (ctx, planes, 3));
+}
+
+int
+schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && src->domain == dest->domain,
+      "hipframe_convert: both frames must live in the same device domain");
+  SchroHipContext *ctx = frame_ctx (dest);
+  if (dest->format & 0x100) {
+    // copy-out into a packed frame (schroframe.c:878-899, 943-968)
+    const bool wide = is_wide_format (dest->format), v210 = dest->format == SCHRO_HIP_FORMAT_v210;
+    SCHRO_HIP_REQUIRE (!(src->format & 0x100) && format_bpp (src->format)
+        && (wide || v210 || format_bpp (src->format) == 1),
+        "hipframe_convert: YUYV / UYVY / AYUV take a planar u8 source (convert to u8 first)");
+    SchroHipPackPlane pl;
+    for (int k = 0; k < 3; k++) {
+      pl.src[k] = (const uint8_t *) src->components[k].data;
+      pl.src_stride[k] = src->components[k].stride;
+    }
+    pl.src_width = src->width;
+    pl.src_height = src->height;
+    pl.src_h_shift = SCHRO_HIP_FORMAT_H_SHIFT (src->format);
+    pl.src_v_shift = SCHRO_HIP_FORMAT_V_SHIFT (src->format);
+    pl.dst = (uint8_t *) dest->components[0].data;
+    pl.dst_stride = dest->components[0].stride;
+    pl.width = dest->width;
+    pl.height = dest->height;
+    pl.format = dest->format;
+    int r = wide ? schro_hip_pack_wide_batch (ctx, &pl, 1, format_bpp (src->format))
+        : v210 ? schro_hip_pack_v210_batch (ctx, &pl, 1, format_bpp (src->format)) : schro_hip_pack_u8_batch (ctx, &pl, 1);
+    return stage_done (ctx, r);
+  }
+  int sb = format_bpp (src->format), db = format_bpp (dest->format);
+  if (db == 1 && (sb == 2 || sb == 4)) {
+    SchroHipConvertPlane planes[3];
+    for (int k = 0; k < 3; k++) {
+      planes[k].src = src->components[k].data;
+      planes[k].src_stride = src->components[k].stride;
+      planes[k].dst = (uint8_t *) dest->components[k].data;
+      planes[k].dst_stride = dest->components[k].stride;
+      planes[k].width = std::min (dest->components[k].width, src->components[k].width);
+      planes[k].height = std::min (dest->components[k].height, src->components[k].height);
+    }
+    return stage_done (ctx, schro_hip_convert_u8_batch (ctx, planes, 3, sb));
+  }
+  if (db == sb) {
+    (void) hipSetDevice (ctx->device);
+    for (int k = 0; k < 3; k++) {
+      int w = std::min (dest->components[k].width, src->components[k].width);
+      int h = std::min (dest->components[k].height, src->components[k].height);
+      SCHRO_HIP_CHECK (hipMemcpy2DAsync (dest->components[k].data, dest->components[k].stride,
+              src->components[k].data, src->components[k].stride, (size_t) w * sb, h,
+              hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return stage_done (ctx, 0);
+  }
+  return set_error (SCHRO_HIP_EUNSUPPORTED, "hipframe_convert: depth %d -> %d is not on the decode path",
+      sb, db);
+}
+
+int
+schro_hipframe_shift_right (SchroHipFrame * frame, int shift)
+{
+  SCHRO_HIP_REQUIRE (frame && frame_ctx (frame) && !(frame->format & 0x100) && format_bpp (frame->format) > 1,
+      "hipframe_shift_right: needs a device s16 / s32 frame");
+  SchroHipDcPlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    planes[k].data = frame->components[k].data;
+    planes[k].stride = frame->components[k].stride;
+    planes[k].width = frame->components[k].width;
+    planes[k].height = frame->components[k].height;
+  }
+  return stage_done (frame_ctx (frame), schro_hip_shift_right_batch (frame_ctx (frame), planes, 3, format_bpp (frame->format), shift));
+}
+
+}                               // extern "C"

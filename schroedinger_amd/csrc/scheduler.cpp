@@ -55,12 +55,12 @@
 #include <thread>
 
 namespace schro {
-// api.cpp: queue 0 of the context waits for its other queues, then `ev` is recorded on it
+// context.cpp: queue 0 of the context waits for its other queues, then `ev` is recorded on it
 int context_join_queues (SchroHipContext * ctx, hipEvent_t ev);
-// api.cpp: a copy of `src` on dst_ctx's device, enqueued on its host-to-device copy queue behind `wait_for`;
+// frame.cpp: a copy of `src` on dst_ctx's device, enqueued on its host-to-device copy queue behind `wait_for`;
 // `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  Nothing is waited for here.
 SchroHipFrame *frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done);
-// api.cpp: a context that does not become the calling thread's domain
+// context.cpp: a context that does not become the calling thread's domain
 SchroHipContext *context_new_unbound (int device);
 }
 

@@ -23,6 +23,18 @@ namespace schro {
 
 int set_error (int code, const char *fmt, ...);
 
+static inline int
+div_up (int a, int b)
+{
+  return (a + b - 1) / b;
+}
+
+static inline size_t
+round_up (size_t a, size_t b)
+{
+  return (a + b - 1) / b * b;
+}
+
 #define SCHRO_HIP_CHECK(expr)                                                  \
   do {                                                                         \
     hipError_t _e = (expr);                                                    \
@@ -480,7 +492,7 @@ struct SchroHipContext {
     bool copy_pending;
   };
   static constexpr int kArgSlots = 256;        // kArgSlots / kQueues per queue
-  static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in api.cpp)
+  static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in plane.cpp)
   char *h_args;                 // kArgSlots pinned mirrors
   char *d_args;
   ArgSlot arg_slots[kArgSlots];
@@ -495,7 +507,7 @@ struct SchroHipContext {
   std::vector < EvPair > ev_pool;
   size_t ev_used;
 
-  // OBMC tile orders (api.cpp obmc_tile_order): device tables of job << 16 | tile, cached by
+  // OBMC tile orders (plane.cpp obmc_tile_order): device tables of job << 16 | tile, cached by
   // the geometry and references of the launch they were built for
   struct OrderSlot {
     uint64_t hash;
@@ -509,7 +521,7 @@ struct SchroHipContext {
   static constexpr int kOrderSlots = 16;        // kOrderSlots / kQueues per queue
   OrderSlot order_slots[kOrderSlots];
 
-  // the register wavelet's chain form (api.cpp iiwt_chain): tile orders cached by the batch's geometry, and per
+  // the register wavelet's chain form (plane.cpp iiwt_chain): tile orders cached by the batch's geometry, and per
   // queue the ticket + counters its launches synchronise through (left zero by every launch)
   struct ChainSlot {
     uint64_t hash;
@@ -562,6 +574,11 @@ int push_big_table (SchroHipContext * ctx, const void *host, size_t bytes, void 
 // ... built in place: *host is the pinned mirror to fill, big_table_commit sends it
 int big_table_begin (SchroHipContext * ctx, size_t bytes, void **host, void **dev);
 int big_table_commit (SchroHipContext * ctx, size_t bytes);
+// rows of row_bytes bytes, host <-> device or device -> device, enqueued on the selected queue (context.cpp)
+int copy_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src, int src_stride, int row_bytes,
+    int height, hipMemcpyKind kind);
+// v216 / ARGB / AY64 (plane.cpp)
+bool is_wide_format (int format);
 // the launches made while a scope is open are timed under its kernel class (when profiling is on)
 struct ProfileScope {
   ProfileScope (SchroHipContext * c, int cls);

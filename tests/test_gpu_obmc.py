@@ -278,36 +278,3 @@ def test_references_of_another_layout_are_refused(ctx):
         ctx.obmc_batch([sa.obmc_plane(d_mv, P, 1, plain, plain, res, out)])
     for p in (d_mv, res, out, single, pair_img, plain):
         p.free()
-
-
-def test_item_kernel_parity_in_a_child_process():
-    # obmc.hip's item kernel -- the second formulation of the default-weight case, the default for
-    # plain and eighth-pel references only -- takes every case (SCHRO_HIP_OBMC_KERNEL=item, read
-    # once per process): all chroma formats, block sets, precisions 1-3, near and far vectors, DC
-    # values outside 8 bits, in a child process against the same oracle
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SCHRO_HIP_OBMC_KERNEL="item")
-    here = os.path.abspath(__file__)
-    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
-                        "test_default_weights or test_dc_values or test_rotating or test_pair_images_default or "
-                        "test_pair_images_edges"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-
-
-def test_pair_kernels_parity_in_a_child_process():
-    # A U + V pair runs as one job (obmc_row_kernel_*_2) only where the batch has more tiles than
-    # the device has workgroup slots; SCHRO_HIP_OBMC_MERGE=2 (read once per process) pairs always,
-    # so the default-weight matrix of this file -- all chroma formats, block sets, precisions, near
-    # and far vectors, DC values outside 8 bits, rotating references -- goes through those kernels
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SCHRO_HIP_OBMC_MERGE="2")
-    here = os.path.abspath(__file__)
-    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
-                        "test_default_weights or test_dc_values or test_rotating or test_ragged"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
