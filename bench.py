@@ -71,6 +71,11 @@ class BatchSet:
             self.up_chroma = [(wl.ref[g][r][k], self.hp[g][r][k]) for g in range(wl.groups) for r in range(2) for k in (1, 2)]
         self.up_pairs = self.up_luma + self.up_chroma
         self.iwt_pairs, self.obmc_jobs = [], []
+        # r04, the combine form (default; SCHRO_BENCH_COMBINE=0: the r03 stage order): the OBMC launches write
+        # their PREDICTION (pred planes), the inverse wavelet's last step adds it and writes the picture -- the
+        # residual picture is never written or read
+        self.combine = wl.combine
+        self.iwt_combine, self.pred_jobs = [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
         self.co_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * wl.frames))
@@ -92,10 +97,19 @@ class BatchSet:
                 d_res = ctx.plane(h, w, np.int16)
                 out = self.out_arena.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
+                if self.combine:
+                    d_pred = ctx.plane(h, w, np.uint8)
+                    self.iwt_combine.append((d_co, out, d_pred))
                 g = min(f // REF_GROUP, wl.groups - 1)
                 # (SCHRO_BENCH_ONE_REF=1, a footprint experiment: both references read the same planes)
                 r1 = 0 if os.environ.get("SCHRO_BENCH_ONE_REF") == "1" else 1
-                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][r1][k], d_res, out))
+                # (SCHRO_BENCH_NO_RESIDUAL=1, a pricing experiment: OBMC without its residual -- what fusing the finest
+                # wavelet level into its finish could save at most on this side; the pictures are then NOT the workload's)
+                no_res = os.environ.get("SCHRO_BENCH_NO_RESIDUAL") == "1"
+                self.obmc_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][r1][k], None if no_res else d_res, out))
+                if self.combine:
+                    self.pred_jobs.append(sa.obmc_plane(d_mv, wl.P, k, self.hp[g][0][k], self.hp[g][r1][k], None, d_pred,
+                                                        prediction_only=True))
                 co_f.append(co)
                 out_f.append(out)
             self.coeff_np.append(co_f)
@@ -110,6 +124,7 @@ class Workload:
 
     def __init__(self, ctx, frames, seed, queues=2):
         self.ctx, self.frames, self.queues = ctx, frames, queues
+        self.combine = os.environ.get("SCHRO_BENCH_COMBINE", "1") != "0"
         self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
         dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
         self.dims = dims
@@ -138,6 +153,27 @@ class Workload:
         c, k = self.ctx, self.k
         self.k += 1
         order = int(os.environ.get("SCHRO_BENCH_ORDER", "2"))
+        if self.combine:
+            # a batch's stages in order on ONE queue, the batches in flight on different queues: the reference planes
+            # are upsampled right before the OBMC launch that gathers from them; the transform comes last and writes
+            # the pictures
+            s = k % self.queues
+            b = self.sets[s]
+            if self.queues > 1:
+                c.select_queue(s)
+                if alone or self.prev_alone:
+                    for other in range(self.queues):
+                        if other != s:
+                            c.queue_wait(s, other)
+                self.prev_alone = alone
+            c.upsample_batch(b.up_luma)
+            c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3 == 0])
+            c.upsample_batch(b.up_chroma)
+            c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
+            c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
+            if self.queues > 1:
+                c.select_queue(0)
+            return
 
         def obmc_side(b):
             if order == 0:
@@ -188,6 +224,18 @@ class Workload:
         obmc_side(b)
         c.queue_mark(8 + s)
         c.select_queue(0)
+
+
+def batch_kernels(c, b):
+    """The kernels of one batch, in the order the workload runs them (the PCIe-inclusive legs)."""
+    if b.combine:
+        c.upsample_batch(b.up_pairs)
+        c.obmc_batch(b.pred_jobs)
+        c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
+    else:
+        c.upsample_batch(b.up_pairs)
+        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
+        c.obmc_batch(b.obmc_jobs)
 
 
 def cpu_baseline(wl, cores, reps=10):
@@ -418,9 +466,7 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
         b.mv_arena.block.upload_async(h.mv)
         if quantised:
             wl.dq_plan.run(planes=h.dq_planes)
-        c.upsample_batch(b.up_pairs)
-        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
-        c.obmc_batch(b.obmc_jobs)
+        batch_kernels(c, b)
         b.out_arena.block.download_async(h.out)
 
     def step(k):
@@ -444,9 +490,7 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
                 wl.dq_plan.run(planes=h.dq_planes)
             else:               # (the r03 form: every codeblock record turned into a job on the host, every step)
                 c.dequant_batch([(dst, dev, tab, False) for dst, dev, tab in h.hand], 0)
-        c.upsample_batch(b.up_pairs)
-        c.iiwt_batch(b.iwt_pairs, DEPTH, FILTER)
-        c.obmc_batch(b.obmc_jobs)
+        batch_kernels(c, b)
         c.queue_mark(8 + i)
         c.queue_mark(4 + i)
         c.select_queue(c.QUEUE_D2H)
@@ -783,8 +827,11 @@ def main():
             "iiwt_finest": 4 * samples,                     # 2 B read + 2 B written per sample
             # levels 1 and 2 are one launch each; the average launch moves (1/4 + 1/16) / 2
             "iiwt_coarse": int(4 * samples * (0.25 + 0.0625) / 2),
-            # residual 2 B + output 1 B + 1 B per reference used + 20 B per block
-            "obmc": int((2 + 1 + refs_per_px) * samples) + 20 * args.frames
+            # residual 2 B + output 1 B + 1 B per reference used + 20 B per block.  r04, the combine
+            # form: the OBMC launches write the prediction (1 B) and read no residual -- their own algorithmic bytes
+            # are 1 B + 1 B per reference used + the vectors; the add lives in the finest wavelet level, which reads
+            # 2 B coefficients + 1 B prediction and writes 1 B picture per sample (4 B, the figure it had)
+            "obmc": int(((1 if wl.combine else 3) + refs_per_px) * samples) + 20 * args.frames
                     * wl.P["x_num_blocks"] * wl.P["y_num_blocks"],
             # 1 B read + 4 B written per sample of every reference plane of the step (two launches: luma, chroma)
             "upsample": wl.groups * 2 * (W * H * 3 // 2) * 5,
@@ -820,6 +867,16 @@ def main():
                                     # quantity rocprof's FETCH_SIZE bounds
                                     "read_frac_of_8TBs": round(2 * samples / (iiwt_ms * 1e-3) / 1e9
                                                                / HBM_PEAK_GBS, 4)}
+        # the whole pixel path of a step against SURVEY 8(d)'s algorithmic bytes, whatever the stage structure:
+        # wavelet 4 B per sample + OBMC and combine (3 + references used) B per sample + vectors + upsample 5 B per
+        # reference sample -- the figure that compares rounds (r03: 971 MB per step in 0.418 ms of kernels)
+        path_bytes = 4 * samples + int((3 + refs_per_px) * samples) + 20 * args.frames * wl.P["x_num_blocks"] * wl.P["y_num_blocks"] \
+            + alg_bytes["upsample"]
+        path_ms = sum(prof[k][0] for k in ("iiwt_finest", "iiwt_coarse", "upsample", "obmc")) / profiled_steps
+        pixel_path = {"alg_bytes_per_step": path_bytes, "sum_of_kernel_ms": round(path_ms, 4),
+                      "alg_GBs": round(path_bytes / (path_ms * 1e-3) / 1e9, 1),
+                      "frac_of_8TBs": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "frac_of_8TBs_by_step_time": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/, collected offline)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -834,6 +891,8 @@ def main():
             "dtype": "s16", "data": "synthetic",
             "config": {"workload": "2160p 4:2:0 inter pictures: 3-level DD(9,7) IIWT s16 + "
                        "half-pel upsample of 2 refs + 12x12/8x8 quarter-pel OBMC + add/clamp",
+                       "stage_order": "upsample, OBMC prediction, inverse wavelet with the add as its last step (the residual "
+                                      "picture stays on the chip)" if wl.combine else "inverse wavelet, upsample, OBMC with the add",
                        "frames_per_step_per_gpu": args.frames, "batches_in_flight": args.queues,
                        "width": W, "height": H,
                        "sharding": "pictures across GPUs, no collective"},
@@ -843,8 +902,12 @@ def main():
                          "avg_launch_ms": round(d_avg, 4), "launches_per_step": round(per_step[dom], 2),
                          "ms_per_step": round(d_step, 4),
                          "note": "algorithmic bytes of one step's launches of this kernel class / their summed "
-                                 "HIP-event time (OBMC: a luma and a chroma launch per step)"},
+                                 "HIP-event time (OBMC: a luma and a chroma launch per step"
+                                 + ("; combine form: the launches write the prediction and read no residual -- 1 B + 1 B per "
+                                    "reference used per sample + the vectors; see pixel_path for the whole path on SURVEY 8(d)'s bytes)"
+                                    if wl.combine else ")")},
             "kernels": kernels,
+            "pixel_path": pixel_path,
         }
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for

@@ -189,6 +189,21 @@ typedef struct {
   int dst_stride;               /* bytes */
   int width;                    /* iwt_{luma,chroma}_width  */
   int height;                   /* iwt_{luma,chroma}_height */
+  /* r04 -- the combine form: the transform's last step writes the PICTURE instead of the residual frame.
+   * combine 0: dst is the s16 / s32 residual plane (width x height), as above.
+   * combine 1: dst is a u8 plane, out_width x out_height (the picture inside the iwt-padded transform):
+   *            dst = sat_u8 (residual + pred) with the reference's 16-bit wrapping add -- the last steps of
+   *            schro_motion_render (..., add = TRUE, output_frame) (orc_rrshift6_add_s16_2d / _s32_2d,
+   *            schromotion8.c:852-876) --, pred (u8, out_width x out_height) = the prediction
+   *            schro_hip_obmc_batch writes with prediction_only = 1.
+   * combine 2: dst = sat_u8 (residual + 128): a picture without references (schro_frame_convert,
+   *            orc_offsetconvert_u8_s16 / _s32, schrodecoder.c:1788-1790).
+   * The residual then never exists in memory (s16, register-form filters, 8-byte aligned planes; other
+   * cases go through a residual plane in the context's scratch): a step of 8 x 2160p moves 2 x 199 MB less. */
+  const uint8_t *pred;
+  int pred_stride;
+  int out_width, out_height;
+  int combine;
 } SchroHipIwtPlane;
 
 /* depth levels, Dirac filter index 0..6 (schrobitstream.h:124-132),
@@ -442,6 +457,12 @@ typedef struct {
   int width;                    /* component picture size */
   int height;
   int ref_pair;                 /* 0: one component per reference image; 1: pair images */
+  int prediction_only;          /* r04: residual must be NULL; `out` receives the PREDICTION (acc + 32) >> 6 for the
+                                 * combine form of schro_hip_iiwt_batch.  The prediction must fit 8 bits -- it does for
+                                 * every legal stream: weights with picture_weight_1, _2 >= 0 and a sum <= 1 << bits are
+                                 * required (else an error at the call), and a DC value outside [-128, 127] makes the
+                                 * launch raise an error the next call of the context reports (such pictures need the
+                                 * residual form, which follows the reference's 16-bit wrap-around). */
 } SchroHipObmcPlane;
 
 int schro_hip_obmc_batch (SchroHipContext * ctx,
@@ -763,6 +784,12 @@ int schro_hip_context_set_stage_completion (SchroHipContext * ctx, int complete_
  * transform into `frame` (device, iwt-padded size). */
 int schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
     SchroHipFrame * transform_frame, SchroHipParams * params);
+/* r04 -- the inverse transform and x_combine's add in one call: output_frame (device u8) = sat_u8 (inverse
+ * transform of transform_frame + prediction), prediction = the frame schro_motion_render_hip (motion, dest, NULL,
+ * FALSE, NULL) rendered (the mc_tmp_frame of the reference's GPU paths, schrodecoder.c:1742-1760, :1908-1921), or
+ * NULL for a picture without references (+ 128, :1788-1790).  The residual picture never exists in memory. */
+int schro_frame_inverse_iwt_transform_combine_hip (SchroHipFrame * output_frame, SchroHipFrame * transform_frame,
+    SchroHipParams * params, SchroHipFrame * prediction);
 
 /* schro_decoder_decode_lowdelay_transform_data (picture), schrolowdelay.c:746-762, with
  * picture->transform_frame on the device: `slices` is picture->lowdelay_buffer->data (host),
@@ -778,8 +805,10 @@ int schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src
 int schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame);
 
 /* schro_motion_render (motion, dest, addframe, add, output_frame) (schromotion.h:100, as
- * x_render_motion calls it, schrodecoder.c:1905-1935) replacement, same arguments: add must
- * be TRUE, `dest` (the CPU path's s16 scratch frame) is not used and may be NULL.  addframe:
+ * x_render_motion calls it, schrodecoder.c:1905-1935) replacement, same arguments.  add TRUE: the CPU path's
+ * fused form -- `dest` (its s16 scratch frame) is not used and may be NULL.  add FALSE (r04): the prediction alone
+ * into `dest`, a u8 device frame (schro_motion_render_cuda (motion, mc_tmp_frame), :1759), addframe and output_frame
+ * NULL -- for schro_frame_inverse_iwt_transform_combine_hip; DC values outside [-128, 127] are an error there.  addframe:
  * device s16/s32 residual (picture->frame), or NULL for a zero_residual picture (nothing is added,
  * nothing is read: schrodecoder.c:1904-1906); output_frame: device u8.  motion->motion_vectors: the
  * host array, or a device copy of it.  Global motion is not

@@ -290,13 +290,25 @@ class Context:
     # ---- batched plane-level launches (asynchronous on the context stream) ----
 
     def iiwt_batch(self, pairs, depth, filt):
-        """pairs: [(src DevicePlane, dst DevicePlane)], all s16 or all s32."""
+        """pairs: [(src, dst DevicePlane)], all s16 or all s32 -- dst: the residual plane; or, the combine
+        form (r04), [(src, out u8 DevicePlane, pred)]: the transform's last step writes the picture
+        out = sat_u8 (residual + pred), pred a u8 DevicePlane (the prediction of obmc_batch (prediction_only)) or
+        None for a picture without references (+ 128)."""
         n = len(pairs)
         arr = (_lib.IwtPlane * n)()
         bpp = pairs[0][0].dtype.itemsize
-        for k, (s, d) in enumerate(pairs):
-            assert s.dtype == d.dtype and s.dtype.itemsize == bpp
-            arr[k] = _lib.IwtPlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height)
+        for k, t in enumerate(pairs):
+            s, d = t[0], t[1]
+            assert s.dtype.itemsize == bpp
+            if len(t) == 2:
+                assert s.dtype == d.dtype
+                arr[k] = _lib.IwtPlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height, None, 0, 0, 0, 0)
+            else:
+                pred = t[2]
+                assert d.dtype == np.uint8 and (pred is None or (pred.dtype == np.uint8 and (pred.height, pred.width) == (d.height, d.width)))
+                arr[k] = _lib.IwtPlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height,
+                                       pred.ptr if pred is not None else None, pred.stride if pred is not None else 0,
+                                       d.width, d.height, 1 if pred is not None else 2)
         check(self.lib.schro_hip_iiwt_batch(self.h, arr, n, depth, filt, bpp))
 
     def pack_u8_batch(self, jobs):
@@ -476,9 +488,10 @@ class Context:
         check(self.lib.schro_hip_obmc_batch(self.h, arr, n))
 
 
-def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
+def obmc_plane(mvs, params, component, ref1, ref2, residual, out, prediction_only=False):
     """Fill a SchroHipObmcPlane.  params: dict with the SchroParams motion fields
-    plus chroma_h_shift / chroma_v_shift; mvs: DevicePlane holding the records."""
+    plus chroma_h_shift / chroma_v_shift; mvs: DevicePlane holding the records.
+    prediction_only (residual None): `out` receives the prediction for iiwt_batch's combine form."""
     p = _lib.ObmcPlane()
     p.mvs = mvs.ptr
     for name in ("x_num_blocks", "y_num_blocks", "xblen_luma", "yblen_luma", "xbsep_luma",
@@ -494,6 +507,7 @@ def obmc_plane(mvs, params, component, ref1, ref2, residual, out):
         p.residual_bpp = residual.dtype.itemsize
     p.out, p.out_stride = out.ptr, out.stride
     p.width, p.height = out.width, out.height
+    p.prediction_only = 1 if prediction_only else 0
     p.ref_pair = 1 if getattr(ref1, "pair", False) else 0      # (U, V) pair images (HpPlane (pair=True))
     assert ref2 is None or bool(getattr(ref2, "pair", False)) == bool(p.ref_pair)
     return p

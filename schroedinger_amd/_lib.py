@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_obmc_batch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
-    "schro_frame_inverse_iwt_transform_hip", "schro_upsampled_hipframe_upsample",
+    "schro_frame_inverse_iwt_transform_hip", "schro_frame_inverse_iwt_transform_combine_hip", "schro_upsampled_hipframe_upsample",
     "schro_motion_render_hip", "schro_hipframe_convert",
 ]
 
@@ -52,7 +52,9 @@ EXPORTED_SYMBOLS = [
 class IwtPlane(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int),
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int),
+                ("pred", C.c_void_p), ("pred_stride", C.c_int),
+                ("out_width", C.c_int), ("out_height", C.c_int), ("combine", C.c_int)]
 
 
 class ConvertPlane(C.Structure):
@@ -120,7 +122,7 @@ class ObmcPlane(C.Structure):
                 ("residual", C.c_void_p), ("residual_stride", C.c_int),
                 ("residual_bpp", C.c_int),
                 ("out", C.c_void_p), ("out_stride", C.c_int),
-                ("width", C.c_int), ("height", C.c_int), ("ref_pair", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("ref_pair", C.c_int), ("prediction_only", C.c_int)]
 
 
 class FrameData(C.Structure):
@@ -370,6 +372,9 @@ def load():
     L.schro_frame_inverse_iwt_transform_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
                                                         C.POINTER(Params)]
     L.schro_frame_inverse_iwt_transform_hip.restype = i
+    L.schro_frame_inverse_iwt_transform_combine_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
+                                                                 C.POINTER(Params), C.POINTER(Frame)]
+    L.schro_frame_inverse_iwt_transform_combine_hip.restype = i
     L.schro_upsampled_hipframe_upsample.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
     L.schro_upsampled_hipframe_upsample.restype = i
     L.schro_motion_render_hip.argtypes = [C.POINTER(Motion), C.POINTER(Frame), C.POINTER(Frame), i,

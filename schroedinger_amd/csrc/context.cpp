@@ -179,6 +179,11 @@ dc_gave_up (SchroHipContext * ctx)
     return set_error (SCHRO_HIP_EDEVICE, "inverse wavelet launch %u: a tile gave up waiting for the level above it (its picture is incomplete)",
         epoch);
   }
+  if (ctx->dc_gave_up && ((volatile uint32_t *) ctx->dc_gave_up)[2]) {
+    ((volatile uint32_t *) ctx->dc_gave_up)[2] = 0;
+    return set_error (SCHRO_HIP_EDEVICE, "a prediction_only OBMC launch met a DC value outside [-128, 127]: its prediction does not fit "
+        "8 bits and the combined picture differs from the reference's; such pictures take the residual form");
+  }
   return 0;
 }
 

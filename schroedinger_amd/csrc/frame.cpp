@@ -309,16 +309,19 @@ schro_hip_frame_copy_to (SchroHipContext * dst_ctx, SchroHipFrame * src)
   return dst;
 }
 
-int
-schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
-    SchroHipFrame * transform_frame, SchroHipParams * params)
+// frame: the residual frame (s16 / s32, combine 0) or the u8 picture (combine 1: + prediction, 2: + 128)
+static int
+inverse_iwt_transform (SchroHipFrame * frame, SchroHipFrame * transform_frame, SchroHipParams * params, int combine,
+    SchroHipFrame * prediction)
 {
   SCHRO_HIP_REQUIRE (frame && transform_frame && params && frame_ctx (frame),
       "inverse_iwt_transform: bad arguments");
   SchroHipContext *ctx = frame_ctx (frame);
-  int bpp = format_bpp (frame->format);
-  SCHRO_HIP_REQUIRE ((bpp == 2 || bpp == 4) && format_bpp (transform_frame->format) == bpp,
-      "inverse_iwt_transform: frames must both be s16 or both s32");
+  int bpp = format_bpp (transform_frame->format);
+  SCHRO_HIP_REQUIRE ((bpp == 2 || bpp == 4) && (combine ? format_bpp (frame->format) == 1 : format_bpp (frame->format) == bpp),
+      "inverse_iwt_transform: the transform frame must be s16 or s32, the destination the same (the u8 picture in the combine form)");
+  SCHRO_HIP_REQUIRE (combine != 1 || (prediction && prediction->domain == frame->domain && format_bpp (prediction->format) == 1),
+      "inverse_iwt_transform: the combine form needs the u8 prediction frame of schro_motion_render_hip (add = FALSE) in the same domain");
 
   // host coefficients are staged on the device first (the H2D step of
   // schro_frame_inverse_iwt_transform_cuda, schrogpuframe.c:584-599)
@@ -340,6 +343,7 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
     src = staged;
   }
   SchroHipIwtPlane planes[3];
+  memset (planes, 0, sizeof (planes));
   for (int k = 0; k < 3; k++) {
     planes[k].src = src->components[k].data;
     planes[k].src_stride = src->components[k].stride;
@@ -347,8 +351,22 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
     planes[k].dst_stride = frame->components[k].stride;
     planes[k].width = k ? params->iwt_chroma_width : params->iwt_luma_width;
     planes[k].height = k ? params->iwt_chroma_height : params->iwt_luma_height;
-    if (planes[k].width > frame->components[k].width || planes[k].height > frame->components[k].height
-        || planes[k].width > src->components[k].width || planes[k].height > src->components[k].height) {
+    bool fits = planes[k].width <= src->components[k].width && planes[k].height <= src->components[k].height;
+    if (combine) {
+      // the picture inside the transform's size (schrodecoder.c:1788-1790 converts with a crop; the render adds
+      // over motion->width x height)
+      planes[k].combine = combine;
+      planes[k].out_width = std::min (frame->components[k].width, planes[k].width);
+      planes[k].out_height = std::min (frame->components[k].height, planes[k].height);
+      if (combine == 1) {
+        planes[k].pred = (const uint8_t *) prediction->components[k].data;
+        planes[k].pred_stride = prediction->components[k].stride;
+        fits = fits && prediction->components[k].width >= planes[k].out_width && prediction->components[k].height >= planes[k].out_height;
+      }
+    } else {
+      fits = fits && planes[k].width <= frame->components[k].width && planes[k].height <= frame->components[k].height;
+    }
+    if (!fits) {
       if (staged)
         schro_hip_frame_unref (staged);
       return set_error (SCHRO_HIP_EINVAL, "inverse_iwt_transform: component %d smaller than the iwt size", k);
@@ -360,6 +378,24 @@ schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
   if (staged)
     schro_hip_frame_unref (staged);
   return r;
+}
+
+int
+schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
+    SchroHipFrame * transform_frame, SchroHipParams * params)
+{
+  return inverse_iwt_transform (frame, transform_frame, params, 0, nullptr);
+}
+
+// r04 -- x_wavelet_transform and the add of x_combine in one call (the structure of the reference's GPU paths:
+// x_render_motion renders the prediction into mc_tmp_frame, x_combine adds, schrodecoder.c:1742-1760, :1908-1921):
+// output = sat_u8 (inverse transform (transform_frame) + prediction), or + 128 where prediction is NULL (a picture
+// without references, :1788-1790).  The residual picture never exists in memory.
+int
+schro_frame_inverse_iwt_transform_combine_hip (SchroHipFrame * output_frame, SchroHipFrame * transform_frame,
+    SchroHipParams * params, SchroHipFrame * prediction)
+{
+  return inverse_iwt_transform (output_frame, transform_frame, params, prediction ? 1 : 2, prediction);
 }
 
 int
@@ -444,13 +480,19 @@ int
 schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHipFrame * addframe, int add,
     SchroHipFrame * output_frame)
 {
-  (void) dest;                  // the CPU path's s16 scratch frame: the accumulator lives in LDS here
+  // add == FALSE (r04): the prediction alone into `dest`, a u8 device frame -- schro_motion_render_cuda (motion,
+  // mc_tmp_frame) (schrodecoder.c:1759) --, for schro_frame_inverse_iwt_transform_combine_hip to add.  Else `dest`
+  // is the CPU path's s16 scratch frame and not used: the accumulator lives in LDS here.
+  if (!add) {
+    SCHRO_HIP_REQUIRE (dest && frame_ctx (dest) && format_bpp (dest->format) == 1 && !addframe,
+        "motion_render: add = FALSE renders the prediction into `dest`, a u8 device frame (addframe NULL)");
+    output_frame = dest;
+  }
   // addframe NULL: nothing to add -- a zero_residual picture has no frame (schrodecoder.c:1800, :1861,
   // :1904-1906: the GPU paths take mc_tmp_frame as the combined frame); the prediction alone is clamped
   SCHRO_HIP_REQUIRE (motion && motion->params && motion->src1 && motion->motion_vectors
       && output_frame && frame_ctx (output_frame) && (!addframe || addframe->domain == output_frame->domain),
       "motion_render: bad arguments");
-  SCHRO_HIP_REQUIRE (add, "motion_render: only the fused form (add = TRUE, output_frame) is exact on this domain");
   const SchroHipParams *p = motion->params;
   if (p->have_global_motion)    // schromotion.c:113-118 routes this to another renderer
     return set_error (SCHRO_HIP_EUNSUPPORTED, "motion_render: global motion is not supported");
@@ -517,6 +559,7 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
     pl.width = output_frame->components[k].width;
     pl.height = output_frame->components[k].height;
     pl.ref_pair = k && motion->src1->is_upsampled == 2;
+    pl.prediction_only = add ? 0 : 1;
   }
   return stage_done (ctx, schro_hip_obmc_batch (ctx, planes, 3));
 }

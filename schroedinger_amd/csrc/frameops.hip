@@ -33,6 +33,16 @@ clampi (int x, int lo, int hi)
 
 constexpr int kCvtTW = 512, kCvtTH = 4;
 
+// the last steps of orc_rrshift6_add_s16_2d / _s32_2d with the prediction p = (acc + 32) >> 6 already there:
+// convlw (s32), addw (wraps), convsuswb
+template < typename T >
+__device__ __forceinline__ uint8_t
+combine_pred (T s, uint32_t p)
+{
+  const int v = (int16_t) ((int16_t) s + (int16_t) p);
+  return (uint8_t) clampi (v, 0, 255);
+}
+
 template < typename T >
 __device__ __forceinline__ uint8_t
 offsetconvert (T s)
@@ -62,6 +72,12 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
   const T *s = (const T *) ((const char *) job.src + (size_t) y * job.src_stride) + x;
   uint8_t *d = job.dst + (size_t) y * job.dst_stride + x;
   const bool vec = x + 8 <= job.w && (((uintptr_t) s & 15) == 0) && (((uintptr_t) d & 7) == 0);
+  if (job.pred) {               // r04: residual + prediction (the fallback of the wavelet's combine form)
+    const uint8_t *p = job.pred + (size_t) y * job.pred_stride + x;
+    for (int e = 0; e < 8 && x + e < job.w; e++)
+      gstore < uint8_t > (d + e, combine_pred < T > (gload < T > (s + e), gload < uint8_t > (p + e)));
+    return;
+  }
   if (vec) {
     T v[8];
     if constexpr (sizeof (T) == 2) {

@@ -34,6 +34,16 @@
 //
 // Bound: HBM.  Algorithmic bytes per output sample: 2 B read + 2 B written; the row
 // halo (2H of 12 row pairs) is re-read through L2.
+//
+// r04 -- the combine form (MODE bit 2, level 0 only).  The residual picture was written by this kernel and read
+// once, by the OBMC finish (or the intra convert): 2 x 199 MB of a step of 8 x 2160p whose other traffic is
+// 1 GB, and priced it costs more than its bytes -- OBMC without its residual reads takes 0.174 instead of
+// 0.221 ms per step (the reads sit on every tile's critical path and push the reference planes out of the
+// caches), the wavelet without its stores 0.041 + 0.026 instead of 0.067 + 0.037.  So the stages swap: the OBMC
+// launch writes its prediction ((acc + 32) >> 6, a u8 plane) and THIS kernel's last step adds it:
+// out = sat_u8 (residual + prediction) -- schro_motion_render's orc_rrshift6_add_s16_2d, schromotion8.c:852-857
+// -- or + 128 for a picture without references (orc_offsetconvert_u8_s16, schrovirtframe.c:1689-1720).  The
+// residual never exists in memory; per output sample this launch reads 2 + 1 B and writes 1 B.
 
 #include "schro_hip_internal.h"
 #include "iiwt_steps.h"
@@ -267,9 +277,16 @@ out_round_pk (P x)
 
 // all horizontal steps of one row, then round + interleave + one 16-byte store
 // (COH bit 1: the row belongs to an intermediate LL image of the chain form)
+// the combine form's per-row inputs: the prediction's 8 bytes for this lane (0x80 bytes: a picture without
+// references) and how many of the lane's samples are inside the picture
+struct Combine {
+  u32x2 pred;
+  int nvalid;
+};
+
 template < int F, bool HEDGE, int COH >
 __device__ __forceinline__ void
-finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst)
+finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst, const Combine & cmb)
 {
   hstep < F, 0, HEDGE > (row, is_first, is_last);
   hstep < F, 1, HEDGE > (row, is_first, is_last);
@@ -285,7 +302,35 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
   o.y = __builtin_amdgcn_perm (b0, a0, 0x07060302u);
   o.z = __builtin_amdgcn_perm (b1, a1, 0x05040100u);
   o.w = __builtin_amdgcn_perm (b1, a1, 0x07060302u);
-  if (store_lane) {
+  if constexpr ((COH & 4) != 0) {
+    // r04 -- the picture, not the residual (see the header of this file): out = sat_u8 (residual + prediction) with the
+    // reference's 16-bit wrapping add (orc_rrshift6_add_s16_2d: addw, convsuswb; the prediction is the (acc + 32) >> 6
+    // of the OBMC launch, a u8 plane), or + 128 for a picture without references (orc_offsetconvert_u8_s16).
+    // cmb.nvalid: how many of the lane's 8 samples of this row lie inside the picture.
+    if (store_lane && cmb.nvalid > 0) {
+      const uint32_t q[4] = { o.x, o.y, o.z, o.w };
+      const uint32_t pw[4] = {
+        __builtin_amdgcn_perm (0u, cmb.pred.x, 0x0c010c00u), __builtin_amdgcn_perm (0u, cmb.pred.x, 0x0c030c02u),
+        __builtin_amdgcn_perm (0u, cmb.pred.y, 0x0c010c00u), __builtin_amdgcn_perm (0u, cmb.pred.y, 0x0c030c02u)
+      };
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s16x2 t = S (q[k]) + S (pw[k]);
+        t = __builtin_elementwise_min (__builtin_elementwise_max (t, (s16x2) (short) 0), (s16x2) (short) 255);
+        v[k] = U (t);
+      }
+      u32x2 b;
+      b.x = __builtin_amdgcn_perm (v[1], v[0], 0x06040200u);
+      b.y = __builtin_amdgcn_perm (v[3], v[2], 0x06040200u);
+      if (cmb.nvalid == 8) {
+        gstore < u32x2 > (dst, b);
+      } else {
+        for (int e = 0; e < cmb.nvalid; e++)
+          gstore < uint8_t > (dst + e, (uint8_t) ((e < 4 ? b.x : b.y) >> (8 * (e & 3))));
+      }
+    }
+  } else if (store_lane) {
     if constexpr ((COH & 2) != 0)
       coh_store16 (dst, o);
     else
@@ -354,12 +399,43 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane, WAIT wai
   const int l_lo = (max (0, -c0) + 3) >> 2, l_hi = min (63, ((nc - c0) >> 2) - 1);
   const bool is_first = lane == l_lo, is_last = lane == l_hi;
   const bool store_lane = lane >= max (l_lo, 1) && lane <= min (l_hi, 62);
-  char *dst = (char *) job.dst + (size_t) (2 * (r0 + H)) * job.dst_stride + (size_t) cl * 4;
+  if constexpr ((COH & 4) != 0) {
+    // combine form: the destination is the u8 picture (out_w x out_h inside the iwt-padded w x h).  The lane's 8
+    // prediction bytes of a row are ONE aligned load (the host keeps rows of the prediction plane 8-byte aligned and
+    // readable up to a multiple of 8 columns); a pair of rows is fetched while the pair before it is finished.
+    const int x = 2 * cl, y0 = 2 * (r0 + H);
+    const int nx = store_lane ? clampi (job.out_w - x, 0, 8) : 0;
+    char *dst = (char *) job.dst + (size_t) y0 * job.dst_stride + x;
+    const uint8_t *pp = job.pred ? job.pred + (size_t) y0 * job.pred_stride + x : nullptr;
+    const u32x2 k128 = (u32x2) { 0x80808080u, 0x80808080u };
+    auto fetch = [&](int i, int odd) {
+      return pp && nx > 0 && y0 + 2 * (i - H) + odd < job.out_h ? gload < u32x2 > (pp + (size_t) (2 * (i - H) + odd) * job.pred_stride) : k128;
+    };
+    u32x2 p0 = fetch (H, 0), p1 = fetch (H, 1);
 #pragma unroll
-  for (int i = H; i < RP - H; i++) {
-    finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst);
-    finish_row < F, HEDGE, COH > (O[i], is_first, is_last, store_lane, dst + job.dst_stride);
-    dst += 2 * (size_t) job.dst_stride;
+    for (int i = H; i < RP - H; i++) {
+      const int y = y0 + 2 * (i - H);
+      const Combine c0 = { p0, y < job.out_h ? nx : 0 }, c1 = { p1, y + 1 < job.out_h ? nx : 0 };
+      if (i + 1 < RP - H) {
+        p0 = fetch (i + 1, 0);
+        p1 = fetch (i + 1, 1);
+      }
+      finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst, c0);
+      finish_row < F, HEDGE, COH > (O[i], is_first, is_last, store_lane, dst + job.dst_stride, c1);
+      dst += 2 * (size_t) job.dst_stride;
+      // (one pair of rows ahead, no more: left alone the scheduler hoists every row's prediction load to the top --
+      // 32 registers beside a tile that fills the budget -- and spills 40)
+      __builtin_amdgcn_sched_barrier (0);
+    }
+  } else {
+    char *dst = (char *) job.dst + (size_t) (2 * (r0 + H)) * job.dst_stride + (size_t) cl * 4;
+    const Combine none = { (u32x2) { 0u, 0u }, 0 };
+#pragma unroll
+    for (int i = H; i < RP - H; i++) {
+      finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst, none);
+      finish_row < F, HEDGE, COH > (O[i], is_first, is_last, store_lane, dst + job.dst_stride, none);
+      dst += 2 * (size_t) job.dst_stride;
+    }
   }
 }
 
@@ -422,8 +498,12 @@ reg_tile_at (const IwtJob & job, int tx, int ty, int lane, WAIT wait = WAIT ())
 #endif
 // (the Haar filters have no halo: all 12 row pairs are worked on, and 128 registers would spill 80 - 90 of them)
 #define IIWT_REG_WAVES(F, RP) (((F) == 3 || (F) == 4) && (RP) == 12 ? 3 : SCHRO_IIWT_WAVES)
-template < int F, int RP >
-__global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES (F, RP), IIWT_REG_WAVES (F, RP))))
+#ifndef SCHRO_IIWT_COMBINE_WAVES
+#define SCHRO_IIWT_COMBINE_WAVES 3
+#endif
+#define IIWT_REG_WAVES_M(F, RP, MODE) ((MODE) == 4 && (RP) == 12 ? SCHRO_IIWT_COMBINE_WAVES : IIWT_REG_WAVES (F, RP))
+template < int F, int RP, int MODE >
+__global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES_M (F, RP, MODE), IIWT_REG_WAVES_M (F, RP, MODE))))
 void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)
 {
   const int wg = xcd_tile_id (blockIdx.x, gridDim.x);
@@ -435,7 +515,7 @@ void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_til
   const int lane = threadIdx.x & 63;
   const IwtJob job = jobs[find_job (jobs, njobs, tile)];
   const int t = tile - job.tile_base;
-  reg_tile_at < F, RP, 0 > (job, t % job.tiles_x, t / job.tiles_x, lane);
+  reg_tile_at < F, RP, MODE > (job, t % job.tiles_x, t / job.tiles_x, lane);
 }
 
 // rows per wave of the small form: 4 useful row pairs whatever the halo
@@ -568,14 +648,20 @@ launch_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d_orde
 
 template < int F >
 int
-launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, bool small)
+launch_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, bool small, bool combine)
 {
   const int wgs = (total_tiles + kRegThreads / 64 - 1) / (kRegThreads / 64);
-  if (small)
-    SCHRO_LAUNCH ((iiwt_reg_kernel < F, small_rp (F) >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
+  if (small && combine)
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, small_rp (F), 4 >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
+        d_jobs, njobs, total_tiles);
+  else if (combine)
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, kRegRP, 4 >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
+        njobs, total_tiles);
+  else if (small)
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, small_rp (F), 0 >), dim3 (wgs), dim3 (kRegThreads), 0, stream,
         d_jobs, njobs, total_tiles);
   else
-    SCHRO_LAUNCH ((iiwt_reg_kernel < F, kRegRP >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
+    SCHRO_LAUNCH ((iiwt_reg_kernel < F, kRegRP, 0 >), dim3 (wgs), dim3 (kRegThreads), 0, stream, d_jobs,
         njobs, total_tiles);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
@@ -628,15 +714,15 @@ launch_iiwt_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d
 
 int
 launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles, int filter,
-    int small)
+    int small, int combine)
 {
   switch (filter) {
-    case 0: return launch_reg < 0 > (stream, d_jobs, njobs, total_tiles, small);
-    case 1: return launch_reg < 1 > (stream, d_jobs, njobs, total_tiles, small);
-    case 2: return launch_reg < 2 > (stream, d_jobs, njobs, total_tiles, small);
-    case 3: return launch_reg < 3 > (stream, d_jobs, njobs, total_tiles, small);
-    case 4: return launch_reg < 4 > (stream, d_jobs, njobs, total_tiles, small);
-    case 6: return launch_reg < 6 > (stream, d_jobs, njobs, total_tiles, small);
+    case 0: return launch_reg < 0 > (stream, d_jobs, njobs, total_tiles, small, combine);
+    case 1: return launch_reg < 1 > (stream, d_jobs, njobs, total_tiles, small, combine);
+    case 2: return launch_reg < 2 > (stream, d_jobs, njobs, total_tiles, small, combine);
+    case 3: return launch_reg < 3 > (stream, d_jobs, njobs, total_tiles, small, combine);
+    case 4: return launch_reg < 4 > (stream, d_jobs, njobs, total_tiles, small, combine);
+    case 6: return launch_reg < 6 > (stream, d_jobs, njobs, total_tiles, small, combine);
   }
   return set_error (SCHRO_HIP_EINVAL, "iiwt (register form): filter %d not built", filter);
 }

@@ -41,7 +41,7 @@ constexpr int kTW = 64, kTH = 4;
 
 template < int PC, bool SIMPLE >
 __global__ __launch_bounds__ (kThreads)
-void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
+void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs, uint32_t * __restrict__ overflow)
 {
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
 
@@ -127,6 +127,8 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs)
             : job.comp == 1 ? (int16_t) (v01 >> 16) : (int16_t) (v23 & 0xffff);
         // get_dc_block stores into a uint8_t; block_acc_dc multiplies a 16-bit parameter
         pred = interior ? (int) (int16_t) (dc + 128) : (int) (uint8_t) (dc + 128);
+        if (overflow && (unsigned) pred > 255u)         // (prediction_only launches: see obmc_row.hip)
+          __hip_atomic_store (overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
         int val[2] = { 0, 0 };
 #pragma unroll
@@ -608,7 +610,8 @@ item_class (const ObmcJob & job, const ItemLane & il, const uint16_t * s_item, c
 
 template < int PC >
 __global__ __launch_bounds__ (kThreads) __attribute__ ((amdgpu_waves_per_eu (5, 5)))
-void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order,
+    uint32_t * __restrict__ overflow)
 {
   __shared__ __attribute__ ((aligned (16))) int acc[(kFTH / 2) * kAccStride];   // rows y and y + 16 per word
   __shared__ int s_wx[kMaxBlk], s_wy[kMaxBlk];
@@ -758,8 +761,11 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
       const bool fold = by < yoff || by + yblen > yfold_hi || bx < xoff || bx + nseg * 4 > xfold_hi;
       // (a DC value outside 0..255 would carry between the halves of an accumulator word)
       const bool wide_dc = mode == 0 && (unsigned) p > 255u;
-      if (wide_dc)
+      if (wide_dc) {
         s_wide = 1;
+        if (overflow)
+          __hip_atomic_store (overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       key = (clamped || fold || wide_dc || yblen * nseg > kItemWCap) ? 4 : (mode == 3 ? 0 : (mode == 0 ? 3 : mode));
       if (key == 4) {
         // the rim path works from the clamped fetch origins (it has no use for the window
@@ -864,17 +870,17 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
 template < int PC >
 int
 launch_one (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int variant,
-    const uint32_t * d_order)
+    const uint32_t * d_order, uint32_t * overflow)
 {
   // SCHRO_HIP_OBMC_LDS_PAD (bytes of unused dynamic LDS): fewer workgroups per CU than the
   // five that fit, to leave registers for a kernel on the other queue (experiments)
   static const int lds_pad = SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
   if (variant == 1)
     SCHRO_LAUNCH ((obmc_item_kernel < PC >), dim3 (total_tiles), dim3 (kThreads), lds_pad, stream,
-        d_jobs, njobs, d_order);
+        d_jobs, njobs, d_order, overflow);
   else
     SCHRO_LAUNCH ((obmc_kernel < PC, false >), dim3 (total_tiles), dim3 (kThreads), 0,
-        stream, d_jobs, njobs);
+        stream, d_jobs, njobs, overflow);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "obmc launch: %s", hipGetErrorString (e));
@@ -921,12 +927,12 @@ obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
 
 int
 launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec,
-    int variant, const uint32_t * d_order)
+    int variant, const uint32_t * d_order, uint32_t * overflow)
 {
   switch (prec == 0 ? 0 : (prec == 1 ? 1 : 2)) {
-    case 0: return launch_one < 0 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
-    case 1: return launch_one < 1 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
-    default: return launch_one < 2 > (stream, d_jobs, njobs, total_tiles, variant, d_order);
+    case 0: return launch_one < 0 > (stream, d_jobs, njobs, total_tiles, variant, d_order, overflow);
+    case 1: return launch_one < 1 > (stream, d_jobs, njobs, total_tiles, variant, d_order, overflow);
+    default: return launch_one < 2 > (stream, d_jobs, njobs, total_tiles, variant, d_order, overflow);
   }
 }
 

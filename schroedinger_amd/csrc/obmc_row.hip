@@ -686,7 +686,7 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
 
 template < int ND, int NP, bool UV = false, int TH = kRTH >
 __device__ __forceinline__ void
-obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order)
+obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow)
 {
   typedef RowGeo < ND, UV > G;
   static_assert (!UV || NP == 1, "a UV job is one virtual plane of (U, V) samples");
@@ -852,8 +852,12 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       // weights fold where the block hangs over the picture's rim: top | bottom << 1 | left << 2 | right << 3
       const int fold = (by < yoff ? 1 : 0) | (by + yblen > yfold_hi ? 2 : 0) | (bx < xoff ? 4 : 0) | (bx + xblen > xfold_hi ? 8 : 0);
       const bool wide_dc = mode == 0 && ((unsigned) pdc > 255u || (unsigned) pdc_b > 255u);
-      if (wide_dc)
+      if (wide_dc) {
         s_wide = 1;
+        // (prediction_only launches, r04: such a prediction does not fit the u8 plane it is written to)
+        if (overflow)
+          __hip_atomic_store (overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       int key;
       if (off_h || wide_dc || yblen * 2 * ND > G::kWCap || xblen > (UV ? 8 : 16)) {
         key = kRRim;
@@ -1056,9 +1060,9 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // or six workgroups per CU; the UV kernels are the 12-byte-row kernel on 64-pixel tiles.
 #define SCHRO_ROW_KERNEL(name, waves, ...) \
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (waves, waves))) \
-void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order) \
+void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow) \
 { \
-  obmc_row_body < __VA_ARGS__ > (jobs, njobs, order); \
+  obmc_row_body < __VA_ARGS__ > (jobs, njobs, order, overflow); \
 }
 SCHRO_ROW_KERNEL (obmc_row_kernel_2_1, 6, 2, 1)
 SCHRO_ROW_KERNEL (obmc_row_kernel_2_2, 6, 2, 2)
@@ -1071,11 +1075,12 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_uv_3, 7, 3, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 4, 4, 1, true)
 #undef SCHRO_ROW_KERNEL
 
-typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *);
+typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *, uint32_t *);
 
 // np: planes per job (1, 2); 3: (U, V) pairs from pair images
 int
-launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int np, const uint32_t * d_order)
+launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int np, const uint32_t * d_order,
+    uint32_t * overflow)
 {
   RowKernel k = nullptr;
   switch (nd * 10 + np) {
@@ -1093,7 +1098,7 @@ launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
     return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row x %d planes unsupported", nd, np);
   // scratch runs: SCHRO_HIP_OBMC_LDS_PAD = bytes of unused dynamic LDS per workgroup (fewer workgroups per CU)
   static const int lds_pad = SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
-  SCHRO_LAUNCH (k, dim3 (total_tiles), dim3 (kRThreads), (size_t) lds_pad, stream, d_jobs, njobs, d_order);
+  SCHRO_LAUNCH (k, dim3 (total_tiles), dim3 (kRThreads), (size_t) lds_pad, stream, d_jobs, njobs, d_order, overflow);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "obmc (row) launch: %s", hipGetErrorString (e));
@@ -1142,9 +1147,9 @@ obmc_row_tile_width (bool uv)
 
 int
 launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int planes_per_job,
-    const uint32_t * d_order)        // planes_per_job 3: (U, V) pairs from pair images
+    const uint32_t * d_order, uint32_t * overflow)   // planes_per_job 3: (U, V) pairs from pair images
 {
-  return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order);
+  return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order, overflow);
 }
 
 }                               // namespace schro

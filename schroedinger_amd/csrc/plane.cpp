@@ -271,6 +271,45 @@ iiwt_chain (SchroHipContext * ctx, int nplanes, int depth, int filter, JOBFN lev
 
 extern "C" {
 
+// r04: the planes of a batch whose combine could not be the register kernel's last step: residual plane in the
+// scratch + prediction (or + 128) -> picture, by the convert kernel
+static int
+iiwt_combine_temps (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes, int depth, int bpp,
+    const std::vector < size_t > &scratch_off, const std::vector < int >&scratch_stride)
+{
+  int tw, th;
+  convert_tile_geometry (&tw, &th);
+  std::vector < ConvertJob > cj;
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipIwtPlane & pl = planes[p];
+    if (!pl.combine || !scratch_stride[(size_t) p * depth])
+      continue;
+    ConvertJob j;
+    memset (&j, 0, sizeof (j));
+    j.src = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth];
+    j.src_stride = scratch_stride[(size_t) p * depth];
+    j.dst = (uint8_t *) pl.dst;
+    j.dst_stride = pl.dst_stride;
+    j.w = pl.out_width;
+    j.h = pl.out_height;
+    j.pred = pl.combine == 1 ? pl.pred : nullptr;
+    j.pred_stride = pl.pred_stride;
+    j.tiles_x = div_up (j.w, tw);
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (j.h, th);
+    cj.push_back (j);
+  }
+  if (cj.empty ())
+    return 0;
+  void *d_jobs;
+  int r = push_args (ctx, cj.data (), sizeof (ConvertJob) * cj.size (), &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
+  return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, (int) cj.size (), tile_base, bpp);
+}
+
 int
 schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, int nplanes,
     int depth, int filter, int bpp)
@@ -293,12 +332,30 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     SCHRO_HIP_REQUIRE (pl.width > 0 && pl.height > 0 && pl.width % (1 << depth) == 0
         && pl.height % (1 << depth) == 0,
         "iiwt_batch: plane %d size %dx%d is not a multiple of 2^depth", p, pl.width, pl.height);
-    SCHRO_HIP_REQUIRE (pl.src_stride >= pl.width * bpp && pl.dst_stride >= pl.width * bpp,
+    // r04, the combine form: dst is the u8 PICTURE (out_width x out_height inside the transform's size)
+    SCHRO_HIP_REQUIRE (pl.combine >= 0 && pl.combine <= 2 && (pl.combine == 0 || (pl.out_width > 0 && pl.out_height > 0
+                && pl.out_width <= pl.width && pl.out_height <= pl.height)) && (pl.combine != 1 || (pl.pred && pl.pred_stride >= pl.out_width)),
+        "iiwt_batch: plane %d: combine %d needs out_width x out_height inside the transform (and a prediction plane for 1)", p, pl.combine);
+    SCHRO_HIP_REQUIRE (pl.src_stride >= pl.width * bpp && pl.dst_stride >= (pl.combine ? pl.out_width : pl.width * bpp),
         "iiwt_batch: plane %d stride too small", p);
     {
       const char *s0 = (const char *) pl.src, *s1 = s0 + (size_t) pl.src_stride * pl.height;
-      const char *d0 = (const char *) pl.dst, *d1 = d0 + (size_t) pl.dst_stride * pl.height;
+      const char *d0 = (const char *) pl.dst, *d1 = d0 + (size_t) pl.dst_stride * (pl.combine ? pl.out_height : pl.height);
       SCHRO_HIP_REQUIRE (s1 <= d0 || d1 <= s0, "iiwt_batch: plane %d src and dst overlap", p);
+    }
+    // a combine plane whose finest level cannot take the register kernel's combine form (s32, the fidelity
+    // filter, unaligned planes) goes through a residual plane in the scratch and the convert kernel
+    if (pl.combine) {
+      const bool direct = bpp == 2 && iiwt_reg_supported (filter, bpp) && (pl.width / 2) % 4 == 0 && pl.height / 2 >= 12
+          && ((((uintptr_t) pl.src | (uintptr_t) pl.src_stride | (uintptr_t) pl.dst | (uintptr_t) pl.dst_stride) & 7) == 0)
+          // (the prediction's rows: 8-byte aligned and readable up to a multiple of 8 columns)
+          && (pl.combine != 1 || ((((uintptr_t) pl.pred | (uintptr_t) pl.pred_stride) & 7) == 0 && pl.pred_stride >= ((pl.out_width + 7) & ~7)));
+      if (!direct) {
+        int stride = (int) round_up ((size_t) pl.width * bpp, 128);
+        scratch_off[(size_t) p * depth] = total;
+        scratch_stride[(size_t) p * depth] = stride;
+        total += round_up ((size_t) stride * pl.height, 256);
+      }
     }
     for (int l = 1; l < depth; l++) {
       int w = pl.width >> l, h = pl.height >> l;
@@ -339,6 +396,9 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     fb = envb ? atoi (envb) : (use_reg ? 1 : 0);
     fb = std::max (0, std::min (fb, depth - 1));
     int want = env ? atoi (env) : 0;
+    for (int p = 0; p < nplanes; p++)
+      if (planes[p].combine)
+        want = 0;               // (the combine form belongs to the per-level kernels)
     nl = std::min (std::min (want, depth - fb), iiwt_fused_max_levels (filter, bpp));
     const int vl = 8 / bpp;
     for (int p = 0; p < nplanes && nl >= 2; p++) {
@@ -379,6 +439,10 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         j.sb_stride[0] = planes[p].src_stride;
         j.dst = planes[p].dst;
         j.dst_stride = planes[p].dst_stride;
+        if (planes[p].combine) {        // (s32: always through a residual plane in the scratch)
+          j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth];
+          j.dst_stride = scratch_stride[(size_t) p * depth];
+        }
         j.w = planes[p].width;
         j.h = planes[p].height;
         j.tiles_x = div_up (j.w / 8, bxs);
@@ -389,8 +453,11 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       int r = push_args (ctx, j3.data (), sizeof (IwtJob) * j3.size (), &d_j3);
       if (r)
         return r;
-      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
-      return launch_iiwt_haar3 (ctx->stream, (const IwtJob *) d_j3, nplanes, tile_base, filter);
+      {
+        ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
+        r = launch_iiwt_haar3 (ctx->stream, (const IwtJob *) d_j3, nplanes, tile_base, filter);
+      }
+      return r ? r : iiwt_combine_temps (ctx, planes, nplanes, depth, bpp, scratch_off, scratch_stride);
     }
   }
 
@@ -417,9 +484,20 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     j.sb_stride[2] = vstride * 2;
     j.sb[3] = base + vstride + (size_t) (w / 2) * bpp;
     j.sb_stride[3] = vstride * 2;
-    if (level == 0) {
+    if (level == 0 && pl.combine && scratch_stride[(size_t) p * depth]) {
+      // (combine through a residual plane in the scratch: see above)
+      j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth];
+      j.dst_stride = scratch_stride[(size_t) p * depth];
+    } else if (level == 0) {
       j.dst = pl.dst;
       j.dst_stride = pl.dst_stride;
+      if (pl.combine) {
+        j.pred = pl.combine == 1 ? pl.pred : nullptr;
+        j.pred_stride = pl.pred_stride;
+        j.out_w = pl.out_width;
+        j.out_h = pl.out_height;
+        j.pad2 = 1;             // (combine form)
+      }
     } else {
       j.dst = (char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level];
       j.dst_stride = scratch_stride[(size_t) p * depth + level];
@@ -431,7 +509,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     bool src_al = (nc % vl) == 0 && nc >= vl;
     for (int s = 0; s < 4; s++)
       src_al = src_al && (((uintptr_t) j.sb[s] | (uintptr_t) j.sb_stride[s]) & 7) == 0;
-    bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & 15) == 0;
+    bool dst_al = (((uintptr_t) j.dst | (uintptr_t) j.dst_stride) & (j.pad2 ? 7 : 15)) == 0;
     j.flags = (src_al ? 1 : 0) | (dst_al ? 2 : 0);
     j.ctr = -1;
     *src_al_out = src_al;
@@ -456,14 +534,17 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   // Built as VERDICT r03 asked and measured: 8 x 2160p 0.135 ms against 0.103 for a launch per level (8 x 1080p
   // 0.058 against 0.038) -- a tile's extra round trip to its producers' counters and the written-through LL
   // stores cost more than the launch gaps they remove -- so it is opt-in: SCHRO_HIP_IIWT_CHAIN=1
-  if (use_reg && depth >= 2 && !nl && SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN")) != 0) {
+  bool any_combine = false;
+  for (int p = 0; p < nplanes; p++)
+    any_combine |= planes[p].combine != 0;
+  if (use_reg && depth >= 2 && !nl && !any_combine && SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN")) != 0) {
     int done = 0;
     const int r = iiwt_chain (ctx, nplanes, depth, filter, level_job, level_is_small, &done);
     if (r || done)
       return r;
   }
 
-  std::vector < IwtJob > jobs, rjobs, hjobs;
+  std::vector < IwtJob > jobs, rjobs, hjobs, cjobs;
   for (int level = depth - 1; level >= 0; level--) {
     if (nl && level >= fb && level < fb + nl) {
       if (level == fb + nl - 1) {
@@ -473,10 +554,11 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       }
       continue;
     }
-    int tile_base = 0, rtile_base = 0, htile_base = 0;
+    int tile_base = 0, rtile_base = 0, htile_base = 0, ctile_base = 0;
     jobs.clear ();
     rjobs.clear ();
     hjobs.clear ();
+    cjobs.clear ();
     int lruc = ruc, lrur = rur, lrmin = rmin, small = 0;
     if (use_reg) {
       small = level_is_small (level);
@@ -494,9 +576,17 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         hjobs.push_back (j);
       } else if (use_reg && src_al && dst_al && nc % 4 == 0 && nr >= lrmin) {
         j.tiles_x = div_up (nc, lruc);
-        j.tile_base = rtile_base;
-        rtile_base += j.tiles_x * div_up (nr, lrur);
-        rjobs.push_back (j);
+        if (j.pad2) {           // the combine form: its own launch (another instantiation of the kernel)
+          j.tile_base = ctile_base;
+          ctile_base += j.tiles_x * div_up (nr, lrur);
+          cjobs.push_back (j);
+        } else {
+          j.tile_base = rtile_base;
+          rtile_base += j.tiles_x * div_up (nr, lrur);
+          rjobs.push_back (j);
+        }
+      } else if (j.pad2) {
+        return set_error (SCHRO_HIP_EINVAL, "iiwt_batch: plane %d: the combine form was promised a register tile it cannot have", p);
       } else {
         j.tiles_x = div_up (nc, uc);
         j.tile_base = tile_base;
@@ -504,10 +594,12 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         jobs.push_back (j);
       }
     }
-    void *d_rjobs = nullptr, *d_jobs = nullptr, *d_hjobs = nullptr;
+    void *d_rjobs = nullptr, *d_jobs = nullptr, *d_hjobs = nullptr, *d_cjobs = nullptr;
     int r = 0;
     if (!rjobs.empty ())
       r = push_args (ctx, rjobs.data (), sizeof (IwtJob) * rjobs.size (), &d_rjobs);
+    if (!r && !cjobs.empty ())
+      r = push_args (ctx, cjobs.data (), sizeof (IwtJob) * cjobs.size (), &d_cjobs);
     if (!r && !hjobs.empty ())
       r = push_args (ctx, hjobs.data (), sizeof (IwtJob) * hjobs.size (), &d_hjobs);
     if (!r && !jobs.empty ())
@@ -516,7 +608,9 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
       return r;
     ProfileScope ps (ctx, level == 0 ? SCHRO_HIP_KERNEL_IIWT_FINEST : SCHRO_HIP_KERNEL_IIWT_COARSE);
     if (d_rjobs)
-      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter, small);
+      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_rjobs, (int) rjobs.size (), rtile_base, filter, small, 0);
+    if (!r && d_cjobs)
+      r = launch_iiwt_reg (ctx->stream, (const IwtJob *) d_cjobs, (int) cjobs.size (), ctile_base, filter, small, 1);
     if (!r && d_hjobs)
       r = launch_iiwt_haar (ctx->stream, (const IwtJob *) d_hjobs, (int) hjobs.size (), htile_base, filter);
     if (!r && d_jobs)
@@ -524,8 +618,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     if (r)
       return r;
   }
-
-  return 0;
+  return iiwt_combine_temps (ctx, planes, nplanes, depth, bpp, scratch_off, scratch_stride);
 }
 
 int
@@ -1532,6 +1625,11 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         "obmc_batch: mv_precision %d out of range", pl.mv_precision);
     SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
     SCHRO_HIP_REQUIRE (!pl.residual || pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
+    // r04: the prediction alone, for the wavelet's combine form: it must fit the u8 plane it is written to
+    SCHRO_HIP_REQUIRE (!pl.prediction_only || (!pl.residual && pl.picture_weight_1 >= 0 && pl.picture_weight_2 >= 0
+            && pl.picture_weight_1 + pl.picture_weight_2 <= (1 << pl.picture_weight_bits)),
+        "obmc_batch: plane %d: prediction_only needs residual NULL and picture weights >= 0 that sum to at most 1 << bits "
+        "(a prediction of 8 bits); other pictures take the residual form", p);
     SCHRO_HIP_REQUIRE (pl.picture_weight_bits >= 0 && pl.picture_weight_bits <= 6,
         "obmc_batch: picture_weight_bits %d unsupported", pl.picture_weight_bits);
     // bits 0 with a gain other than 1: the reference's edge-block ROUND_SHIFT is
@@ -1596,7 +1694,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     const int variant = variant_of (pl);
     const int nd_row = (variant == 1 && use_row) ? obmc_row_nd (j, false) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
-    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0);
+    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only ? 1 << 19 : 0);
     row_nd[p] = nd_row;
   }
   // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
@@ -1622,11 +1720,11 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // (obmc_row.hip, UV form); what it does not take (eighth pel, other weights, long rows) reads
     // its component out of the pair images in obmc.hip
     if (a.ref_ps && b.ref_ps && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
-        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1]) {
+        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1] && !planes[p].prediction_only == !planes[p + 1].prediction_only) {
       const int nd = obmc_row_nd (a, true);
       if (nd) {
         row_nd[p] = row_nd[p + 1] = nd;
-        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18);
+        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only ? 1 << 19 : 0);
         p++;
       }
       continue;
@@ -1649,7 +1747,15 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       for (int p = first; p < nplanes; p++)
         if (!done[p] && key[p] == key[first])
           nd = std::max (nd, row_nd[p]);
-    const bool paired = (key[first] >> 17) & 1, uv = (key[first] >> 18) & 1;
+    const bool paired = (key[first] >> 17) & 1, uv = (key[first] >> 18) & 1, pred_only = (key[first] >> 19) & 1;
+    uint32_t *overflow = nullptr;
+    if (pred_only) {
+      if (!ctx->dc_gave_up) {
+        SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
+        memset (ctx->dc_gave_up, 0, 64);
+      }
+      overflow = ctx->dc_gave_up + 2;
+    }
     const int variant = uv ? 4 : nd ? 3 : ((key[first] >> 4) & 15);
     std::vector < ObmcJob > jobs;
     int tile_base = 0;
@@ -1692,8 +1798,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order)
-          : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order);
+      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow)
+          : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
     }
     if (r)
       return r;

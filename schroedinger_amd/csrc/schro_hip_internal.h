@@ -83,6 +83,12 @@ struct IwtJob {
   // reads its output in the launch: level 0), and its tile form
   int dep_rows2, dep_tiles_y, dep_tiles_x, dep_ctr;
   int ctr, small;
+  // combine form (r04, level 0 of the register kernel): dst is the u8 PICTURE, out_w x out_h inside the
+  // iwt-padded w x h; pred: the OBMC prediction to add (u8), NULL: + 128 (a picture without references)
+  const uint8_t *pred;
+  int pred_stride;
+  int out_w, out_h;
+  int pad2;
 };
 
 struct ConvertJob {
@@ -92,6 +98,9 @@ struct ConvertJob {
   int w, h;
   int tiles_x;
   int tile_base;
+  const uint8_t *pred;          // r04: NULL: + 128 (offsetconvert); else the prediction to add (rrshift6_add's last steps)
+  int pred_stride;
+  int pad;
 };
 
 struct PackJob {
@@ -400,7 +409,7 @@ bool iiwt_reg_supported (int filter, int bpp);
 void iiwt_reg_geometry (int filter, int small, int *useful_cols, int *useful_row_pairs,
     int *min_row_pairs);
 int launch_iiwt_reg (hipStream_t stream, const IwtJob * d_jobs, int njobs, int total_tiles,
-    int filter, int small);
+    int filter, int small, int combine);
 int launch_iiwt_chain (hipStream_t stream, const IwtJob * d_jobs, const uint32_t * d_order, int n_tiles, uint32_t * ctrl,
     uint32_t run, uint32_t * gave_up, uint32_t epoch, int filter);
 void iiwt_tile_geometry (int filter, int bpp, int *useful_cols,
@@ -433,13 +442,14 @@ void dequant_tile_geometry (int *tw, int *th);
 int launch_table_copy (hipStream_t stream, void *dst, const void *src, size_t bytes);
 // schro_table_quant[i] and schro_table_offset_1_2[i] (intra) / _3_8[i] (inter)
 void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t * offset);
+// overflow: NULL, or (prediction_only launches) the word a prediction that does not fit 8 bits is reported in
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
-    int total_tiles, int prec, int variant, const uint32_t * d_order);
+    int total_tiles, int prec, int variant, const uint32_t * d_order, uint32_t * overflow);
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
 int obmc_row_nd (const ObmcJob & job, bool uv);
 int obmc_row_tile_width (bool uv);
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
-    int max_planes, const uint32_t * d_order);
+    int max_planes, const uint32_t * d_order, uint32_t * overflow);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);

@@ -1,0 +1,183 @@
+"""GPU parity: the combine form (r04) -- the OBMC launch writes its PREDICTION, the inverse wavelet's last step adds
+it and writes the picture; the residual picture never exists in memory.
+
+  reference:  schro_motion_render (motion, mc_tmp, frame, add = TRUE, output) = orc_rrshift6_add_s16_2d / _s32_2d
+              over the inverse transform's output (schromotion8.c:852-876; the stages of the reference's GPU paths:
+              x_render_motion -> mc_tmp_frame, x_combine adds, schrodecoder.c:1742-1760, :1908-1921), and
+              schro_frame_convert (+ 128) for pictures without references (:1788-1790)
+  here:       schro_hip_obmc_batch (prediction_only) -> u8 prediction; schro_hip_iiwt_batch (combine 1 | 2)
+
+Checked against the oracle's two-step result (inverse transform, then motion render with that residual) on every
+route: the register kernel's combine epilogue (s16, filters 0-4 and 6, aligned planes), the fallback through a
+residual plane in the scratch (s32, the fidelity filter, unaligned / tiny planes), pictures smaller than the
+transform (crop), chroma from pair images, and the frame-layer calls.  DC values outside 8 bits are refused loudly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import schroedinger_amd as sa
+import synth
+from schroedinger_amd import _lib, frames
+
+pytestmark = pytest.mark.gpu
+
+
+def up(v, depth):
+    return -(-v // (1 << depth)) * (1 << depth)
+
+
+def run_case(ctx, w, h, depth, filt, dtype=np.int16, chroma=(1, 1), prec=2, blk=(12, 8), seed=1, intra=False, edit_mv=None,
+             src_pad=0):
+    hs, vs = chroma
+    dims = [(h, w), (-(-h >> vs), -(-w >> hs)), (-(-h >> vs), -(-w >> hs))]
+    iw = [(up(ph, depth), up(pw, depth)) for (ph, pw) in dims]
+    resid = [(synth.image_s(ih, iwd, dtype, seed=seed + k).astype(np.int64) * 3).astype(dtype) for k, (ih, iwd) in enumerate(iw)]
+    coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+    res_want = [O.inverse_iwt(c, depth, filt) for c in coeffs]
+    d_co = [ctx.upload(c) for c in coeffs]
+    outs = [ctx.plane(ph, pw, np.uint8).fill(0x5e) for (ph, pw) in dims]
+    keep = list(d_co) + list(outs)
+    if intra:
+        ctx.iiwt_batch([(d_co[k], outs[k], None) for k in range(3)], depth, filt)
+        for k, (ph, pw) in enumerate(dims):
+            assert np.array_equal(outs[k].download(), O.convert_u8(res_want[k], pw, ph)), (k, "intra")
+        [p.free() for p in keep]
+        return
+    P = synth.motion_params(w, h, blk[0], blk[1], prec, (1, 1, 1), chroma)
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 20 << prec, seed + 5)
+    if edit_mv is not None:
+        edit_mv(mv)
+    d_mv = ctx.upload_bytes(mv)
+    refs_np = [[synth.picture_u8(ph, pw, seed=seed + 10 * (r + 1) + k) for k, (ph, pw) in enumerate(dims)] for r in range(2)]
+    pair = prec > 0 and hs == 1
+    hp = []
+    for r in range(2):
+        if prec == 0:
+            planes = [ctx.upload(p) for p in refs_np[r]]
+            hp.append(planes)
+            keep += planes
+            continue
+        g0 = ctx.hp_plane(*dims[0])
+        ctx.upsample_batch([(ctx.upload(refs_np[r][0]), g0)])
+        if pair:
+            gp = ctx.hp_plane(*dims[1], pair=True)
+            ctx.upsample_batch([((ctx.upload(refs_np[r][1]), ctx.upload(refs_np[r][2])), gp)])
+            hp.append([g0, gp, gp])
+            keep += [g0, gp]
+        else:
+            g1, g2 = ctx.hp_plane(*dims[1]), ctx.hp_plane(*dims[2])
+            ctx.upsample_batch([(ctx.upload(refs_np[r][1]), g1), (ctx.upload(refs_np[r][2]), g2)])
+            hp.append([g0, g1, g2])
+            keep += [g0, g1, g2]
+    preds = [ctx.plane(ph, pw, np.uint8).fill(0xa1) for (ph, pw) in dims]
+    keep += preds + [d_mv]
+    ctx.obmc_batch([sa.obmc_plane(d_mv, P, k, hp[0][k], hp[1][k], None, preds[k], prediction_only=True) for k in range(3)])
+    ctx.iiwt_batch([(d_co[k], outs[k], preds[k]) for k in range(3)], depth, filt)
+    ctx.synchronize()
+    for k, (ph, pw) in enumerate(dims):
+        want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                               O.UpComp(refs_np[1][k], upsample=prec > 0), res_want[k], pw, ph)
+        got = outs[k].download()
+        if not np.array_equal(got, want):
+            bad = np.argwhere(got != want)
+            raise AssertionError("component %d: %d mismatches, first at %s" % (k, len(bad), tuple(bad[0])))
+    [p.free() for p in keep]
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4, 6])
+def test_register_form_filters(ctx, filt):
+    for (w, h, depth) in [(320, 240, 3), (176, 144, 2), (640, 368, 4), (1920, 1080, 3)]:
+        run_case(ctx, w, h, depth, filt, seed=filt + 3)
+
+
+def test_sizes_that_crop_and_ragged_edges(ctx):
+    # pictures smaller than the transform (1080 rows in 1088; widths that are not multiples of 8 or 16), tiny planes
+    for (w, h) in [(100, 70), (97, 61), (64, 36), (130, 18), (72, 132), (500, 260), (1000, 120), (24, 16)]:
+        run_case(ctx, w, h, 2, 0, seed=w)
+        run_case(ctx, w, h, 3, 1, chroma=(1, 0), prec=1, seed=h)
+
+
+def test_fallback_through_a_residual_plane(ctx):
+    # what the register kernel's epilogue does not take: s32 coefficients (the Haar one-pass kernel too), the 8-tap
+    # fidelity filter, depth 1
+    run_case(ctx, 320, 240, 3, 0, dtype=np.int32)
+    run_case(ctx, 320, 256, 3, 3, dtype=np.int32)
+    run_case(ctx, 320, 240, 2, 5)
+    run_case(ctx, 320, 240, 1, 0)
+    run_case(ctx, 208, 112, 3, 6, chroma=(0, 0), prec=3, blk=(16, 12))
+    run_case(ctx, 208, 112, 3, 2, chroma=(1, 1), prec=0)
+
+
+@pytest.mark.parametrize("filt,dtype", [(0, np.int16), (1, np.int16), (3, np.int32), (5, np.int16)])
+def test_pictures_without_references(ctx, filt, dtype):
+    for (w, h, depth) in [(176, 144, 3), (97, 61, 2), (1920, 1080, 3)]:
+        run_case(ctx, w, h, depth, filt, dtype=dtype, intra=True)
+
+
+def test_headline_size(ctx):
+    run_case(ctx, 3840, 2160, 3, 0, seed=2)
+
+
+def test_predictions_outside_8_bits_are_refused(ctx):
+    # a DC value outside [-128, 127]: the reference's 16-bit arithmetic wraps; the u8 prediction plane cannot carry
+    # it -- the launch raises an error that the next synchronisation reports (the residual form stays exact)
+    def widen(mv):
+        dc = np.flatnonzero((mv["flags"] & 3) == 0)
+        mv["v"][dc[::3], :3] = 300
+    with pytest.raises(sa.SchroHipError, match="does not fit"):
+        run_case(ctx, 320, 240, 3, 0, edit_mv=widen)
+    ctx.synchronize()           # (reported once)
+    # ... and weights whose prediction can leave 8 bits are refused at the call
+    P = synth.motion_params(96, 64, 12, 8, 2, (2, 3, 1), (1, 1))
+    d_mv = ctx.upload_bytes(synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 8, 1))
+    g, out = ctx.hp_plane(64, 96), ctx.plane(64, 96, np.uint8)
+    with pytest.raises(sa.SchroHipError, match="prediction_only"):
+        ctx.obmc_batch([sa.obmc_plane(d_mv, P, 0, g, g, None, out, prediction_only=True)])
+
+
+@pytest.mark.parametrize("hs,vs,prec,filt,depth", [(1, 1, 2, 0, 3), (1, 0, 1, 1, 4), (0, 0, 3, 6, 2)])
+def test_frame_layer_calls(ctx, hs, vs, prec, filt, depth):
+    """schro_motion_render_hip (motion, mc_tmp, NULL, FALSE, NULL) + schro_frame_inverse_iwt_transform_combine_hip:
+    the stage structure of the reference's GPU paths, and the intra form (prediction NULL)."""
+    w, h = 320, 240
+    lib = ctx.lib
+    pd = [(h, w), (-(-h >> vs), -(-w >> hs)), (-(-h >> vs), -(-w >> hs))]
+    iw = [(up(ph, depth), up(pw, depth)) for (ph, pw) in pd]
+    P = synth.motion_params(w, h, 12, 8, prec, (1, 1, 1), (hs, vs))
+    params = frames.make_params(wavelet_filter_index=filt, transform_depth=depth, iwt_luma_width=iw[0][1], iwt_luma_height=iw[0][0],
+                                iwt_chroma_width=iw[1][1], iwt_chroma_height=iw[1][0], num_refs=2,
+                                **{k: P[k] for k in ("xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma", "mv_precision",
+                                                     "picture_weight_bits", "picture_weight_1", "picture_weight_2", "x_num_blocks", "y_num_blocks")})
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, seed=4)
+    resid = [synth.image_s(ih, iwd, np.int16, seed=20 + k) for k, (ih, iwd) in enumerate(iw)]
+    coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+    res_want = [O.inverse_iwt(c, depth, filt) for c in coeffs]
+    fmt16, fmt8 = frames.frame_format(np.int16, hs, vs), frames.frame_format(np.uint8, hs, vs)
+    transform_frame = frames.HostFrame(coeffs, hs, vs)
+    refs_np = [[synth.picture_u8(ph, pw, seed=40 + 10 * r + k) for k, (ph, pw) in enumerate(pd)] for r in range(2)]
+    refs = []
+    for r in range(2):
+        d = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(refs_np[r], hs, vs))
+        if prec > 0:
+            u = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+            sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
+            refs.append(u)
+        else:
+            refs.append(d)
+    mc_tmp, out = frames.DeviceFrame(ctx, fmt8, w, h), frames.DeviceFrame(ctx, fmt8, w, h)
+    motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
+    sa.check(lib.schro_motion_render_hip(C.byref(motion), mc_tmp.ptr(), None, 0, None))
+    sa.check(lib.schro_frame_inverse_iwt_transform_combine_hip(out.ptr(), transform_frame.ptr(), C.byref(params), mc_tmp.ptr()))
+    got = out.download()
+    for k, (ph, pw) in enumerate(pd):
+        want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                               O.UpComp(refs_np[1][k], upsample=prec > 0), res_want[k], pw, ph)
+        assert np.array_equal(got[k], want), k
+    sa.check(lib.schro_frame_inverse_iwt_transform_combine_hip(out.ptr(), transform_frame.ptr(), C.byref(params), None))
+    got = out.download()
+    for k, (ph, pw) in enumerate(pd):
+        assert np.array_equal(got[k], O.convert_u8(res_want[k], pw, ph)), (k, "intra")
+    for f in (mc_tmp, out) + tuple(refs):
+        f.unref()
