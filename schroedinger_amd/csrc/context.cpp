@@ -119,14 +119,11 @@ int
 big_table_commit (SchroHipContext * ctx, size_t bytes)
 {
   SchroHipContext::BigTable & b = ctx->big_q[ctx->cur][ctx->big_turn[ctx->cur]];
-  static const bool dma = SCHRO_ENV ("SCHRO_HIP_TABLE_COPY") && !strcmp (SCHRO_ENV ("SCHRO_HIP_TABLE_COPY"), "dma");   // (experiment)
-  if (dma) {
-    SCHRO_HIP_CHECK (hipMemcpyAsync (b.d, b.h, bytes, hipMemcpyHostToDevice, ctx->stream));
-  } else {
-    const int r = launch_table_copy (ctx->stream, b.d, b.h, bytes);
-    if (r)
-      return r;
-  }
+  // (a kernel, not hipMemcpyAsync: the runtime's copy path blocks the calling thread when the queue waits for another
+  // queue's event)
+  const int r = launch_table_copy (ctx->stream, b.d, b.h, bytes);
+  if (r)
+    return r;
   SCHRO_HIP_CHECK (hipEventRecord (b.copied, ctx->stream));
   b.pending = true;
   return 0;

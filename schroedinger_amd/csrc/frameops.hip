@@ -110,10 +110,7 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
 
 // (tile height, a multiple of 16: 8 x 2160p upsample 0.0570 ms per step at 16, 0.0565 at 32, 0.0648 at 64 --
 // the kernel is bound by its writes, two homes per column)
-#ifndef SCHRO_UP_TH
-#define SCHRO_UP_TH 16
-#endif
-constexpr int kUpTW = 128, kUpTH = SCHRO_UP_TH;
+constexpr int kUpTW = 128, kUpTH = 16;
 
 typedef short short2v __attribute__ ((ext_vector_type (2)));
 

@@ -113,13 +113,9 @@ haar_quad (uint32_t ll, uint32_t hl, uint32_t lh, uint32_t hh, uint32_t * o00, u
   *o11 = hh;
 }
 
-#ifdef SCHRO_HAAR3_NT             // (scratch builds: coefficients and pixels as streaming accesses)
-#define H3_LOAD(V, p) __builtin_nontemporal_load ((const SCHRO_GLOBAL V *) (p))
-#define H3_STORE(p, ...) __builtin_nontemporal_store ((__VA_ARGS__), (SCHRO_GLOBAL u32x4 *) (p))
-#else
+// (plain accesses: streaming loads and stores measured no different here, r03)
 #define H3_LOAD(V, p) gload < V > (p)
 #define H3_STORE(p, ...) gstore < u32x4 > ((p), (__VA_ARGS__))
-#endif
 template < int SHIFT >
 __global__ __launch_bounds__ (kHaarThreads)
 void iiwt_haar3_s32_kernel (const IwtJob * __restrict__ jobs, int njobs)

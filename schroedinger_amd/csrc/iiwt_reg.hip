@@ -493,15 +493,11 @@ reg_tile_at (const IwtJob & job, int tx, int ty, int lane, WAIT wait = WAIT ())
 // compiler spreads to 144, three waves).  Alone the kernel runs the same either way; beside the other batch's
 // OBMC (seven waves of 69 registers on every SIMD) the smaller waves find room: finest level 0.0722 -> 0.0703 ms,
 // the 8 x 2160p step 0.4054 -> 0.4012.  Five waves (102 registers) spill: 0.101 ms.
-#ifndef SCHRO_IIWT_WAVES
-#define SCHRO_IIWT_WAVES 4
-#endif
 // (the Haar filters have no halo: all 12 row pairs are worked on, and 128 registers would spill 80 - 90 of them)
-#define IIWT_REG_WAVES(F, RP) (((F) == 3 || (F) == 4) && (RP) == 12 ? 3 : SCHRO_IIWT_WAVES)
-#ifndef SCHRO_IIWT_COMBINE_WAVES
-#define SCHRO_IIWT_COMBINE_WAVES 3
-#endif
-#define IIWT_REG_WAVES_M(F, RP, MODE) ((MODE) == 4 && (RP) == 12 ? SCHRO_IIWT_COMBINE_WAVES : IIWT_REG_WAVES (F, RP))
+#define IIWT_REG_WAVES(F, RP) (((F) == 3 || (F) == 4) && (RP) == 12 ? 3 : 4)
+// (the combine form of the 12-pair tiles: 4 waves spill ~40 registers of the epilogue and are still the faster
+// launch -- 8 x 2160p finest level 0.081 ms against 0.086 ms at 3 waves without a spill, r04)
+#define IIWT_REG_WAVES_M(F, RP, MODE) ((MODE) == 4 && (RP) == 12 ? 4 : IIWT_REG_WAVES (F, RP))
 template < int F, int RP, int MODE >
 __global__ __launch_bounds__ (kRegThreads) __attribute__ ((amdgpu_waves_per_eu (IIWT_REG_WAVES_M (F, RP, MODE), IIWT_REG_WAVES_M (F, RP, MODE))))
 void iiwt_reg_kernel (const IwtJob * __restrict__ jobs, int njobs, int total_tiles)

@@ -603,11 +603,9 @@ run_string (RunReader & r, const SliceJob & job, const SliceParams & P, int32_t 
   }
 }
 
-#ifndef SCHRO_RUN_WAVES
-#define SCHRO_RUN_WAVES 6
-#endif
+constexpr int kRunWaves = 6;
 template < typename T, int ARITH >
-__global__ __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (SCHRO_RUN_WAVES, SCHRO_RUN_WAVES)))
+__global__ __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (kRunWaves, kRunWaves)))
 void slice_run_kernel (const SliceJob * __restrict__ jobs, const SliceParams P)
 {
   extern __shared__ int32_t stage[];    // 64 * (P.run_cap + 1) words

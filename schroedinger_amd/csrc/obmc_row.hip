@@ -674,13 +674,8 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
     ov.x = __builtin_amdgcn_perm (a23, a01, 0x07060302u);
     ov.y = __builtin_amdgcn_perm (a67, a45, 0x07060302u);
     const int x = x_lo + 8 * g;
-#ifdef SCHRO_UV_PLAIN_STORE
-    gstore < u32x2 > (iou.out + (size_t) y * iou.out_stride + x, ou);
-    gstore < u32x2 > (iov.out + (size_t) y * iov.out_stride + x, ov);
-#else
     __builtin_nontemporal_store (ou, (SCHRO_GLOBAL u32x2 *) (iou.out + (size_t) y * iou.out_stride + x));
     __builtin_nontemporal_store (ov, (SCHRO_GLOBAL u32x2 *) (iov.out + (size_t) y * iov.out_stride + x));
-#endif
   }
 }
 
