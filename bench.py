@@ -255,7 +255,7 @@ def cpu_baseline(wl, cores, reps=10):
                 res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
                 outs.append(O.motion_render(wl.mv_np[f], O.MotionParams(**wl.P), k, ups[0][k], ups[1][k],
                                             res, w, h))
-            if rep == 0:
+            if rep == 0 and i == 0:
                 results[i] = outs
 
     t0 = time.perf_counter()
@@ -430,7 +430,7 @@ class HostSide:
         return self.out[0, o:o + p.nbytes].reshape(p.height, p.stride)[:, :p.width]
 
 
-def pcie_pipeline(wl, quantised, steps=12, warmup=4):
+def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
     """The step with the host hand-over in it, as a three-stage pipeline on the context's four queues
     (include/schro_hip.h, asynchronous transfers): batch k + 1's coefficients (dense s16 frames, or
     quantised values for schro_hip_dequant_batch) and vectors go up on the H2D queue while batch k's
@@ -442,9 +442,13 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
     c.synchronize()
     # three batches' buffers: one going up, one in the kernels, one coming down (with two the download of
     # batch k holds back the kernels of batch k + 2 and the copy engines idle a quarter of the time)
+    per_queue = (form or os.environ.get("SCHRO_BENCH_PCIE", "queues" if quantised else "copyq")) == "queues"
+    nq = int(os.environ.get("SCHRO_BENCH_PCIE_QUEUES", "3"))
+    want = max(3, nq) if per_queue else 3
     if not hasattr(wl, "pcie_sets"):
-        wl.pcie_sets = list(wl.sets) + [BatchSet(wl, 4242 + 50 * n) for n in range(max(0, 3 - len(wl.sets)))]
-    sets = wl.pcie_sets
+        wl.pcie_sets = list(wl.sets)
+    wl.pcie_sets += [BatchSet(wl, 4242 + 50 * n) for n in range(len(wl.pcie_sets), want)]
+    sets = wl.pcie_sets[:want]
     nb = len(sets)
     hs = [HostSide(wl, b, quantised, 900 + 100 * i) for i, b in enumerate(sets)]
 
@@ -453,12 +457,10 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
     # thread until that event (quantised hand-over: 1.4 of the step's 2.3 ms spent inside the two copy calls,
     # scripts/pcie_host_time.py; the dense hand-over does not show it) -- SCHRO_BENCH_PCIE=copyq is the r03 form
     # on the copy queues with marks.
-    per_queue = os.environ.get("SCHRO_BENCH_PCIE", "queues" if quantised else "copyq") == "queues"
-
     def step_one_queue(k):
         i = k % nb
         b, h = sets[i], hs[i]
-        c.select_queue(i % 3)
+        c.select_queue(i % nq)
         if quantised:
             h.d_blob.block.upload_async(h.blob)
         else:
@@ -515,7 +517,7 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4):
            "h2d_MB": round(hs[0].h2d / 1e6, 1), "d2h_MB": round(hs[0].d2h / 1e6, 1),
            "host_GBs": round((hs[0].h2d + hs[0].d2h) / dt / 1e9, 1), "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3),
            "downloaded_equals_device": bool(ok),
-           "queues": "a batch's copies and kernels in order on one queue, three batches on three queues" if per_queue
+           "queues": "a batch's copies and kernels in order on one queue, %d batches on %d queues" % (nb, nq) if per_queue
                      else "copies on the H2D / D2H queues beside the kernels, marks for the dependencies",
            "note": "pinned host buffers, asynchronous copies, one copy per kind and step; %d steps in steady state; "
                    "never `value`" % steps}
@@ -912,6 +914,12 @@ def main():
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
             out["iiwt_1080p"] = iiwt_1080p(ctx)
+            # ... and with 1 and 32 pictures per launch set (one batch in flight / two): where latency ends
+            out["iiwt_1080p"]["pictures_per_launch_set"] = {
+                str(n): {"one_batch_ms": r["median_ms"], "one_batch_frac_of_8TBs": r["frac_of_8TBs"],
+                         "two_batches_ms": r["two_batches_in_flight"]["ms"],
+                         "two_batches_frac_of_8TBs": r["two_batches_in_flight"]["frac_of_8TBs"]}
+                for n, r in ((n, iiwt_1080p(ctx, frames=n)) for n in (1, 32))}
             out["kernels"].update(extra_kernels(wl))
             out["pcie_inclusive"] = pcie_pipeline(wl, quantised=False)
             out["frame_layer_2160p"] = frame_layer_2160p()
@@ -936,10 +944,27 @@ def main():
                                    "sample": "%d pictures (%d threads x 10, one picture per thread at a "
                                    "time) of the same workload + the two reference upsamples, oracle/ C "
                                    "port, gcc -O3" % (10 * cores, cores)}
+            # the same on every core this process may use (the 16-thread figure is a one-GPU box's share,
+            # not the host's ceiling); capped at 128 threads to bound the sample's memory
+            try:
+                nproc = len(os.sched_getaffinity(0))
+            except AttributeError:
+                nproc = os.cpu_count() or 1
+            nthr = max(1, min(nproc, 128))
+            if nthr > cores:
+                v_all, _, _ = cpu_baseline(wl, nthr, reps=4)
+                out["cpu_baseline"]["all_cores"] = {"value": round(v_all, 2), "threads": nthr, "usable_cpus": nproc,
+                                                    "sample": "%d pictures (%d threads x 4)" % (4 * nthr, nthr)}
             out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
         if world == 1 and not args.headline_only:
             wl.queues = 2
             out["pcie_inclusive_quantised"] = pcie_pipeline(wl, quantised=True)
+            # the r03 form beside it (copies on the two copy queues, marks): the copy engines overlap better, and the
+            # host thread spends most of the step inside the two copy calls
+            alt = pcie_pipeline(wl, quantised=True, form="copyq")
+            out["pcie_inclusive_quantised"]["copy_queues_form"] = {
+                "ms_per_step": alt["ms_per_step"], "Mpix_per_s": alt["Mpix_per_s"],
+                "host_enqueue_ms_per_step": alt["host_enqueue_ms_per_step"]}
             out["lowdelay_8k"] = lowdelay_8k(ctx)
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):

@@ -114,7 +114,14 @@ int schro_hip_download_2d_async (SchroHipContext * ctx, void *dst, int dst_strid
 int schro_hip_queue_synchronize (SchroHipContext * ctx, int queue);
 /* Restricts a queue's kernels to the compute units whose bits are set in mask[0 .. words) (the queue's
  * pending work is waited for first; hipExtStreamCreateWithCUMask): two queues with disjoint masks run
- * side by side without sharing a CU's registers and LDS. */
+ * side by side without sharing a CU's registers and LDS.
+ * The queue becomes a NEW stream, and one with default flags (the runtime offers no non-blocking form of
+ * this call): unlike the context's other queues it synchronises implicitly with the process's NULL stream,
+ * so a synchronous hipMemcpy / hipMemset anywhere in the process serialises against it.  This library's
+ * per-picture calls issue every copy, memset and kernel on an explicit queue; its set-up calls
+ * (schro_hip_dequant_plan_new, a scratch buffer that grows) use synchronous ones.  If the runtime refuses the mask the
+ * old queue stays in place (drained) and the call returns SCHRO_HIP_EDEVICE.  Measured slower than whole
+ * batches per queue for this path: a tool for experiments, not part of the decode loop. */
 int schro_hip_queue_set_cu_mask (SchroHipContext * ctx, int queue, const uint32_t * mask, int words);
 /* waits for everything enqueued on both queues */
 int schro_hip_synchronize (SchroHipContext * ctx);
