@@ -296,14 +296,23 @@ main (int argc, char **argv)
       const int g = k / GROUP, set = k % NSETS;
       const double ta = now_ms ();
       CHECK (schro_hip_context_select_queue (ctx, s));
+      /* the transform frame and the vectors up (pinned host memory): the picture's first commands, in front of
+       * any wait for another queue */
+      CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
+      CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
       if (k % GROUP == 0) {
-        /* new references (a decoder has them on the device already): up and upsampled on this picture's queue,
-         * behind the pictures of two groups back that read this reference set (all queues meet: no host wait) */
+        /* new references (a decoder has them on the device already): up and upsampled on this picture's queue.
+         * The copies go FIRST: the integer-pel frames of this set were last read by the upsample of two groups back,
+         * which the host has long waited for, and a copy enqueued behind a wait for another queue's event blocks the
+         * calling thread until that event -- seen here as 7 ms calls whenever the other queues were still
+         * busy at a group's first picture.  Then the queues meet (kernels behind a wait cost the host nothing): the
+         * half-pel planes are rewritten behind the pictures of two groups back that predicted from them. */
+        for (int r = 0; r < 2; r++)
+          CHECK (schro_frame_to_hip_async (d_ref[g & 1][r], h_refs[2 * g + r]));
         for (int o = 0; o < SLOTS; o++)
           if (o != s)
             CHECK (schro_hip_queue_wait (ctx, s, o));
         for (int r = 0; r < 2; r++) {
-          CHECK (schro_frame_to_hip_async (d_ref[g & 1][r], h_refs[2 * g + r]));
           d_up[g & 1][r]->upsample_done = 0;
           CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));       /* x_upsample */
         }
@@ -311,9 +320,6 @@ main (int argc, char **argv)
       } else if (k % GROUP < SLOTS) {
         CHECK (schro_hip_queue_wait_mark (ctx, REFS + (g & 1)));       /* the other queues' first picture of the group */
       }
-      /* the transform frame and the vectors up (pinned host memory), in order in front of the stages */
-      CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
-      CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
       const double tb = now_ms ();
       t_up += tb - ta;
       CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[s], d_transform[s], &params));    /* x_wavelet_transform */
