@@ -442,7 +442,8 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
     c.synchronize()
     # three batches' buffers: one going up, one in the kernels, one coming down (with two the download of
     # batch k holds back the kernels of batch k + 2 and the copy engines idle a quarter of the time)
-    per_queue = (form or os.environ.get("SCHRO_BENCH_PCIE", "queues" if quantised else "copyq")) == "queues"
+    form = form or os.environ.get("SCHRO_BENCH_PCIE", "handover")
+    per_queue, handover = form == "queues", form == "handover"
     nq = int(os.environ.get("SCHRO_BENCH_PCIE_QUEUES", "3"))
     want = max(3, nq) if per_queue else 3
     if not hasattr(wl, "pcie_sets"):
@@ -452,7 +453,7 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
     nb = len(sets)
     hs = [HostSide(wl, b, quantised, 900 + 100 * i) for i, b in enumerate(sets)]
 
-    # r04: a batch's copies and kernels in order on ONE queue (batch k on queue k % 3), nothing crosses queues.
+    # r04, second form ("queues"): a batch's copies and kernels in order on ONE queue (batch k on queue k % 3), nothing crosses queues.
     # On this runtime a hipMemcpyAsync whose queue waits for another queue's event can block the calling
     # thread until that event (quantised hand-over: 1.4 of the step's 2.3 ms spent inside the two copy calls,
     # scripts/pcie_host_time.py; the dense hand-over does not show it) -- SCHRO_BENCH_PCIE=copyq is the r03 form
@@ -471,7 +472,43 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
         batch_kernels(c, b)
         b.out_arena.block.download_async(h.out)
 
+    # r04, third form ("handover"): the copy queues of the r03 form, but the host hands over picture batch k - 2 -- waits for
+    # ITS download, the one wait a decoder has anyway -- before it enqueues anything of step k.  Every event a copy of step k
+    # then depends on has already fired when the copy is enqueued (the set's last readers are the kernels of step k - 3, the
+    # download of step k - 1 follows kernels that ran while download k - 2 was on the bus), so no copy call blocks, and the copy
+    # engines overlap as in the r03 form.
+    waited = [0.0]
+
+    def step_handover(k):
+        i = k % nb
+        b, h = sets[i], hs[i]
+        if k >= 2:
+            tw = time.perf_counter()
+            c.queue_mark_synchronize(12 + (k - 2) % nb)
+            waited[0] += time.perf_counter() - tw
+        c.select_queue(c.QUEUE_H2D)
+        if quantised:
+            h.d_blob.block.upload_async(h.blob)
+        else:
+            b.co_arena.block.upload_async(h.co)
+        b.mv_arena.block.upload_async(h.mv)
+        c.queue_mark(i)
+        c.select_queue(k % 2)
+        c.queue_wait_mark(i)
+        if quantised:
+            wl.dq_plan.run(planes=h.dq_planes)
+        batch_kernels(c, b)
+        c.queue_mark(4 + i)
+        if k >= 1:
+            j = (k - 1) % nb
+            c.select_queue(c.QUEUE_D2H)
+            c.queue_wait_mark(4 + j)
+            sets[j].out_arena.block.download_async(hs[j].out)
+            c.queue_mark(12 + j)
+
     def step(k):
+        if handover:
+            return step_handover(k)
         if per_queue:
             return step_one_queue(k)
         i = k % nb
@@ -504,10 +541,16 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
         step(k)
     c.select_queue(0)
     c.synchronize()
+    waited[0] = 0.0
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
         step(k)
     t_host = time.perf_counter() - t0
+    if handover:        # the last step's pictures
+        c.select_queue(c.QUEUE_D2H)
+        j = (warmup + steps - 1) % nb
+        c.queue_wait_mark(4 + j)
+        sets[j].out_arena.block.download_async(hs[j].out)
     c.select_queue(0)
     c.synchronize()
     dt = (time.perf_counter() - t0) / steps
@@ -518,9 +561,13 @@ def pcie_pipeline(wl, quantised, steps=12, warmup=4, form=None):
            "host_GBs": round((hs[0].h2d + hs[0].d2h) / dt / 1e9, 1), "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3),
            "downloaded_equals_device": bool(ok),
            "queues": "a batch's copies and kernels in order on one queue, %d batches on %d queues" % (nb, nq) if per_queue
+                     else "copies on the H2D / D2H queues, marks; the host hands over batch k - 2 before it enqueues step k" if handover
                      else "copies on the H2D / D2H queues beside the kernels, marks for the dependencies",
            "note": "pinned host buffers, asynchronous copies, one copy per kind and step; %d steps in steady state; "
                    "never `value`" % steps}
+    if handover:
+        res["host_wait_for_handover_ms_per_step"] = round(waited[0] / steps * 1e3, 3)
+        res["host_enqueue_ms_per_step"] = round((t_host - waited[0]) / steps * 1e3, 3)
     if quantised:
         dense = sum(co.nbytes for cf in sets[0].coeff_np for co in cf)
         res["share_of_dense_coefficient_bytes"] = round((hs[0].h2d - sets[0].mv_arena.used) / dense, 3)
@@ -959,12 +1006,14 @@ def main():
         if world == 1 and not args.headline_only:
             wl.queues = 2
             out["pcie_inclusive_quantised"] = pcie_pipeline(wl, quantised=True)
-            # the r03 form beside it (copies on the two copy queues, marks): the copy engines overlap better, and the
-            # host thread spends most of the step inside the two copy calls
-            alt = pcie_pipeline(wl, quantised=True, form="copyq")
-            out["pcie_inclusive_quantised"]["copy_queues_form"] = {
-                "ms_per_step": alt["ms_per_step"], "Mpix_per_s": alt["Mpix_per_s"],
-                "host_enqueue_ms_per_step": alt["host_enqueue_ms_per_step"]}
+            # the two other forms beside it: the r03 form -- the same queues and marks, the host never waits on
+            # purpose and spends most of the step blocked inside the two copy calls --, and a batch's copies and kernels in
+            # order on one queue (never blocks, the copy engines overlap worse)
+            for key, f in (("copy_queues_no_handover_form", "copyq"), ("one_queue_per_batch_form", "queues")):
+                alt = pcie_pipeline(wl, quantised=True, form=f)
+                out["pcie_inclusive_quantised"][key] = {
+                    "ms_per_step": alt["ms_per_step"], "Mpix_per_s": alt["Mpix_per_s"],
+                    "host_enqueue_ms_per_step": alt["host_enqueue_ms_per_step"]}
             out["lowdelay_8k"] = lowdelay_8k(ctx)
         print(json.dumps(out))
         if out.get("parity", "").startswith("MISMATCH"):

@@ -239,6 +239,10 @@ class Context:
         """Later work on the selected queue waits for the latest recording of `mark`."""
         check(self.lib.schro_hip_queue_wait_mark(self.h, mark))
 
+    def queue_mark_synchronize(self, mark):
+        """The calling thread waits for the latest recording of `mark` (and for nothing else)."""
+        check(self.lib.schro_hip_queue_mark_synchronize(self.h, mark))
+
     def queue_wait(self, waiter, signaller):
         """Later work on `waiter` starts after everything enqueued so far on `signaller`."""
         check(self.lib.schro_hip_queue_wait(self.h, waiter, signaller))

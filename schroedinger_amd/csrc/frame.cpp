@@ -185,6 +185,25 @@ copy_frame_async (SchroHipContext * ctx, SchroHipFrame * dest, const SchroHipFra
   }
   int bpp = format_bpp (src->format);
   SCHRO_HIP_REQUIRE (bpp && format_bpp (dest->format) == bpp, "frame copy: depth mismatch");
+  // (r04) Frames as the domains hand them out -- the components one behind the other in ONE block, the same sizes and
+  // strides on both sides -- cross as one copy: three copies per 2160p frame cost the pipelined frame layer 0.05 ms per
+  // picture.  (The row padding of such a frame belongs to it: copying it too is harmless.)
+  {
+    bool one = true;
+    size_t total = 0;
+    for (int k = 0; k < 3 && one; k++) {
+      const SchroHipFrameData *s = &src->components[k];
+      const SchroHipFrameData *d = &dest->components[k];
+      one = s->data && d->data && s->width == d->width && s->height == d->height && s->width > 0 && s->height > 0
+          && s->stride == d->stride && s->stride >= s->width * bpp && s->length == d->length
+          && (size_t) s->length == (size_t) s->stride * s->height
+          && (const uint8_t *) s->data == (const uint8_t *) src->components[0].data + total
+          && (const uint8_t *) d->data == (const uint8_t *) dest->components[0].data + total;
+      total += (size_t) s->length;
+    }
+    if (one && total < ((size_t) 1 << 31))
+      return copy_2d_async (ctx, dest->components[0].data, (int) total, src->components[0].data, (int) total, (int) total, 1, kind);
+  }
   for (int k = 0; k < 3; k++) {
     const SchroHipFrameData *s = &src->components[k];
     SchroHipFrameData *d = &dest->components[k];

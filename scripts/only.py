@@ -17,4 +17,4 @@ else:
     wl = bench.Workload(ctx, 8, seed=1, queues=2)
     for _ in range(3):
         wl.step()
-    print(json.dumps(bench.pcie_pipeline(wl, quantised=(what == "pcie_quantised"))))
+    print(json.dumps(bench.pcie_pipeline(wl, quantised=(what == "pcie_quantised"), form=(sys.argv[2] if len(sys.argv) > 2 else None))))

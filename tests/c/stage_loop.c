@@ -28,7 +28,10 @@
 #define NSETS 4                 /* distinct coefficient frames / vector fields, used in turn */
 #define GROUP 8                 /* pictures that share a pair of references */
 #define DEPTH 3
+#ifndef SLOTS
 #define SLOTS 3                 /* pictures in flight in pass (ii) */
+#endif
+#define LAG (SLOTS - 1)        /* the host hands over picture k - LAG before it enqueues picture k */
 
 static uint32_t lcg_state;
 static uint32_t
@@ -265,76 +268,82 @@ main (int argc, char **argv)
     ms[0] = (now_ms () - t0) / npic;
   }
 
-  /* ---- pass (ii): three pictures in flight, nothing waits but the hand-over of a finished picture ----
-   * One QUEUE per picture in flight: a picture's copies up, its stage calls and its copy down are enqueued
-   * in order on queue k % 3, so nothing of it depends on another queue (measured on this runtime: a
-   * hipMemcpyAsync whose queue waits for an event of ANOTHER queue blocks the calling thread until that
-   * event -- 0.68 ms per 2160p picture, the whole pipeline in lockstep).  Only the references
-   * cross queues: a mark, once per group of 8 pictures. */
-  enum { REFS = 0, DOWN = 12 };                 /* marks: REFS + (g & 1), DOWN + slot */
+  /* ---- pass (ii): pictures in flight, nothing waits but the hand-over of a finished picture ----
+   * Copies up on the H2D queue, the stage calls on queue 0, copies down on the D2H queue, marks between them
+   * (INTEGRATION 3a).  The order of the calls matters on this runtime: a hipMemcpyAsync whose queue waits for
+   * an event that has NOT fired yet blocks the calling thread until it has, and the copy engines
+   * only overlap when the copies sit on queues of their own.  So the host does the one wait a decoder has
+   * anyway -- it hands over picture k - LAG (LAG = SLOTS - 1) -- before it enqueues anything of picture k: the frames picture k's
+   * upload overwrites were last read by picture k - SLOTS, and the download of picture k - 1 is enqueued once
+   * its stage calls are done (a wait of the host, not of the D2H queue).  Measured here: 0.70 ms per picture
+   * with a picture's copies and stage calls in order on one queue (three queues in flight); one run in four
+   * at that and the others at 1.04 with the reference uploads behind a wait that joined the queues. */
+  enum { UP = 0, DONE = SLOTS, DOWN = 2 * SLOTS };      /* marks: + slot (16 marks: SLOTS <= 5) */
   CHECK (schro_hip_context_set_stage_completion (ctx, 0));
   double waited = 0, t_up = 0, t_stage = 0, t_down = 0;      /* where the host's time goes in the timed repetition */
   for (int rep = 0; rep < 2; rep++) {
     CHECK (schro_hip_synchronize (ctx));
     waited = t_up = t_stage = t_down = 0;
     const double t0 = now_ms ();
-    for (int k = 0; k < npic + SLOTS; k++) {
+    for (int k = 0; k < npic + LAG; k++) {
       const int s = k % SLOTS;
-      if (k >= SLOTS) {
-        /* picture k - SLOTS leaves: the host waits for ITS download only */
+      if (k >= LAG) {
+        /* picture k - LAG leaves: the host waits for ITS download only */
+        const int s2 = (k - LAG) % SLOTS;
         const double tw = now_ms ();
-        CHECK (schro_hip_queue_mark_synchronize (ctx, DOWN + s));
+        CHECK (schro_hip_queue_mark_synchronize (ctx, DOWN + s2));
         waited += now_ms () - tw;
         if (rep == 0) {
-          sums[1][k - SLOTS] = checksum (h_out[s]);
+          sums[1][k - LAG] = checksum (h_out[s2]);
           if (dump)
-            write_file (dir, "%s/out_pipelined%d.bin", k - SLOTS, h_out[s]->regions[0], frame_bytes (h_out[s]));
+            write_file (dir, "%s/out_pipelined%d.bin", k - LAG, h_out[s2]->regions[0], frame_bytes (h_out[s2]));
         }
       }
-      if (k >= npic)
-        continue;
-      const int g = k / GROUP, set = k % NSETS;
-      const double ta = now_ms ();
-      CHECK (schro_hip_context_select_queue (ctx, s));
-      /* the transform frame and the vectors up (pinned host memory): the picture's first commands, in front of
-       * any wait for another queue */
-      CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
-      CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
-      if (k % GROUP == 0) {
-        /* new references (a decoder has them on the device already): up and upsampled on this picture's queue.
-         * The copies go FIRST: the integer-pel frames of this set were last read by the upsample of two groups back,
-         * which the host has long waited for, and a copy enqueued behind a wait for another queue's event blocks the
-         * calling thread until that event -- seen here as 7 ms calls whenever the other queues were still
-         * busy at a group's first picture.  Then the queues meet (kernels behind a wait cost the host nothing): the
-         * half-pel planes are rewritten behind the pictures of two groups back that predicted from them. */
-        for (int r = 0; r < 2; r++)
-          CHECK (schro_frame_to_hip_async (d_ref[g & 1][r], h_refs[2 * g + r]));
-        for (int o = 0; o < SLOTS; o++)
-          if (o != s)
-            CHECK (schro_hip_queue_wait (ctx, s, o));
-        for (int r = 0; r < 2; r++) {
-          d_up[g & 1][r]->upsample_done = 0;
-          CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));       /* x_upsample */
-        }
-        CHECK (schro_hip_queue_mark (ctx, REFS + (g & 1)));
-      } else if (k % GROUP < SLOTS) {
-        CHECK (schro_hip_queue_wait_mark (ctx, REFS + (g & 1)));       /* the other queues' first picture of the group */
+      if (k < npic) {
+        const int g = k / GROUP, set = k % NSETS;
+        const double ta = now_ms ();
+        /* the transform frame and the vectors up (pinned host memory); a group's first picture also brings the new
+         * references (a decoder has them on the device already) */
+        CHECK (schro_hip_context_select_queue (ctx, SCHRO_HIP_QUEUE_H2D));
+        CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
+        CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
+        if (k % GROUP == 0)
+          for (int r = 0; r < 2; r++)
+            CHECK (schro_frame_to_hip_async (d_ref[g & 1][r], h_refs[2 * g + r]));
+        CHECK (schro_hip_queue_mark (ctx, UP + s));
+        const double tb = now_ms ();
+        t_up += tb - ta;
+        CHECK (schro_hip_context_select_queue (ctx, 0));
+        CHECK (schro_hip_queue_wait_mark (ctx, UP + s));         /* (kernels behind a wait cost the host nothing) */
+        if (k % GROUP == 0)
+          for (int r = 0; r < 2; r++) {
+            d_up[g & 1][r]->upsample_done = 0;
+            CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));     /* x_upsample */
+          }
+        CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[s], d_transform[s], &params));  /* x_wavelet_transform */
+        SchroHipMotion motion;
+        memset (&motion, 0, sizeof (motion));
+        motion.src1 = d_up[g & 1][0];
+        motion.src2 = d_up[g & 1][1];
+        motion.motion_vectors = d_mv[s];        /* already on the device */
+        motion.params = &params;
+        CHECK (schro_motion_render_hip (&motion, NULL, d_frame[s], 1, d_out[s]));             /* x_render_motion */
+        CHECK (schro_hip_queue_mark (ctx, DONE + s));
+        t_stage += now_ms () - tb;
       }
-      const double tb = now_ms ();
-      t_up += tb - ta;
-      CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[s], d_transform[s], &params));    /* x_wavelet_transform */
-      SchroHipMotion motion;
-      memset (&motion, 0, sizeof (motion));
-      motion.src1 = d_up[g & 1][0];
-      motion.src2 = d_up[g & 1][1];
-      motion.motion_vectors = d_mv[s];          /* already on the device */
-      motion.params = &params;
-      CHECK (schro_motion_render_hip (&motion, NULL, d_frame[s], 1, d_out[s]));               /* x_render_motion */
-      const double tc = now_ms ();
-      t_stage += tc - tb;
-      CHECK (schro_hipframe_to_cpu_async (h_out[s], d_out[s]));                               /* x_combine */
-      CHECK (schro_hip_queue_mark (ctx, DOWN + s));
-      t_down += now_ms () - tc;
+      if (k >= 1 && k - 1 < npic) {
+        /* x_combine of picture k - 1: its stage calls have had the time of picture k's enqueue; the host makes sure,
+         * so that the copy call finds its event fired */
+        const int s1 = (k - 1) % SLOTS;
+        const double tw = now_ms ();
+        CHECK (schro_hip_queue_mark_synchronize (ctx, DONE + s1));
+        const double tc = now_ms ();
+        waited += tc - tw;
+        CHECK (schro_hip_context_select_queue (ctx, SCHRO_HIP_QUEUE_D2H));
+        CHECK (schro_hipframe_to_cpu_async (h_out[s1], d_out[s1]));
+        CHECK (schro_hip_queue_mark (ctx, DOWN + s1));
+        t_down += now_ms () - tc;
+      }
     }
     CHECK (schro_hip_context_select_queue (ctx, 0));
     CHECK (schro_hip_synchronize (ctx));
