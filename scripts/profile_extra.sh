@@ -15,6 +15,11 @@ for leg in "iiwt_1080p 8" "lowdelay_8k"; do
 done
 cd $repo
 for leg in iiwt_1080p lowdelay_8k; do
-  echo "== $leg kernel stats"; cut -d, -f1-4 gpurun_out/x_$leg/run_kernel_stats.csv
+  echo "== $leg kernel stats (calls, total ns, average ns, min ns, max ns)"
+  python3 -c "
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    print('%-100s %6s %12s %12.0f %9s %9s' % (r['Name'][:100], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), r['MinNs'], r['MaxNs']))
+" gpurun_out/x_$leg/run_kernel_stats.csv
   echo "== $leg counters"; python3 scripts/pmc_sum.py gpurun_out/xpmc_${leg}_fetch gpurun_out/xpmc_${leg}_write gpurun_out/xpmc_${leg}_inst
 done > gpurun_out/extra_summary.txt
