@@ -96,6 +96,66 @@ def test_pictures_through_the_copy_queues(ctx):
             assert np.array_equal(got[n][k], wants[n][k]), (n, k)
 
 
+def test_pictures_through_the_copy_queues_handover_order(ctx):
+    """The same pipeline in the order DESIGN 5 (r04) prescribes -- the host hands over picture n - 2 (waits for ITS download
+    mark and nothing else) before it enqueues picture n; the download of picture n - 1 is enqueued once its kernels' mark has
+    fired -- in the combine form (prediction-only OBMC, the wavelet's epilogue writes the picture).  No copy is ever enqueued
+    behind an event that has not fired; the pictures are the oracle's."""
+    P, dims, _, _ = picture_inputs(0)
+    refs_np = [[synth.picture_u8(h, w, seed=300 + 10 * r + k) for k, (h, w) in enumerate(dims)] for r in range(2)]
+    ups = [[O.UpComp(p) for p in comps] for comps in refs_np]
+    hp = [[ctx.hp_plane(h, w) for (h, w) in dims] for _ in range(2)]
+    ctx.upsample_batch([(ctx.upload(refs_np[r][k]), hp[r][k]) for r in range(2) for k in range(3)])
+    ctx.synchronize()
+    npic, slots = 7, 3
+    UP, DONE, DOWN = 0, 4, 12
+    slot = []
+    for s in range(slots):
+        slot.append(dict(
+            h_co=[ctx.host_array(d, np.int16) for d in dims], h_out=[ctx.host_array(d, np.uint8) for d in dims],
+            h_mv=ctx.host_array((1, 20 * P["x_num_blocks"] * P["y_num_blocks"]), np.uint8),
+            d_co=[ctx.plane(h, w, np.int16) for (h, w) in dims], d_pred=[ctx.plane(h, w, np.uint8) for (h, w) in dims],
+            d_out=[ctx.plane(h, w, np.uint8) for (h, w) in dims]))
+        slot[s]["d_mv"] = ctx.plane(1, slot[s]["h_mv"].shape[1], np.uint8)
+    wants, got = [], {}
+    for n in range(npic + 2):
+        if n >= 2:
+            ctx.queue_mark_synchronize(DOWN + (n - 2) % slots)          # picture n - 2 leaves
+            got[n - 2] = [o.copy() for o in slot[(n - 2) % slots]["h_out"]]
+        if n < npic:
+            s = slot[n % slots]
+            _, _, coeffs, mv = picture_inputs(10 * n)
+            for k in range(3):
+                s["h_co"][k][...] = coeffs[k]
+            s["h_mv"][...] = np.ascontiguousarray(mv).view(np.uint8).reshape(1, -1)
+            wants.append([O.motion_render(mv, O.MotionParams(**P), k, ups[0][k], ups[1][k],
+                                          O.inverse_iwt(coeffs[k], DEPTH, FILT), dims[k][1], dims[k][0]) for k in range(3)])
+            ctx.select_queue(ctx.QUEUE_H2D)                             # (this queue never waits for anything)
+            for k in range(3):
+                s["d_co"][k].upload_async(s["h_co"][k])
+            s["d_mv"].upload_async(s["h_mv"])
+            ctx.queue_mark(UP + n % slots)
+            ctx.select_queue(n % 2)
+            ctx.queue_wait_mark(UP + n % slots)
+            ctx.obmc_batch([sa.obmc_plane(s["d_mv"], P, k, hp[0][k], hp[1][k], None, s["d_pred"][k], prediction_only=True)
+                            for k in range(3)])
+            ctx.iiwt_batch([(s["d_co"][k], s["d_out"][k], s["d_pred"][k]) for k in range(3)], DEPTH, FILT)
+            ctx.queue_mark(DONE + n % slots)
+        if 1 <= n <= npic:
+            t = slot[(n - 1) % slots]
+            ctx.queue_mark_synchronize(DONE + (n - 1) % slots)          # its kernels are done: the copy's event has fired
+            ctx.select_queue(ctx.QUEUE_D2H)
+            for k in range(3):
+                t["d_out"][k].download_async(t["h_out"][k])
+            ctx.queue_mark(DOWN + (n - 1) % slots)
+    ctx.select_queue(0)
+    ctx.synchronize()
+    assert sorted(got) == list(range(npic))
+    for n in range(npic):
+        for k in range(3):
+            assert np.array_equal(got[n][k], wants[n][k]), (n, k)
+
+
 def test_frame_layer_async_twins(ctx):
     lib = ctx.lib
     dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
