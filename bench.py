@@ -997,11 +997,23 @@ def main():
                 nproc = len(os.sched_getaffinity(0))
             except AttributeError:
                 nproc = os.cpu_count() or 1
-            nthr = max(1, min(nproc, 128))
+            quota = None            # a container's CPU share (cgroup v2 cpu.max "quota period"): more threads than that only queue
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    quota = max(1, -(-int(q) // int(per)))
+            except (OSError, ValueError):
+                pass
+            nthr = max(1, min(nproc, quota or nproc, 128))
+            out["cpu_baseline"]["usable_cpus"] = nproc
+            out["cpu_baseline"]["cgroup_cpu_quota"] = quota
             if nthr > cores:
                 v_all, _, _ = cpu_baseline(wl, nthr, reps=4)
-                out["cpu_baseline"]["all_cores"] = {"value": round(v_all, 2), "threads": nthr, "usable_cpus": nproc,
+                out["cpu_baseline"]["all_cores"] = {"value": round(v_all, 2), "threads": nthr,
                                                     "sample": "%d pictures (%d threads x 4)" % (4 * nthr, nthr)}
+            else:
+                out["cpu_baseline"]["all_cores"] = "the %d-thread figure: this process may use %d CPU(s)%s" % (
+                    cores, nproc, ", its cgroup's quota is %d" % quota if quota else "")
             out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
         if world == 1 and not args.headline_only:
             wl.queues = 2
