@@ -700,11 +700,12 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 
   const uint64_t t_start = __builtin_amdgcn_s_memtime ();
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  const uint32_t entry = order ? __builtin_amdgcn_readfirstlane (gload < uint32_t > (order + bid)) : 0u;
+  const uint32_t entry = order ? order[bid] : 0u;        // (a uniform address: a scalar load)
   const ObmcJob job = jobs[order ? (int) (entry >> 16) : find_job (jobs, njobs, bid)];
   // scratch runs (SCHRO_HIP_OBMC_STAMPS): cycles since the workgroup started, per phase
 #define RSTAMP(n) do { if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) \
     job.stamps[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime () - t_start; } while (0)
+  RSTAMP (7);                   // (the job is here)
   const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
   const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x;
@@ -750,7 +751,9 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       mv_pre[1] = gload < uint32_t > (mvp + 12);
       mv_pre[2] = gload < uint32_t > (mvp + 16);
     }
+    RSTAMP (10);                // (accumulator cleared, ramps, the vectors asked for)
     __syncthreads ();           // ramps, counters
+    RSTAMP (8);
     // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
     // 2 * ND words, zero beyond the block's width.  UV: a word per pixel, its weight for both components
     for (int i = tid; i < yblen * 2 * ND && i < G::kWCap; i += kRThreads) {

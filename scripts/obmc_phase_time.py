@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """OBMC alone on bench.py's workload (GPU box): wall time of a luma-only and a chroma-only batch
 over 20 launches, and -- with SCHRO_HIP_OBMC_STAMPS=1 -- the row kernel's in-kernel phase stamps
-(cycles since the workgroup started: 1 set-up, 2 decode, 3 items, 4 passes, 5 rim, 6 barrier,
-9 end; 10/11 one two-reference pass without / with the accumulate) and the residency per CU.
+(cycles since the workgroup started: 7 the job is here, 10 accumulator cleared / ramps / vectors asked for, 8 the barrier
+behind them, 1 set-up done (weight tables), 2 decode, 3 items, 4 passes, 5 rim, 6 barrier, 9 end) and the residency per CU.
+r04, luma, prediction-only jobs (medians of 16 320 tiles): 808 / 3280 / 3628 / 5728 / 9564 / 12508 / 22512 / 22624 / 22872 /
+23652 -- with 6.4 workgroups of four waves per CU every vector instruction of a wave waits for six others': the phases'
+lengths are their instruction counts.
 PLANES=luma|chroma restricts the run; MOTION=random|smooth|const replaces the bench's motion
 field (uniform in +-16 pel per block) by a pan + slow zoom or by one vector per reference:
 the launch takes the same time with all three."""
@@ -27,7 +30,8 @@ def main():
     b = wl.sets[0]
     nbx, nby = wl.P["x_num_blocks"], wl.P["y_num_blocks"]
     kind = os.environ.get("MOTION", "random")
-    jobs = b.obmc_jobs
+    # (r04: the prediction-only jobs of the combine form, as bench.py's step runs them; FORM=add: the r03 jobs)
+    jobs = b.obmc_jobs if os.environ.get("FORM") == "add" or not b.pred_jobs else b.pred_jobs
     if kind != "random":
         jobs = []
         for f in range(wl.frames):
