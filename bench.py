@@ -159,6 +159,24 @@ class Workload:
             # the pictures
             s = k % self.queues
             b = self.sets[s]
+            if self.queues == 2 and os.environ.get("SCHRO_BENCH_PIPE", "whole") == "stages":
+                # (A/B form: prediction on queue 1, the transform that adds it on queue 0 -- step k + 1's OBMC beside step k's
+                # wavelet; measured no faster than whole batches per queue)
+                c.select_queue(1)
+                if alone or self.prev_alone:
+                    c.queue_wait(1, 0)
+                self.prev_alone = alone
+                c.queue_wait_mark(8 + s)        # the transform that last read this set's prediction planes
+                c.upsample_batch(b.up_luma)
+                c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3 == 0])
+                c.upsample_batch(b.up_chroma)
+                c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
+                c.queue_mark(s)
+                c.select_queue(0)
+                c.queue_wait_mark(s)
+                c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
+                c.queue_mark(8 + s)
+                return
             if self.queues > 1:
                 c.select_queue(s)
                 if alone or self.prev_alone:
