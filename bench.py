@@ -75,7 +75,7 @@ class BatchSet:
         # their PREDICTION (pred planes), the inverse wavelet's last step adds it and writes the picture -- the
         # residual picture is never written or read
         self.combine = wl.combine
-        self.iwt_combine, self.pred_jobs = [], []
+        self.iwt_combine, self.pred_jobs, self.iwt_coarse, self.iwt_ll = [], [], [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
         self.co_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * wl.frames))
@@ -100,6 +100,10 @@ class BatchSet:
                 if self.combine:
                     d_pred = ctx.plane(h, w, np.uint8)
                     self.iwt_combine.append((d_co, out, d_pred))
+                    # the transform in two calls (SchroHipIwtPlane.ll): the levels above 0 into an LL plane ...
+                    d_ll = ctx.plane(h // 2, w // 2, np.int16)
+                    self.iwt_coarse.append((d_co.level_view(1), d_ll))
+                    self.iwt_ll.append(d_ll)
                 g = min(f // REF_GROUP, wl.groups - 1)
                 # (SCHRO_BENCH_ONE_REF=1, a footprint experiment: both references read the same planes)
                 r1 = 0 if os.environ.get("SCHRO_BENCH_ONE_REF") == "1" else 1
@@ -184,11 +188,26 @@ class Workload:
                         if other != s:
                             c.queue_wait(s, other)
                 self.prev_alone = alone
+            # (A/B, SCHRO_BENCH_SPLIT_IWT=1: measured slower, 0.361 against 0.350 ms per step)
+            split = self.queues > 1 and not alone and os.environ.get("SCHRO_BENCH_SPLIT_IWT", "0") == "1"
+            if split:
+                # ... which do not depend on the prediction: on a queue of their own (2 + s) beside this batch's upsample
+                # and OBMC launches -- two launches of a few thousand waves that are latency, not bandwidth
+                c.select_queue(2 + s)
+                c.queue_wait_mark(12 + s)       # the finest level that last read this set's LL planes
+                c.iiwt_batch(b.iwt_coarse, DEPTH - 1, FILTER)
+                c.queue_mark(8 + s)
+                c.select_queue(s)
             c.upsample_batch(b.up_luma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3 == 0])
             c.upsample_batch(b.up_chroma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
-            c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
+            if split:
+                c.queue_wait_mark(8 + s)
+                c.iiwt_batch(b.iwt_combine, 1, FILTER, ll=b.iwt_ll)
+                c.queue_mark(12 + s)
+            else:
+                c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
             if self.queues > 1:
                 c.select_queue(0)
             return

@@ -217,6 +217,16 @@ typedef struct {
   int pred_stride;
   int out_width, out_height;
   int combine;
+  /* r04 -- a picture's transform in TWO calls.  ll != NULL: the LL band of this call's COARSEST level (level
+   * depth - 1: (width >> depth) x (height >> depth) samples of the plane's type) is read from this compact plane
+   * instead of from the frame's LL quadrant.  The levels above 0 do not depend on the picture's prediction, so a
+   * host runs them early and beside other work -- call 1: src = the frame, src_stride = 2 x the frame's stride,
+   * width / 2 x height / 2 (the level-1 view of the in-place layout, schroparams.c:319-352), depth - 1 levels,
+   * dst = an LL plane of the host's; call 2, once the prediction exists: the frame itself, depth 1, ll = that
+   * plane, combine as above.  The two calls together are the one call, bit for bit. */
+  const void *ll;
+  int ll_stride;                /* bytes */
+  int reserved;
 } SchroHipIwtPlane;
 
 /* depth levels, Dirac filter index 0..6 (schrobitstream.h:124-132),

@@ -43,6 +43,17 @@ class DevicePlane:
         self.nbytes = self.stride * self.height
         self.ptr = ctx.alloc(self.nbytes)
 
+    def level_view(self, level=1):
+        """The level-`level` view of a coefficient plane in the reference's in-place layout (schroparams.c:319-352): the
+        same memory, {width >> level, height >> level, stride << level} -- the `src` of a call that runs only the levels
+        from `level` up (Context.iiwt_batch)."""
+        v = DevicePlane.__new__(DevicePlane)
+        v.ctx, v.dtype = self.ctx, self.dtype
+        v.height, v.width, v.stride = self.height >> level, self.width >> level, self.stride << level
+        v.nbytes, v.ptr = 0, self.ptr
+        v.free = lambda: None           # (the memory is the parent's)
+        return v
+
     def upload(self, a):
         a = np.ascontiguousarray(a, dtype=self.dtype)
         assert a.shape == (self.height, self.width), (a.shape, self.height, self.width)
@@ -293,11 +304,12 @@ class Context:
 
     # ---- batched plane-level launches (asynchronous on the context stream) ----
 
-    def iiwt_batch(self, pairs, depth, filt):
+    def iiwt_batch(self, pairs, depth, filt, ll=None):
         """pairs: [(src, dst DevicePlane)], all s16 or all s32 -- dst: the residual plane; or, the combine
         form (r04), [(src, out u8 DevicePlane, pred)]: the transform's last step writes the picture
         out = sat_u8 (residual + pred), pred a u8 DevicePlane (the prediction of obmc_batch (prediction_only)) or
-        None for a picture without references (+ 128)."""
+        None for a picture without references (+ 128).  ll: per plane, the DevicePlane that holds the LL band of
+        this call's coarsest level (the output of an earlier call on the planes' level views, `level_view`)."""
         n = len(pairs)
         arr = (_lib.IwtPlane * n)()
         bpp = pairs[0][0].dtype.itemsize
@@ -313,6 +325,10 @@ class Context:
                 arr[k] = _lib.IwtPlane(s.ptr, s.stride, d.ptr, d.stride, s.width, s.height,
                                        pred.ptr if pred is not None else None, pred.stride if pred is not None else 0,
                                        d.width, d.height, 1 if pred is not None else 2)
+            if ll is not None:
+                q = ll[k]
+                assert q.dtype.itemsize == bpp and (q.height, q.width) == (s.height >> depth, s.width >> depth)
+                arr[k].ll, arr[k].ll_stride = q.ptr, q.stride
         check(self.lib.schro_hip_iiwt_batch(self.h, arr, n, depth, filt, bpp))
 
     def pack_u8_batch(self, jobs):

@@ -54,7 +54,8 @@ class IwtPlane(C.Structure):
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
                 ("width", C.c_int), ("height", C.c_int),
                 ("pred", C.c_void_p), ("pred_stride", C.c_int),
-                ("out_width", C.c_int), ("out_height", C.c_int), ("combine", C.c_int)]
+                ("out_width", C.c_int), ("out_height", C.c_int), ("combine", C.c_int),
+                ("ll", C.c_void_p), ("ll_stride", C.c_int), ("reserved", C.c_int)]
 
 
 class ConvertPlane(C.Structure):

@@ -326,6 +326,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   std::vector < size_t > scratch_off ((size_t) nplanes * depth, 0);
   std::vector < int >scratch_stride ((size_t) nplanes * depth, 0);
   size_t total = 0;
+  bool any_ll = false;
   for (int p = 0; p < nplanes; p++) {
     const SchroHipIwtPlane & pl = planes[p];
     SCHRO_HIP_REQUIRE (pl.src && pl.dst, "iiwt_batch: plane %d has a NULL pointer", p);
@@ -338,6 +339,10 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
         "iiwt_batch: plane %d: combine %d needs out_width x out_height inside the transform (and a prediction plane for 1)", p, pl.combine);
     SCHRO_HIP_REQUIRE (pl.src_stride >= pl.width * bpp && pl.dst_stride >= (pl.combine ? pl.out_width : pl.width * bpp),
         "iiwt_batch: plane %d stride too small", p);
+    // r04: the coarsest level's LL band from a plane of the caller's (the transform split in two calls)
+    SCHRO_HIP_REQUIRE (!pl.ll || (pl.ll_stride >= (pl.width >> depth) * bpp && ((uintptr_t) pl.ll | (uintptr_t) pl.ll_stride) % bpp == 0),
+        "iiwt_batch: plane %d: the LL plane's stride %d does not hold %d samples", p, pl.ll_stride, pl.width >> depth);
+    any_ll |= pl.ll != nullptr;
     {
       const char *s0 = (const char *) pl.src, *s1 = s0 + (size_t) pl.src_stride * pl.height;
       const char *d0 = (const char *) pl.dst, *d1 = d0 + (size_t) pl.dst_stride * (pl.combine ? pl.out_height : pl.height);
@@ -397,8 +402,8 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     fb = std::max (0, std::min (fb, depth - 1));
     int want = env ? atoi (env) : 0;
     for (int p = 0; p < nplanes; p++)
-      if (planes[p].combine)
-        want = 0;               // (the combine form belongs to the per-level kernels)
+      if (planes[p].combine || planes[p].ll)
+        want = 0;               // (the combine form and split transforms belong to the per-level kernels)
     nl = std::min (std::min (want, depth - fb), iiwt_fused_max_levels (filter, bpp));
     const int vl = 8 / bpp;
     for (int p = 0; p < nplanes && nl >= 2; p++) {
@@ -422,7 +427,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   // r03: a depth-3 s32 Haar transform (the low-delay 10-bit configurations) is ONE pass over the
   // coefficient frame when every plane allows it (iiwt_haar.hip, iiwt_haar3_s32_kernel);
   // SCHRO_HIP_IIWT_HAAR3=0 keeps a launch per level
-  if (use_haar && depth == 3 && !nl && !(SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3")) == 0)) {
+  if (use_haar && depth == 3 && !nl && !any_ll && !(SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_HAAR3")) == 0)) {
     bool all_ok = true;
     for (int p = 0; p < nplanes && all_ok; p++)
       all_ok = iiwt_haar3_job_ok (planes[p].src, planes[p].src_stride, planes[p].dst, planes[p].dst_stride, planes[p].width,
@@ -475,6 +480,9 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     if (level < depth - 1) {
       ll = (const char *) ctx->scratch_ref () + scratch_off[(size_t) p * depth + level + 1];
       ll_stride = scratch_stride[(size_t) p * depth + level + 1];
+    } else if (pl.ll) {         // (r04: the coarser levels ran in a call of their own)
+      ll = (const char *) pl.ll;
+      ll_stride = pl.ll_stride;
     }
     j.sb[0] = ll;
     j.sb_stride[0] = ll_stride;
@@ -537,7 +545,7 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   bool any_combine = false;
   for (int p = 0; p < nplanes; p++)
     any_combine |= planes[p].combine != 0;
-  if (use_reg && depth >= 2 && !nl && !any_combine && SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN")) != 0) {
+  if (use_reg && depth >= 2 && !nl && !any_combine && !any_ll && SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_CHAIN")) != 0) {
     int done = 0;
     const int r = iiwt_chain (ctx, nplanes, depth, filter, level_job, level_is_small, &done);
     if (r || done)

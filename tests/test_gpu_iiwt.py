@@ -164,3 +164,26 @@ def test_three_level_haar_in_one_pass(ctx, filt, monkeypatch):
             monkeypatch.setenv("SCHRO_HIP_IIWT_HAAR3", "0")
             assert np.array_equal(gpu_iiwt(ctx, arr, 3, filt), want), (filt, h, w, "per level")
     monkeypatch.delenv("SCHRO_HIP_IIWT_HAAR3", raising=False)
+
+
+@pytest.mark.parametrize("filt", range(7))
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_transform_in_two_calls(ctx, filt, dtype):
+    """r04 (SchroHipIwtPlane.ll): the levels above 0 on the level-1 view of the frame into an LL plane of the caller's, then
+    level 0 with that plane as its LL band -- together the one call, bit for bit, on the register kernels (s16, large planes),
+    the LDS kernels (s32, the fidelity filter, small planes) and for depths 2 .. 4."""
+    for (h, w, depth) in ((112, 208, 3), (544, 960, 3), (256, 512, 2), (192, 320, 4)):
+        img = synth.image_s(h, w, dtype, seed=7 * filt + depth)
+        co = O.forward_iwt(img, depth, filt)
+        want = O.inverse_iwt(co, depth, filt)
+        d_co = ctx.upload(co)
+        whole, split = ctx.plane(h, w, dtype), ctx.plane(h, w, dtype)
+        ll = ctx.plane(h // 2, w // 2, dtype)
+        ctx.iiwt_batch([(d_co, whole)], depth, filt)
+        ctx.iiwt_batch([(d_co.level_view(1), ll)], depth - 1, filt)
+        ctx.iiwt_batch([(d_co, split)], 1, filt, ll=[ll])
+        got = split.download()
+        assert np.array_equal(whole.download(), want), (h, w, depth)
+        assert np.array_equal(got, want), (h, w, depth)
+        for p in (d_co, whole, split, ll):
+            p.free()
