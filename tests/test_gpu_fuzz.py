@@ -96,6 +96,37 @@ def test_obmc_random_geometry(ctx):
                  res_dtype=[np.int16, np.int32][rnd & 1], modes=tuple(modes))
 
 
+def test_obmc_random_geometry_pair_images(ctx):
+    """r04: the same draws with the chroma planes' references as (U, V) pair images (one UV job per picture)."""
+    rng = np.random.default_rng(505 + SEED)
+    seps = [4, 8, 12, 16, 24, 32]
+    for rnd in range(120 * SCALE):
+        sep = seps[int(rng.integers(0, len(seps)))]
+        blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep, 64)
+        w, h = int(rng.integers(blen, 260)), int(rng.integers(blen, 140))
+        prec = int(rng.integers(1, 4))
+        chroma = [(1, 0), (1, 1)][int(rng.integers(0, 2))]
+        weights = [(1, 1, 1), (1, 1, 1), (1, 1, 1), (2, 3, 1), (1, 2, 2)][int(rng.integers(0, 5))]
+        run_case(ctx, w, h, blen, sep, prec, weights, chroma, int(rng.integers(1, 120)) << prec, seed=int(rng.integers(1, 1 << 16)),
+                 res_dtype=[np.int16, np.int32][rnd & 1], modes=tuple(rng.dirichlet([1, 2, 1, 2])), pair=True)
+
+
+def test_combine_random_geometry(ctx):
+    """r04: prediction-only OBMC + the transform's combine step (register epilogue or the scratch route) against the oracle's
+    two-step result: random sizes (pictures smaller than the padded transform), filters, depths, sample sizes, block sets."""
+    from test_gpu_combine import run_case as combine_case
+    rng = np.random.default_rng(606 + SEED)
+    seps = [4, 8, 12, 16]
+    for rnd in range(60 * SCALE):
+        sep = seps[int(rng.integers(0, len(seps)))]
+        blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep)
+        depth = int(rng.integers(1, 5))
+        w, h = int(rng.integers(max(blen, 24), 420)), int(rng.integers(max(blen, 24), 200))
+        chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
+        combine_case(ctx, w, h, depth, int(rng.integers(0, 7)), dtype=[np.int16, np.int32][int(rng.integers(0, 2))], chroma=chroma,
+                     prec=int(rng.integers(0, 4)), blk=(blen, sep), seed=int(rng.integers(1, 1 << 16)), intra=rnd % 7 == 0)
+
+
 def test_lowdelay_random_layouts(ctx):
     rng = np.random.default_rng(404 + SEED)
     for rnd in range(150 * SCALE):
