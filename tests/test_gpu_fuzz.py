@@ -127,6 +127,33 @@ def test_combine_random_geometry(ctx):
                      prec=int(rng.integers(0, 4)), blk=(blen, sep), seed=int(rng.integers(1, 1 << 16)), intra=rnd % 7 == 0)
 
 
+def test_iiwt_two_calls_random(ctx):
+    """r04 (SchroHipIwtPlane.ll): the levels above 0 on the level-1 views, then level 0 from their LL planes = the one call."""
+    rng = np.random.default_rng(707 + SEED)
+    for rnd in range(80 * SCALE):
+        filt, depth = int(rng.integers(0, 7)), int(rng.integers(2, 5))
+        dtype = [np.int16, np.int32][int(rng.integers(0, 2))]
+        unit = 1 << depth
+        srcs, wholes, splits, lls, want = [], [], [], [], []
+        for _ in range(int(rng.integers(1, 4))):
+            h, w = unit * int(rng.integers(1, 30)), unit * int(rng.integers(1, 50))
+            co = synth.full_range(h, w, dtype, seed=int(rng.integers(1, 1 << 20)))
+            co = (co >> (3 if dtype == np.int16 else 18)).astype(dtype)
+            srcs.append(ctx.upload(co))
+            wholes.append(ctx.plane(h, w, dtype))
+            splits.append(ctx.plane(h, w, dtype).fill(0x33))
+            lls.append(ctx.plane(h // 2, w // 2, dtype))
+            want.append(O.inverse_iwt(co, depth, filt))
+        ctx.iiwt_batch(list(zip(srcs, wholes)), depth, filt)
+        ctx.iiwt_batch([(s.level_view(1), q) for s, q in zip(srcs, lls)], depth - 1, filt)
+        ctx.iiwt_batch(list(zip(srcs, splits)), 1, filt, ll=lls)
+        for n in range(len(srcs)):
+            assert np.array_equal(wholes[n].download(), want[n]), (rnd, n, filt, depth, dtype)
+            assert np.array_equal(splits[n].download(), want[n]), (rnd, n, filt, depth, dtype, "two calls")
+        for p in srcs + wholes + splits + lls:
+            p.free()
+
+
 def test_lowdelay_random_layouts(ctx):
     rng = np.random.default_rng(404 + SEED)
     for rnd in range(150 * SCALE):
