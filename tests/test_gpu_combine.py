@@ -29,7 +29,7 @@ def up(v, depth):
 
 
 def run_case(ctx, w, h, depth, filt, dtype=np.int16, chroma=(1, 1), prec=2, blk=(12, 8), seed=1, intra=False, edit_mv=None,
-             src_pad=0):
+             src_pad=0, weights=(1, 1, 1)):
     hs, vs = chroma
     dims = [(h, w), (-(-h >> vs), -(-w >> hs)), (-(-h >> vs), -(-w >> hs))]
     iw = [(up(ph, depth), up(pw, depth)) for (ph, pw) in dims]
@@ -45,7 +45,7 @@ def run_case(ctx, w, h, depth, filt, dtype=np.int16, chroma=(1, 1), prec=2, blk=
             assert np.array_equal(outs[k].download(), O.convert_u8(res_want[k], pw, ph)), (k, "intra")
         [p.free() for p in keep]
         return
-    P = synth.motion_params(w, h, blk[0], blk[1], prec, (1, 1, 1), chroma)
+    P = synth.motion_params(w, h, blk[0], blk[1], prec, weights, chroma)
     mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 20 << prec, seed + 5)
     if edit_mv is not None:
         edit_mv(mv)
@@ -181,3 +181,14 @@ def test_frame_layer_calls(ctx, hs, vs, prec, filt, depth):
         assert np.array_equal(got[k], O.convert_u8(res_want[k], pw, ph)), (k, "intra")
     for f in (mc_tmp, out) + tuple(refs):
         f.unref()
+
+
+def test_picture_weights(ctx):
+    """Weighted prediction (schromotion8.c:542-657, picture_weight_1 / _2 / _bits): weights whose prediction still fits 8 bits take
+    the combine form on the item kernel; weights with gain (w1 + w2 > 1 << bits) are refused loudly -- such pictures keep the
+    residual form."""
+    for weights in ((3, 5, 3), (1, 2, 2), (0, 4, 2)):
+        for prec in range(4):
+            run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=prec, seed=5 + prec, weights=weights)
+    with pytest.raises(sa.SchroHipError, match="prediction_only"):
+        run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=2, seed=5, weights=(2, 3, 1))
