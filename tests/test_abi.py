@@ -29,6 +29,20 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
 
 
+def test_product_library_reads_no_environment_switch_but_debug():
+    """r04 hygiene: the switches between kernel forms and the measured-slower forms live in libschro_hip_exp.so
+    (-DSCHRO_HIP_EXPERIMENTS) only; the product library's one environment variable is SCHRO_HIP_DEBUG."""
+    from schroedinger_amd import _lib
+    def env_names(path):
+        blob = open(path, "rb").read()
+        return sorted(set(m.decode() for m in re.findall(rb"SCHRO_HIP_[A-Z0-9_]{3,}", blob)))
+    assert env_names(_lib.LIB_PATH) == ["SCHRO_HIP_DEBUG"]
+    exp = os.path.join(os.path.dirname(_lib.LIB_PATH), "libschro_hip_exp.so")
+    if os.path.exists(exp):
+        names = env_names(exp)
+        assert "SCHRO_HIP_IIWT_CHAIN" in names and "SCHRO_HIP_OBMC_KERNEL" in names, names
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import schroedinger_amd as sa
     if sa.device_count() > 0:
