@@ -650,8 +650,11 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
   const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
   const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
   const int nblk = nbi > 0 && nbj > 0 ? nbi * nbj : 0;
-  // blk / nbi for blk < 2^10: one scalar division per workgroup instead of one per thread
-  const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+  // blk / nbi: one table read per workgroup instead of a division per thread.  (r04: the 32-bit magic, exact for every block
+  // count a tile can have.  r01's 16-bit form -- (blk * ceil (2^16 / nbi)) >> 16 -- is exact only while blk * nbi < 2^16: a
+  // 128 x 32 tile of 4 x 4 blocks every 2 pixels meets 62 x 18 = 1116 of them, and the last one, blk 1115, came out a row
+  // down and a column left of the grid; found by tests/test_gpu_fuzz.py, draw 4430 of seed 77 x 100.)
+  const uint32_t m_nbi = nbi > 1 && nbi <= 1024 ? kDivMagic.m[nbi] : 0u;
   const int xfold_hi = job.nbx * xbsep - xoff, yfold_hi = job.nby * ybsep - yoff;
   const int gw = PC == 0 ? job.w - 1 : 2 * job.w - 2;   // last valid sample column
   const int gh = PC == 0 ? job.h - 1 : 2 * job.h - 2;
@@ -704,7 +707,7 @@ void obmc_item_kernel (const ObmcJob * __restrict__ jobs, int njobs, const uint3
     const bool have = tid < nb;
     if (have) {
       const int blk = chunk0 + tid;
-      const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
+      const int bj = nbi == 1 ? blk : nbi <= 1024 ? (int) __umulhi ((uint32_t) blk, m_nbi) : blk / nbi;
       const int i = i_lo + (blk - bj * nbi), jj = j_lo + bj;
       const uint8_t *mvp = job.mvs + (size_t) 20 * ((size_t) jj * job.nbx + i);
       const uint32_t flags = gload < uint32_t > (mvp);

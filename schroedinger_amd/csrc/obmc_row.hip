@@ -740,6 +740,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
     const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
     nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
+    // (blk / nbi as (blk * ceil (2^16 / nbi)) >> 16: exact while blk * nbi < 2^16 -- here blk < kRBlkCap <= 344 and nbi <= 66)
+    static_assert (kRBlkCap * 128 < 65536, "the 16-bit block-row division below");
     const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
     const int gh = 2 * job.h - 2;       // last valid half-pel sample row
     // the motion vectors of the first round start their way from memory beside the set-up

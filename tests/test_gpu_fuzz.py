@@ -123,8 +123,12 @@ def test_combine_random_geometry(ctx):
         depth = int(rng.integers(1, 5))
         w, h = int(rng.integers(max(blen, 24), 420)), int(rng.integers(max(blen, 24), 200))
         chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
-        combine_case(ctx, w, h, depth, int(rng.integers(0, 7)), dtype=[np.int16, np.int32][int(rng.integers(0, 2))], chroma=chroma,
-                     prec=int(rng.integers(0, 4)), blk=(blen, sep), seed=int(rng.integers(1, 1 << 16)), intra=rnd % 7 == 0)
+        args = dict(w=w, h=h, depth=depth, filt=int(rng.integers(0, 7)), dtype=[np.int16, np.int32][int(rng.integers(0, 2))], chroma=chroma,
+                    prec=int(rng.integers(0, 4)), blk=(blen, sep), seed=int(rng.integers(1, 1 << 16)), intra=rnd % 7 == 0)
+        try:
+            combine_case(ctx, **args)
+        except AssertionError as e:
+            raise AssertionError("draw %d %r: %s" % (rnd, args, e)) from e
 
 
 def test_iiwt_two_calls_random(ctx):

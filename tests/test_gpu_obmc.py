@@ -278,3 +278,14 @@ def test_references_of_another_layout_are_refused(ctx):
         ctx.obmc_batch([sa.obmc_plane(d_mv, P, 1, plain, plain, res, out)])
     for p in (d_mv, res, out, single, pair_img, plain):
         p.free()
+
+
+def test_more_than_1024_blocks_meet_a_tile(ctx):
+    """r04 regression (found by the fuzz campaign): 8 x 8 luma blocks every 4 pixels are 4 x 4 chroma blocks every 2 -- a
+    128 x 32 tile of a 4:2:0 chroma plane meets 62 x 18 = 1116 of them, and the item kernel's 16-bit block-row division was
+    exact only below 2^16 / 62 = 1057: the tile's last block was decoded a row down and a column left of the grid (one
+    pixel of the plane's last column wrong).  Plain and half-pel references, both kernels' routes."""
+    for prec in (0, 1, 2):
+        run_case(ctx, 244, 150, 8, 4, prec, (1, 1, 1), (1, 1), 20 << prec, 47753)
+        run_case(ctx, 260, 136, 8, 4, prec, (1, 1, 1), (1, 0), 20 << prec, 11, pair=prec > 0)
+    run_case(ctx, 250, 140, 4, 4, 0, (1, 1, 1), (1, 1), 16, 3)
