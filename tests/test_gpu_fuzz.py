@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 # is `SCHRO_FUZZ_SCALE=50 SCHRO_FUZZ_SEED=7 pytest tests/test_gpu_fuzz.py -m gpu`)
 SCALE = int(os.environ.get("SCHRO_FUZZ_SCALE", "1"))
 SEED = int(os.environ.get("SCHRO_FUZZ_SEED", "0"))
+# SCHRO_FUZZ_BIG multiplies the picture sizes of the OBMC / combine draws (more tiles per plane, tile rows that end
+# inside blocks, block counts per tile near the kernels' caps); the draws cost BIG^2 as much
+BIG = int(os.environ.get("SCHRO_FUZZ_BIG", "1"))
 
 
 def test_iiwt_random_batches(ctx):
@@ -86,7 +89,7 @@ def test_obmc_random_geometry(ctx):
         sep = seps[int(rng.integers(0, len(seps)))]
         blen = sep + 4 * int(rng.integers(0, sep // 4 + 1))
         blen = min(blen, 2 * sep, 64)
-        w, h = int(rng.integers(blen, 260)), int(rng.integers(blen, 140))
+        w, h = int(rng.integers(blen, 260 * BIG)), int(rng.integers(blen, 140 * BIG))
         prec = int(rng.integers(0, 4))
         chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
         weights = [(1, 1, 1), (1, 1, 1), (2, 3, 1), (3, 5, 3), (1, 2, 2)][int(rng.integers(0, 5))]
@@ -103,7 +106,7 @@ def test_obmc_random_geometry_pair_images(ctx):
     for rnd in range(120 * SCALE):
         sep = seps[int(rng.integers(0, len(seps)))]
         blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep, 64)
-        w, h = int(rng.integers(blen, 260)), int(rng.integers(blen, 140))
+        w, h = int(rng.integers(blen, 260 * BIG)), int(rng.integers(blen, 140 * BIG))
         prec = int(rng.integers(1, 4))
         chroma = [(1, 0), (1, 1)][int(rng.integers(0, 2))]
         weights = [(1, 1, 1), (1, 1, 1), (1, 1, 1), (2, 3, 1), (1, 2, 2)][int(rng.integers(0, 5))]
@@ -121,7 +124,7 @@ def test_combine_random_geometry(ctx):
         sep = seps[int(rng.integers(0, len(seps)))]
         blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep)
         depth = int(rng.integers(1, 5))
-        w, h = int(rng.integers(max(blen, 24), 420)), int(rng.integers(max(blen, 24), 200))
+        w, h = int(rng.integers(max(blen, 24), 420 * BIG)), int(rng.integers(max(blen, 24), 200 * BIG))
         chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
         args = dict(w=w, h=h, depth=depth, filt=int(rng.integers(0, 7)), dtype=[np.int16, np.int32][int(rng.integers(0, 2))], chroma=chroma,
                     prec=int(rng.integers(0, 4)), blk=(blen, sep), seed=int(rng.integers(1, 1 << 16)), intra=rnd % 7 == 0)
