@@ -70,6 +70,18 @@ def test_upsample_and_convert_random(ctx):
         assert np.array_equal(dst.download(), want), (rnd, h, w)
         src.free()
         dst.free()
+        if rnd % 3 == 0:        # r04: the same picture and a second one as a (U, V) pair image
+            pv = synth.picture_u8(h, w, seed=int(rng.integers(1, 1 << 20)))
+            su, sv, dp = ctx.upload(pic), ctx.upload(pv), ctx.hp_plane(h, w, pair=True)
+            ctx.upsample_batch([((su, sv), dp)])
+            gu, gv = dp.download()
+            upv = O.UpComp(pv, upsample=True)
+            want_v = np.zeros((2 * h, 2 * w), np.uint8)
+            for k in range(4):
+                want_v[k >> 1::2, k & 1::2] = upv.plane(k)
+            assert np.array_equal(gu, want) and np.array_equal(gv, want_v), (rnd, h, w, "pair")
+            for p in (su, sv, dp):
+                p.free()
         dtype = [np.int16, np.int32][rnd & 1]
         ih, iw = h + int(rng.integers(0, 9)), w + int(rng.integers(0, 17))
         res = synth.full_range(ih, iw, dtype, seed=rnd + 5)
