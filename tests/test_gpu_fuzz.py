@@ -173,6 +173,48 @@ def test_iiwt_two_calls_random(ctx):
             p.free()
 
 
+def test_dequant_random_codeblocks(ctx):
+    """Core-syntax dequantisation (schro_hip_dequant_batch and, r04, a plan run over the same records): random plane sizes,
+    depths, codeblock partitions (down to empty and 1 x 1 codeblocks), zero codeblocks, value widths, both arithmetics."""
+    from test_gpu_dequant import D, pack_codeblocks, synthetic_records
+    rng = np.random.default_rng(808 + SEED)
+    for rnd in range(40 * SCALE):
+        dtype, arith = [(np.int16, 0), (np.int16, 1), (np.int32, 0)][int(rng.integers(0, 3))]
+        jobs, want, outs = [], [], []
+        for _ in range(int(rng.integers(1, 4))):
+            depth = int(rng.integers(1, 5))
+            unit = 1 << depth
+            h, w = unit * int(rng.integers(1, 24)), unit * int(rng.integers(1, 40))
+            span = int(rng.choice([60, 3000, 40000]))
+            intra = int(rng.integers(0, 2))
+            quant = rng.integers(-span, span + 1, (h, w)).astype(np.int32)
+            quant[rng.random((h, w)) < rng.uniform(0.2, 0.9)] = 0
+            records = synthetic_records(h, w, depth, rng, zero_share=float(rng.uniform(0.0, 0.8)),
+                                        counts=(int(rng.integers(1, 9)), int(rng.integers(1, 7))))
+            dst = ctx.plane(h, w, dtype).fill(0x5a)
+            blob, cbs = pack_codeblocks((h, w), np.dtype(dtype).itemsize, dst.stride, depth, quant, records)
+            jobs.append((dst, ctx.upload_bytes(blob), cbs, intra))
+            ref = np.full((h, w), 0x5a5a5a5a & (0xffff if dtype == np.int16 else 0xffffffff), np.uint32).astype(dtype)
+            for (index, x0, y0, x1, y1, zero, qi) in records:
+                band, qb = D.subband_view(ref, depth, index), D.subband_view(quant, depth, index)
+                if x1 > x0 and y1 > y0:
+                    O.dequant_codeblock(band[y0:y1, x0:x1], None if zero else qb[y0:y1, x0:x1], qi, intra, arith)
+            want.append(ref)
+            outs.append(dst)
+        ctx.dequant_batch(jobs, arith)
+        for n, (dst, ref) in enumerate(zip(outs, want)):
+            assert np.array_equal(dst.download(), ref), (rnd, n, dtype, arith, "batch")
+            dst.fill(0x5a)
+        plan = ctx.dequant_plan(jobs, arith)
+        plan.run(jobs)
+        for n, (dst, ref) in enumerate(zip(outs, want)):
+            assert np.array_equal(dst.download(), ref), (rnd, n, dtype, arith, "plan")
+        plan.free()
+        for dst, dev, _, _ in jobs:
+            dst.free()
+            dev.free()
+
+
 def test_lowdelay_random_layouts(ctx):
     rng = np.random.default_rng(404 + SEED)
     for rnd in range(150 * SCALE):
