@@ -215,6 +215,76 @@ def test_dequant_random_codeblocks(ctx):
             dev.free()
 
 
+def test_frame_layer_random_pictures(ctx):
+    """The SchroFrame-shaped stage calls on random pictures (sizes that are not multiples of anything, 4:4:4 / 4:2:2 /
+    4:2:0, every filter, depths 1 .. 4, block sets, precisions): the reference's stage order (inverse transform, render with
+    add = TRUE) and the r04 order (render add = FALSE, combine transform) both give the oracle's picture."""
+    import ctypes as C
+    from schroedinger_amd import _lib, frames
+    lib = ctx.lib
+    rng = np.random.default_rng(909 + SEED)
+    seps = [4, 8, 12, 16]
+    for rnd in range(30 * SCALE):
+        hs, vs = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
+        sep = seps[int(rng.integers(0, len(seps)))]
+        blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep)
+        depth, filt, prec = int(rng.integers(1, 5)), int(rng.integers(0, 7)), int(rng.integers(0, 4))
+        w = 2 * int(rng.integers(max(blen, 16) // 2 + 1, 200 * BIG))       # (even sizes: the chroma formats' own rule)
+        h = 2 * int(rng.integers(max(blen, 16) // 2 + 1, 120 * BIG))
+        pd = [(h, w), (-(-h >> vs), -(-w >> hs)), (-(-h >> vs), -(-w >> hs))]
+        unit = 1 << depth
+        iw = [(-(-ph // unit) * unit, -(-pw // unit) * unit) for (ph, pw) in pd]
+        P = synth.motion_params(w, h, blen, sep, prec, (1, 1, 1), (hs, vs))
+        params = frames.make_params(wavelet_filter_index=filt, transform_depth=depth, iwt_luma_width=iw[0][1], iwt_luma_height=iw[0][0],
+                                    iwt_chroma_width=iw[1][1], iwt_chroma_height=iw[1][0], num_refs=2,
+                                    **{k: P[k] for k in ("xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma", "mv_precision",
+                                                         "picture_weight_bits", "picture_weight_1", "picture_weight_2", "x_num_blocks", "y_num_blocks")})
+        mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], int(rng.integers(1, 60)) << prec, seed=int(rng.integers(1, 1 << 16)))
+        resid = [synth.image_s(ih, iwd, np.int16, seed=int(rng.integers(1, 1 << 16))) for (ih, iwd) in iw]
+        coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+        res_want = [O.inverse_iwt(c, depth, filt) for c in coeffs]
+        fmt16, fmt8 = frames.frame_format(np.int16, hs, vs), frames.frame_format(np.uint8, hs, vs)
+        # (picture->transform_frame and picture->frame as the reference allocates them: schro_video_format_get_iwt_alloc_size
+        # rounds the luma size up so far that the chroma components hold their own padded transform too)
+        fw, fh = -(-w // (unit << hs)) * (unit << hs), -(-h // (unit << vs)) * (unit << vs)
+        padded = []
+        for k, c in enumerate(coeffs):
+            a = np.zeros((fh >> (vs if k else 0), fw >> (hs if k else 0)), np.int16)
+            a[:c.shape[0], :c.shape[1]] = c
+            padded.append(a)
+        transform_frame = frames.HostFrame(padded, hs, vs)
+        refs_np = [[synth.picture_u8(ph, pw, seed=int(rng.integers(1, 1 << 16))) for (ph, pw) in pd] for r in range(2)]
+        refs, held = [], []
+        for r in range(2):
+            d = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(refs_np[r], hs, vs))
+            held.append(d)
+            if prec > 0:
+                u = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+                sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
+                held.append(u)
+                refs.append(u)
+            else:
+                refs.append(d)
+        want = [O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                                O.UpComp(refs_np[1][k], upsample=prec > 0), res_want[k], pw, ph) for k, (ph, pw) in enumerate(pd)]
+        motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
+        tag = (rnd, w, h, (hs, vs), depth, filt, prec, (blen, sep))
+        # the reference's order
+        frame, out = frames.DeviceFrame(ctx, fmt16, fw, fh), frames.DeviceFrame(ctx, fmt8, w, h)
+        sa.check(lib.schro_frame_inverse_iwt_transform_hip(frame.ptr(), transform_frame.ptr(), C.byref(params)))
+        sa.check(lib.schro_motion_render_hip(C.byref(motion), None, frame.ptr(), 1, out.ptr()))
+        for k, g in enumerate(out.download()):
+            assert np.array_equal(g, want[k]), tag + (k, "stage order of the reference")
+        # r04: prediction first, the transform adds it
+        mc_tmp, out2 = frames.DeviceFrame(ctx, fmt8, w, h), frames.DeviceFrame(ctx, fmt8, w, h)
+        sa.check(lib.schro_motion_render_hip(C.byref(motion), mc_tmp.ptr(), None, 0, None))
+        sa.check(lib.schro_frame_inverse_iwt_transform_combine_hip(out2.ptr(), transform_frame.ptr(), C.byref(params), mc_tmp.ptr()))
+        for k, g in enumerate(out2.download()):
+            assert np.array_equal(g, want[k]), tag + (k, "combine order")
+        for f in [frame, out, mc_tmp, out2] + held:
+            f.unref()
+
+
 def test_lowdelay_random_layouts(ctx):
     rng = np.random.default_rng(404 + SEED)
     for rnd in range(150 * SCALE):
