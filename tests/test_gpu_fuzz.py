@@ -285,6 +285,26 @@ def test_frame_layer_random_pictures(ctx):
             f.unref()
 
 
+def test_pack_random_sizes(ctx):
+    """Packed copy-out of u8 pictures (YUYV / UYVY / AYUV): random source sizes and chroma formats, destinations smaller
+    (crop) and larger (edge extension) than the source, several unlike pictures per launch."""
+    from test_gpu_pack import gpu_pack, planes
+    rng = np.random.default_rng(1010 + SEED)
+    fmts = [sa.FORMAT_YUYV, sa.FORMAT_UYVY, sa.FORMAT_AYUV]
+    for rnd in range(40 * SCALE):
+        cases = []
+        for _ in range(int(rng.integers(1, 6))):
+            hs, vs = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
+            w, h = int(rng.integers(1, 300)), int(rng.integers(1, 90))
+            pl = planes(w, h, hs, vs, seed=int(rng.integers(1, 1 << 16)))
+            # (crop OR extension: a destination narrower and taller than its source, or the reverse, is refused -- no decoder has one)
+            sign = 1 if rng.integers(0, 2) else -1
+            W, H = max(1, w + sign * int(rng.integers(0, 9))), max(1, h + sign * int(rng.integers(0, 6)))
+            cases.append((pl, hs, vs, fmts[int(rng.integers(0, 3))], W, H))
+        for (pl, hs, vs, f, W, H), g in zip(cases, gpu_pack(ctx, cases)):
+            assert np.array_equal(g, O.pack_u8(pl, hs, vs, f, W, H)), (rnd, f, (hs, vs), pl[0].shape, W, H)
+
+
 def test_lowdelay_random_layouts(ctx):
     rng = np.random.default_rng(404 + SEED)
     for rnd in range(150 * SCALE):
