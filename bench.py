@@ -858,7 +858,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        # (a rank that died must not leave the others at the rendezvous for gloo's default half hour)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
 
     ctx = sa.Context(local_rank % ndev if share else local_rank)
     wl = Workload(ctx, args.frames, seed=1 + 1000 * rank, queues=args.queues)

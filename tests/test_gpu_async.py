@@ -353,8 +353,11 @@ def test_bench_two_ranks_on_this_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SCHRO_BENCH_SHARE_DEVICE="1")
     env.pop("WORLD_SIZE", None)
+    # (on a fresh box the first `import torch` pages the libraries in for a minute or two: once, here, not twice at the
+    # same time in the two ranks with the other one waiting at the rendezvous)
+    subprocess.run([sys.executable, "-c", "import torch, torch.distributed"], env=env, capture_output=True, timeout=400)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--headline-only", "--prewarm-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+                        "--headline-only", "--prewarm-ms", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
