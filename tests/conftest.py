@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may stall a run for good: where pytest-timeout is installed every test that does not ask for its own limit gets
+    six minutes (the slowest takes half a minute); a stalled one then fails with the threads' stacks instead of hanging."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(360))
+
+
 @pytest.fixture(scope="session")
 def ctx():
     """One device context for the whole GPU session (one exec-domain thread)."""

@@ -343,6 +343,7 @@ def test_two_reference_pictures_of_one_device_in_flight():
     sched.close()
 
 
+@pytest.mark.timeout(780)
 def test_bench_two_ranks_on_this_device():
     """The N > 1 path of bench.py (launcher, rank processes, gloo rendezvous, max over ranks) on the one GPU
     of this box: two ranks share the device (SCHRO_BENCH_SHARE_DEVICE=1), rc 0, one JSON line, n_gpus 2."""
