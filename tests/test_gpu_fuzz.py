@@ -14,7 +14,6 @@ import synth
 from test_gpu_lowdelay import compare, decode_cpu, decode_gpu
 from test_gpu_obmc import run_case
 
-pytestmark = pytest.mark.gpu
 
 # SCHRO_FUZZ_SCALE multiplies the number of draws, SCHRO_FUZZ_SEED shifts the seeds (a long campaign
 # is `SCHRO_FUZZ_SCALE=50 SCHRO_FUZZ_SEED=7 pytest tests/test_gpu_fuzz.py -m gpu`)
@@ -23,6 +22,9 @@ SEED = int(os.environ.get("SCHRO_FUZZ_SEED", "0"))
 # SCHRO_FUZZ_BIG multiplies the picture sizes of the OBMC / combine draws (more tiles per plane, tile rows that end
 # inside blocks, block counts per tile near the kernels' caps); the draws cost BIG^2 as much
 BIG = int(os.environ.get("SCHRO_FUZZ_BIG", "1"))
+
+# (tests/conftest.py gives every test six minutes; a campaign's tests get theirs by its size)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(360 + 60 * SCALE * BIG * BIG)]
 
 
 def test_iiwt_random_batches(ctx):
