@@ -901,8 +901,14 @@ int schro_hip_scheduler_publish_reference (SchroHipScheduler * sched, int device
 void *schro_hip_scheduler_reference_frame (SchroHipScheduler * sched, int device_index, int picture_number);
 long schro_hip_scheduler_moves (SchroHipScheduler * sched);       /* frames copied between devices so far */
 /* r04: nothing on the path drains a device.  A reference picture is complete when an event stands behind
- * the work its function enqueued; pictures of the same device follow it in the in-order queues, a picture
- * on another device waits for the event on its copy queue and copies asynchronously (TODO-CUDA:5-7).
+ * the work its function enqueued; pictures of the same device follow it in the in-order KERNEL queues (r05:
+ * both of them wait for that event, and every picture function starts with queue 0 selected; what a function
+ * puts on the COPY queues it orders itself with marks), a picture
+ * on another device waits for the event on its copy queue and copies asynchronously (TODO-CUDA:5-7) -- the
+ * scheduler waits for nothing itself, but the ROCm 7.2 runtime keeps the worker of the device that needs the
+ * frame inside the copy call until the event has fired (it runs its pictures in coded order anyway).
+ * r05: a frame the scheduler lets go of (a retired reference, its copies on other devices) is released only
+ * when the kernel queues of its device have passed that point -- kernels of dependents may still read it.
  * A reference whose function returned an error is marked failed: its dependents -- and theirs -- do not
  * run, they finish with SCHRO_HIP_ESKIPPED (the reference decoder skips such pictures: picture->error,
  * schrodecoder.c:1308-1311, :1399-1418); schro_hip_scheduler_wait still reports the first real error. */

@@ -242,6 +242,10 @@ class Context:
         """Calls that follow are enqueued on in-order queue q (0 or 1)."""
         check(self.lib.schro_hip_context_select_queue(self.h, q))
 
+    def queue(self):
+        """The queue selected at the moment."""
+        return self.lib.schro_hip_context_queue(self.h)
+
     def queue_mark(self, mark):
         """Record mark (0..15) behind the work enqueued so far on the selected queue."""
         check(self.lib.schro_hip_queue_mark(self.h, mark))

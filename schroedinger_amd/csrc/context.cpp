@@ -529,7 +529,12 @@ context_new_unbound (int device)
 }
 
 // Queue 0 waits for everything enqueued so far on the context's other queues, then `ev` is recorded on it:
-// one event behind all the device work of a picture, whichever queues its function used.  No host wait.
+// one event behind all the device work of a picture, whichever queues its function used.  The second kernel
+// queue then waits for `ev` too (r05, ADVICE r04: "pictures of the same device follow the reference in the
+// in-order queues" was true of queue 0 only) -- kernels behind an unfired event cost the host nothing.  The
+// copy queues do NOT wait: a copy enqueued behind an unfired event holds its caller, and what a
+// later picture uploads is ordered against earlier readers by that picture's own marks.
+// No host wait.
 int
 context_join_queues (SchroHipContext * ctx, hipEvent_t ev)
 {
@@ -539,6 +544,7 @@ context_join_queues (SchroHipContext * ctx, hipEvent_t ev)
     SCHRO_HIP_CHECK (hipStreamWaitEvent (ctx->streams[0], ctx->queue_ev[q], 0));
   }
   SCHRO_HIP_CHECK (hipEventRecord (ev, ctx->streams[0]));
+  SCHRO_HIP_CHECK (hipStreamWaitEvent (ctx->streams[1], ev, 0));
   return 0;
 }
 }                               // namespace schro

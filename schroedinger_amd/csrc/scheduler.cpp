@@ -29,10 +29,23 @@
 // When a reference picture's function has returned, the worker joins the context's queues behind ONE
 // event (`ready`) and the reference is complete: pictures of the same device follow it in the in-order
 // queues, a picture on another device makes its copy queue WAIT for the event (hipStreamWaitEvent), issues
-// the peer copy asynchronously and makes its kernel queues wait for the copy -- no host thread waits for a
-// device anywhere on the path, so a device can have any number of reference pictures in flight
-// (refs_in_flight_max counts them from the events).  r03 drained the whole device after every reference
-// picture and copied synchronously (the reference's precedent: schrogpuframe.c:480-609).
+// the peer copy asynchronously and makes its kernel queues wait for the copy -- the scheduler itself waits
+// for no device on the path, so a device can have any number of reference pictures in flight
+// (refs_in_flight_max counts them from events of its own).  One caveat, measured in r04: on ROCm 7.2 an
+// asynchronous copy enqueued behind an event that has not fired returns to its caller only when the event
+// has, so the worker of the device that NEEDS a foreign frame can sit inside the peer-copy call for the rest
+// of the producer's picture (it would run its pictures in coded order anyway; no other device's worker is
+// held).  r03 drained the whole device after every reference picture and copied synchronously (the
+// reference's precedent: schrogpuframe.c:480-609).
+// r05: (1) after `ready` is recorded on queue 0 the context's second kernel queue waits for it as
+// well, and every picture function starts with queue 0 selected -- so a dependent on the same device follows
+// the reference whichever KERNEL queue it uses (copy queues are ordered by the function's own marks, as in
+// a function that uploads into a buffer an earlier picture reads must wait for that picture's
+// mark); (2) the in-flight statistic owns its events (the records' `ready` events are destroyed with the
+// records); (3) a frame leaves the scheduler -- and its memory becomes reusable -- only when the kernel
+// queues of its device have passed the point of its release: dependents whose functions have returned may
+// still be reading it, and the next peer copy into the recycled slot runs on a copy queue that is not
+// ordered against them.
 // A reference whose function FAILED is complete too (nobody waits forever) but marked failed: its
 // dependents -- on this device and on others -- do not run their functions, they finish with
 // SCHRO_HIP_ESKIPPED, and a skipped reference fails in turn; the reference decoder does the same with
@@ -48,6 +61,7 @@
 // device whose context owns them (a context is not thread-safe).
 #include "schro_hip_internal.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -58,7 +72,8 @@ namespace schro {
 // context.cpp: queue 0 of the context waits for its other queues, then `ev` is recorded on it
 int context_join_queues (SchroHipContext * ctx, hipEvent_t ev);
 // frame.cpp: a copy of `src` on dst_ctx's device, enqueued on its host-to-device copy queue behind `wait_for`;
-// `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  Nothing is waited for here.
+// `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  No explicit wait (the runtime may hold
+// the caller inside the copy call until `wait_for` has fired: see the note on r04 above).
 SchroHipFrame *frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done);
 // context.cpp: a context that does not become the calling thread's domain
 SchroHipContext *context_new_unbound (int device);
@@ -98,7 +113,12 @@ struct SchroHipScheduler {
       hipEvent_t destroy;
     };
     std::vector < Garbage > garbage;
-    std::deque < hipEvent_t > in_flight;        // `ready` events of this device's reference pictures, oldest first
+    // garbage whose frame still waits for this device's kernel queues to pass the point of release
+    // (`after` = the events recorded there); polled by the worker, never waited for while work is runnable
+    std::vector < Garbage > pending;
+    // events of the statistic's own, one behind each reference picture of this device, oldest first
+    // (NOT the records' `ready` events: those are destroyed with their records)
+    std::deque < hipEvent_t > in_flight;
   };
   std::vector < Device > devs;
   std::mutex mutex;
@@ -130,20 +150,64 @@ release_if_unused (SchroHipScheduler * s, Ref * r)
   delete r;
 }
 
+// On the thread of the device that owns the frames.  A frame is not released here: the peer copies made from
+// it must have run (`after`, recorded by other devices' workers) AND this device's kernel queues must have
+// passed this point -- kernels of dependents whose functions have returned may still read it, and once the
+// slot is recycled the next writer may be a copy queue that is not ordered against them.  So two
+// more events go behind the kernel queues and the entry moves to `pending`.
 void
-empty_garbage (std::vector < SchroHipScheduler::Device::Garbage > &g)
+empty_garbage (SchroHipContext * ctx, std::vector < SchroHipScheduler::Device::Garbage > &g,
+    std::vector < SchroHipScheduler::Device::Garbage > &pending)
 {
   for (auto & e:g) {
-    for (hipEvent_t ev:e.after) {
-      (void) hipEventSynchronize (ev);
-      (void) hipEventDestroy (ev);
+    if (e.frame && ctx) {
+      for (int q = 0; q < 2; q++) {
+        hipEvent_t ev = nullptr;
+        hipStream_t st = ctx->streams[q];
+        if (st && hipEventCreateWithFlags (&ev, hipEventDisableTiming) == hipSuccess) {
+          if (hipEventRecord (ev, st) == hipSuccess)
+            e.after.push_back (ev);
+          else
+            (void) hipEventDestroy (ev);
+        }
+      }
     }
+    pending.push_back (e);
+  }
+  g.clear ();
+}
+
+// release what has become releasable; `wait`: block for the rest (shutdown).  Returns whether entries are left.
+bool
+poll_pending (std::vector < SchroHipScheduler::Device::Garbage > &pending, bool wait)
+{
+  size_t keep = 0;
+  for (size_t k = 0; k < pending.size (); k++) {
+    auto & e = pending[k];
+    bool fired = true;
+    for (hipEvent_t ev:e.after) {
+      if (wait)
+        (void) hipEventSynchronize (ev);
+      else if (hipEventQuery (ev) == hipErrorNotReady) {
+        fired = false;
+        break;
+      }
+    }
+    if (!fired) {
+      if (keep != k)
+        pending[keep] = e;
+      keep++;
+      continue;
+    }
+    for (hipEvent_t ev:e.after)
+      (void) hipEventDestroy (ev);
     if (e.frame)
       schro_hip_frame_unref (e.frame);
     if (e.destroy)
       (void) hipEventDestroy (e.destroy);
   }
-  g.clear ();
+  pending.resize (keep);
+  return keep != 0;
 }
 
 bool
@@ -167,20 +231,31 @@ worker (SchroHipScheduler * s, int index)
   }
   std::unique_lock < std::mutex > lock (s->mutex);
   for (;;) {
-    s->work.wait (lock,[&] {
-          return s->quit || runnable (s, d, index) || !d.garbage.empty ();
-        });
-    if (!d.garbage.empty ()) {
+    auto awake =[&] {
+      return s->quit || runnable (s, d, index) || !d.garbage.empty ();
+    };
+    if (d.pending.empty ())
+      s->work.wait (lock, awake);
+    else                        // frames waiting for this device's queues: look again in a moment
+      s->work.wait_for (lock, std::chrono::milliseconds (1), awake);
+    if (!d.garbage.empty () || !d.pending.empty ()) {
       std::vector < SchroHipScheduler::Device::Garbage > g;
       g.swap (d.garbage);
       lock.unlock ();
-      empty_garbage (g);
+      empty_garbage (d.ctx, g, d.pending);     // (`pending` is this thread's alone while it runs)
+      poll_pending (d.pending, false);
       lock.lock ();
-      continue;
+      if (!d.garbage.empty ())
+        continue;
     }
     if (!runnable (s, d, index)) {
-      if (s->quit)
-        return;
+      if (s->quit && d.garbage.empty ()) {
+        lock.unlock ();
+        poll_pending (d.pending, true);
+        lock.lock ();
+        if (d.garbage.empty ())
+          return;
+      }
       continue;
     }
     SchroHipScheduler::Task t = d.queue.front ();
@@ -216,7 +291,8 @@ worker (SchroHipScheduler * s, int index)
       if (s->virtual_devices) {
         m.moved = m.frame;
       } else {
-        // the copy waits for the owner's `ready` on this device's copy queue; this thread does not wait
+        // the copy waits for the owner's `ready` on this device's copy queue (no explicit host wait; the runtime may
+        // keep this thread inside the copy call until the event has fired)
         if (hipEventCreateWithFlags (&m.done, hipEventDisableTiming) != hipSuccess)
           m.done = nullptr;
         m.moved = m.done ? schro::frame_copy_to_async (d.ctx, (SchroHipFrame *) m.frame, m.ready, m.done) : nullptr;
@@ -237,8 +313,11 @@ worker (SchroHipScheduler * s, int index)
         }
       lock.unlock ();
     }
-    if (!rc)
+    if (!rc) {
+      if (d.ctx)
+        (void) schro_hip_context_select_queue (d.ctx, 0);        // (the selection of the picture before does not leak into this one)
       rc = t.func (d.ctx, index, t.priv);
+    }
     // the function only ENQUEUES on the context's queues: a reference is complete -- usable by its
     // dependents, here through the in-order queues, elsewhere through `ready` -- when an event stands
     // behind that work.  Nothing is drained.
@@ -250,11 +329,20 @@ worker (SchroHipScheduler * s, int index)
       const int rs = ready ? schro::context_join_queues (d.ctx, ready) : SCHRO_HIP_EDEVICE;
       if (!rc)
         rc = rs;
-      // how many reference pictures of this device are in flight now (their events not yet reached)
-      while (!d.in_flight.empty () && hipEventQuery (d.in_flight.front ()) != hipErrorNotReady)
+      // how many reference pictures of this device are in flight now (their events not yet reached): events
+      // of the statistic's own, recorded right behind `ready` -- `ready` itself belongs to the record and is
+      // destroyed with it, possibly before the next reference picture of this device looks here
+      while (!d.in_flight.empty () && hipEventQuery (d.in_flight.front ()) != hipErrorNotReady) {
+        (void) hipEventDestroy (d.in_flight.front ());
         d.in_flight.pop_front ();
-      if (ready && !rs)
-        d.in_flight.push_back (ready);
+      }
+      hipEvent_t stat = nullptr;
+      if (ready && !rs && hipEventCreateWithFlags (&stat, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord (stat, d.ctx->streams[0]) == hipSuccess)
+          d.in_flight.push_back (stat);
+        else
+          (void) hipEventDestroy (stat);
+      }
       in_flight = (int) d.in_flight.size ();
     }
     lock.lock ();
@@ -375,7 +463,11 @@ schro_hip_scheduler_free (SchroHipScheduler * s)
     if (d.ctx) {
       (void) hipSetDevice (d.device);
       schro_hip_thread_bind (d.ctx);
-      empty_garbage (d.garbage);
+      empty_garbage (d.ctx, d.garbage, d.pending);
+      poll_pending (d.pending, true);
+      for (hipEvent_t ev:d.in_flight)
+        (void) hipEventDestroy (ev);
+      d.in_flight.clear ();
       schro_hip_context_free (d.ctx);
     }
   }

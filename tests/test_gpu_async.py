@@ -343,6 +343,99 @@ def test_two_reference_pictures_of_one_device_in_flight():
     sched.close()
 
 
+def test_retired_references_then_more_on_the_same_device_and_the_second_kernel_queue():
+    """r05.  (1) A reference is submitted, RETIRED and complete -- its record and `ready` event are
+    gone -- before the next reference picture of the same device runs: the in-flight statistic must not look at
+    the destroyed event (it owns events of its own now).  (2) A dependent that selects the SECOND kernel queue
+    follows the reference all the same: the reference's upsample sits behind a pile of device work on queue 0,
+    and the prediction from it, enqueued on queue 1 without any host wait, equals the oracle's.  (3) Every
+    picture function starts with queue 0 selected, whatever the one before it left selected.  (4) Frames the
+    scheduler lets go of are released behind the device's kernel queues: the run ends with nothing pending."""
+    sched = sa.Scheduler(devices=[0])
+    lib = sched.lib
+    P, dims, coeffs, mv = picture_inputs(1300)
+    fmt8 = frames.frame_format(np.uint8, 1, 1)
+    refs_np = {n: [synth.picture_u8(h, w, seed=5 * n + k) for k, (h, w) in enumerate(dims)] for n in range(4)}
+    ctx0 = sched.contexts[0]
+    big = (ctx0.upload(synth.picture_u8(2160, 3840, seed=9)), [ctx0.hp_plane(2160, 3840) for _ in range(2)])
+    pre = {}
+    for n in range(4):
+        pre[n] = (frames.DeviceFrame(ctx0, fmt8, W, H).upload(frames.HostFrame(refs_np[n], 1, 1)),
+                  frames.DeviceFrame(ctx0, fmt8, W, H, upsampled=True))
+    d_mv = ctx0.upload_bytes(mv)
+    d_co = [ctx0.upload(coeffs[k]) for k in range(3)]
+    d_res = [ctx0.plane(h, w, np.int16) for (h, w) in dims]
+    outs = {n: [ctx0.plane(h, w, np.uint8) for (h, w) in dims] for n in (10, 11)}
+    ctx0.synchronize()
+    keep, seen_queue = {}, []
+
+    def reference(number, pile):
+        def run(ctx, dev):
+            seen_queue.append(ctx.queue())
+            src, hps = big
+            for _ in range(pile):                       # device work in front of the reference's own
+                for hp in hps:
+                    ctx.upsample_batch([(src, hp)])
+            plain, up = pre[number]
+            c, pc = up.c.components, plain.c.components
+            planes = (_lib.UpsamplePlane * 2)()
+            planes[0] = _lib.UpsamplePlane(pc[0].data, pc[0].stride, c[0].data, c[0].stride, pc[0].width, pc[0].height, None, 0)
+            planes[1] = _lib.UpsamplePlane(pc[1].data, pc[1].stride, c[1].data, c[1].stride, pc[1].width, pc[1].height,
+                                           pc[2].data, pc[2].stride)
+            sa.check(lib.schro_hip_upsample_batch(ctx.h, planes, 2))
+            up.c.upsample_done = 1
+            sched.publish_reference(dev, up.ptr())
+            keep[number] = (plain, up)
+            return 0
+        return run
+
+    def dependent(number, refs):
+        def run(ctx, dev):
+            seen_queue.append(ctx.queue())
+            ctx.select_queue(1)                         # the header's second kernel queue; left selected on purpose
+            f = [C.cast(sched.reference_frame(dev, n), C.POINTER(_lib.Frame)) for n in refs]
+            assert f[0] and f[1]
+            if number == 10:
+                ctx.iiwt_batch(list(zip(d_co, d_res)), DEPTH, FILT)
+            planes = []
+            for k in range(3):
+                class V:
+                    pass
+                views = []
+                for fr in f:
+                    v = V()
+                    v.ptr, v.stride = fr.contents.components[k].data, fr.contents.components[k].stride
+                    v.pair = k > 0 and fr.contents.is_upsampled == 2
+                    views.append(v)
+                planes.append(sa.obmc_plane(d_mv, P, k, views[0], views[1], d_res[k], outs[number][k]))
+            ctx.obmc_batch(planes)
+            return 0
+        return run
+
+    # reference 0: submitted, retired, complete -> its record (and event) go before reference 1 runs
+    sched.submit(0, [], True, reference(0, 1))
+    sched.retire(0)
+    assert sched.wait() == 0
+    sched.submit(1, [], True, reference(1, 12))
+    sched.submit(2, [], True, reference(2, 12))
+    sched.submit(10, [1, 2], False, dependent(10, (1, 2)))
+    sched.retire(1)
+    sched.submit(3, [2], True, reference(3, 12))
+    sched.submit(11, [3, 2], False, dependent(11, (3, 2)))
+    sched.retire(2)
+    sched.retire(3)
+    assert sched.wait() == 0
+    assert seen_queue == [0] * len(seen_queue), seen_queue
+    ctx0.synchronize()
+    resid = [O.inverse_iwt(coeffs[k], DEPTH, FILT) for k in range(3)]
+    ups = {n: [O.UpComp(p) for p in refs_np[n]] for n in (1, 2, 3)}
+    for number, (a, b) in ((10, (1, 2)), (11, (3, 2))):
+        for k, (h, w) in enumerate(dims):
+            want = O.motion_render(mv, O.MotionParams(**P), k, ups[a][k], ups[b][k], resid[k], w, h)
+            assert np.array_equal(outs[number][k].download(), want), (number, k)
+    sched.close()
+
+
 @pytest.mark.timeout(780)
 def test_bench_two_ranks_on_this_device():
     """The N > 1 path of bench.py (launcher, rank processes, gloo rendezvous, max over ranks) on the one GPU
