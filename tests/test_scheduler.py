@@ -212,13 +212,17 @@ def test_a_failed_reference_skips_its_dependents_everywhere():
             return 0
         return f
 
+    gate = threading.Event()        # (holds the anchor until chain B has been placed: "least loaded" then sees device d0 busy)
+
     def broken(ctx, index):
+        gate.wait(30)
         with lock:
             ran.append("broken")
         return -2                                       # SCHRO_HIP_EDEVICE
 
     d0, _ = s.submit(0, [], True, broken)               # chain A's anchor fails
     d1, _ = s.submit(100, [], True, ok(100))            # chain B is healthy
+    gate.set()
     assert d0 != d1
     s.submit(1, [0], True, ok(1))                       # P from the failed anchor: skipped, and fails in turn
     s.submit(2, [0, 1], False, ok(2))                   # B between them: skipped
