@@ -322,6 +322,18 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "iiwt_batch: bpp must be 2 or 4");
   (void) hipSetDevice (ctx->device);
 
+  // per level: planes that allow it run the register form (iiwt_reg.hip), the rest the
+  // LDS tile kernel; SCHRO_HIP_IIWT_REG=0 keeps everything on the LDS kernel
+  const bool use_reg = iiwt_reg_supported (filter, bpp)
+      && !(SCHRO_ENV ("SCHRO_HIP_IIWT_REG") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_REG")) == 0);
+  int ruc = 0, rur = 0, rmin = 0, rmin_any = 0;
+  if (use_reg) {
+    int suc, sur, srmin;
+    iiwt_reg_geometry (filter, 0, &ruc, &rur, &rmin);
+    iiwt_reg_geometry (filter, 1, &suc, &sur, &srmin);
+    rmin_any = std::max (rmin, srmin);  // (whichever tile form the level loop picks for level 0)
+  }
+
   // scratch for the intermediate LL images: levels depth-1 .. 1 of every plane
   std::vector < size_t > scratch_off ((size_t) nplanes * depth, 0);
   std::vector < int >scratch_stride ((size_t) nplanes * depth, 0);
@@ -351,8 +363,12 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
     // a combine plane whose finest level cannot take the register kernel's combine form (s32, the fidelity
     // filter, unaligned planes) goes through a residual plane in the scratch and the convert kernel
     if (pl.combine) {
-      const bool direct = bpp == 2 && iiwt_reg_supported (filter, bpp) && (pl.width / 2) % 4 == 0 && pl.height / 2 >= 12
+      // (exactly what the level loop below asks of a level-0 register tile -- ADVICE r04: a plane this test let
+      // through and the loop then refused returned EINVAL instead of taking the scratch route)
+      const bool direct = bpp == 2 && use_reg && (pl.width / 2) % 4 == 0 && pl.height / 2 >= rmin_any
           && ((((uintptr_t) pl.src | (uintptr_t) pl.src_stride | (uintptr_t) pl.dst | (uintptr_t) pl.dst_stride) & 7) == 0)
+          // (a depth-1 call reads its LL band from the caller's plane)
+          && (depth > 1 || !pl.ll || (((uintptr_t) pl.ll | (uintptr_t) pl.ll_stride) & 7) == 0)
           // (the prediction's rows: 8-byte aligned and readable up to a multiple of 8 columns)
           && (pl.combine != 1 || ((((uintptr_t) pl.pred | (uintptr_t) pl.pred_stride) & 7) == 0 && pl.pred_stride >= ((pl.out_width + 7) & ~7)));
       if (!direct) {
@@ -381,13 +397,6 @@ schro_hip_iiwt_batch (SchroHipContext * ctx, const SchroHipIwtPlane * planes, in
   int uc, ur;
   iiwt_tile_geometry (filter, bpp, &uc, &ur);
 
-  // per level: planes that allow it run the register form (iiwt_reg.hip), the rest the
-  // LDS tile kernel; SCHRO_HIP_IIWT_REG=0 keeps everything on the LDS kernel
-  const bool use_reg = iiwt_reg_supported (filter, bpp)
-      && !(SCHRO_ENV ("SCHRO_HIP_IIWT_REG") && atoi (SCHRO_ENV ("SCHRO_HIP_IIWT_REG")) == 0);
-  int ruc = 0, rur = 0, rmin = 0;
-  if (use_reg)
-    iiwt_reg_geometry (filter, 0, &ruc, &rur, &rmin);
 
   // Fused group (opt-in): SCHRO_HIP_IIWT_FUSE=n runs levels b .. b+n-1 as ONE launch of
   // the fused LDS kernel, b = SCHRO_HIP_IIWT_FUSE_BASE (default 1 where level 0 has the

@@ -192,3 +192,33 @@ def test_picture_weights(ctx):
             run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=prec, seed=5 + prec, weights=weights)
     with pytest.raises(sa.SchroHipError, match="prediction_only"):
         run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=2, seed=5, weights=(2, 3, 1))
+
+
+def test_depth_one_call_with_an_unaligned_ll_plane_takes_the_scratch_route(ctx):
+    """r05: the second call of a transform in two calls (depth 1, SchroHipIwtPlane.ll) in the combine form,
+    with an LL plane whose rows are NOT 8-byte aligned: the register kernel cannot read it, and the call must fall back to
+    the residual plane in the scratch + convert route (it returned EINVAL, "promised a register tile") -- same picture."""
+    from schroedinger_amd import DevicePlane
+    h, w, depth, filt = 544, 960, 3, 0
+    img = (synth.image_s(h, w, np.int16, seed=31).astype(np.int64) * 3).astype(np.int16)
+    co = O.forward_iwt(img, depth, filt)
+    res_want = O.inverse_iwt(co, depth, filt)
+    d_co = ctx.upload(co)
+    ll_al = ctx.plane(h // 2, w // 2, np.int16)
+    ctx.iiwt_batch([(d_co.level_view(1), ll_al)], depth - 1, filt)
+    # the same LL band two bytes into a wider plane: pointer % 8 == 2
+    wide = ctx.plane(h // 2, w // 2 + 8, np.int16)
+    host = np.zeros((h // 2, w // 2 + 8), np.int16)
+    host[:, 1:1 + w // 2] = ll_al.download()
+    wide.upload(host)
+    ll_un = DevicePlane.__new__(DevicePlane)
+    ll_un.ctx, ll_un.dtype = ctx, np.dtype(np.int16)
+    ll_un.height, ll_un.width, ll_un.stride = h // 2, w // 2, wide.stride
+    ll_un.nbytes, ll_un.ptr = 0, wide.ptr + 2
+    for ll in (ll_al, ll_un):
+        out = ctx.plane(h, w, np.uint8).fill(0x33)
+        ctx.iiwt_batch([(d_co, out, None)], 1, filt, ll=[ll])
+        assert np.array_equal(out.download(), O.convert_u8(res_want, w, h)), "aligned" if ll is ll_al else "unaligned"
+        out.free()
+    for p in (d_co, ll_al, wide):
+        p.free()
