@@ -47,6 +47,16 @@ extern "C" {
 #define SCHRO_HIP_ENOMEM (-3)
 #define SCHRO_HIP_EUNSUPPORTED (-4)
 #define SCHRO_HIP_ESKIPPED (-5) /* scheduler: the picture did not run, one of its references had failed */
+/* r05 -- not an error of the stream but a ROUTING answer of the combine form (add = FALSE / prediction_only): this
+ * picture's prediction does not fit the u8 plane it would be written to (a DC value outside [-128, 127], or picture
+ * weights with a gain above 1 -- the reference's 16-bit block arithmetic wraps there, schromotion8.c:542-657), so
+ * the picture takes the residual order instead (inverse transform into the residual frame, then
+ * schro_motion_render_hip (..., add = TRUE, ...): INTEGRATION 3).  schro_motion_render_hip (add = FALSE) answers
+ * BEFORE it launches anything when the vectors are in host memory (it scans them); with device-resident vectors the
+ * launch raises a flag that the next synchronising call of the context reports with this code, naming the
+ * prediction_only batch (schro_hip_obmc_prediction_epoch).  schro_hip_set_abort_on_error (1) never turns this
+ * code into an abort. */
+#define SCHRO_HIP_ENEEDS_RESIDUAL (-6)
 
 /* schroedinger/schrodomain.h:30-36 -- ids for the new domain */
 #define SCHRO_EXEC_DOMAIN_HIP 0x0004
@@ -484,12 +494,16 @@ typedef struct {
                                  * combine form of schro_hip_iiwt_batch.  The prediction must fit 8 bits -- it does for
                                  * every legal stream: weights with picture_weight_1, _2 >= 0 and a sum <= 1 << bits are
                                  * required (else an error at the call), and a DC value outside [-128, 127] makes the
-                                 * launch raise an error the next call of the context reports (such pictures need the
+                                 * launch raise a flag: the next synchronising call of the context answers
+                                 * SCHRO_HIP_ENEEDS_RESIDUAL and names the batch (such pictures need the
                                  * residual form, which follows the reference's 16-bit wrap-around). */
 } SchroHipObmcPlane;
 
 int schro_hip_obmc_batch (SchroHipContext * ctx,
     const SchroHipObmcPlane * planes, int nplanes);
+/* r05: prediction_only calls of schro_hip_obmc_batch are numbered per context (1, 2, ...); this is the number of
+ * the latest one (0: none yet) -- what a later SCHRO_HIP_ENEEDS_RESIDUAL names. */
+unsigned int schro_hip_obmc_prediction_epoch (SchroHipContext * ctx);
 
 /* ---- core-syntax coefficients: dequantisation on the device ----------------
  *

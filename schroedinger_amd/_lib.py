@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
     "schro_hip_decode_lowdelay_transform_data",
-    "schro_hip_obmc_batch",
+    "schro_hip_obmc_batch", "schro_hip_obmc_prediction_epoch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
     "schro_frame_inverse_iwt_transform_hip", "schro_frame_inverse_iwt_transform_combine_hip", "schro_upsampled_hipframe_upsample",
@@ -360,6 +360,8 @@ def load():
     L.schro_hip_upsampled_pair_download.restype = i
     L.schro_hip_obmc_batch.argtypes = [vp, C.POINTER(ObmcPlane), i]
     L.schro_hip_obmc_batch.restype = i
+    L.schro_hip_obmc_prediction_epoch.argtypes = [vp]
+    L.schro_hip_obmc_prediction_epoch.restype = C.c_uint
     L.schro_hip_frame_new_and_alloc.argtypes = [vp, i, i, i, i]
     L.schro_hip_frame_new_and_alloc.restype = C.POINTER(Frame)
     L.schro_hip_frame_ref.argtypes = [C.POINTER(Frame)]
@@ -388,10 +390,15 @@ def load():
 
 
 class SchroHipError(RuntimeError):
-    pass
+    code = None         # the SCHRO_HIP_E* value where the error came from a call's return value
+
+
+ENEEDS_RESIDUAL = -6    # SCHRO_HIP_ENEEDS_RESIDUAL: a routing answer of the combine form, not an error of the stream
 
 
 def check(rc):
     if rc != 0:
         msg = load().schro_hip_last_error()
-        raise SchroHipError("schro_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        e = SchroHipError("schro_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        e.code = rc
+        raise e

@@ -34,6 +34,16 @@ set_error (int code, const char *fmt, ...)
 }
 
 int
+set_status (int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (g_err, sizeof (g_err), fmt, ap);
+  va_end (ap);
+  return code;
+}
+
+int
 push_args (SchroHipContext * ctx, const void *host, size_t bytes, void **dev)
 {
   if (bytes == 0 || bytes > SchroHipContext::kArgSlotBytes)
@@ -176,10 +186,24 @@ dc_gave_up (SchroHipContext * ctx)
     return set_error (SCHRO_HIP_EDEVICE, "inverse wavelet launch %u: a tile gave up waiting for the level above it (its picture is incomplete)",
         epoch);
   }
-  if (ctx->dc_gave_up && ((volatile uint32_t *) ctx->dc_gave_up)[2]) {
-    ((volatile uint32_t *) ctx->dc_gave_up)[2] = 0;
-    return set_error (SCHRO_HIP_EDEVICE, "a prediction_only OBMC launch met a DC value outside [-128, 127]: its prediction does not fit "
-        "8 bits and the combined picture differs from the reference's; such pictures take the residual form");
+  // r05: predictions that did not fit 8 bits (prediction_only OBMC batches, numbered).  Not an error of the
+  // stream -- the reference decodes such a picture (16-bit wrap, schromotion8.c:542-657) -- but an answer the
+  // caller routes on: the picture of that batch is wrong and takes the residual order.  Never aborts.
+  if (ctx->dc_gave_up) {
+    volatile uint32_t *ring = (volatile uint32_t *) ctx->dc_gave_up + 4;
+    uint32_t first = 0;
+    int n = 0;
+    for (int k = 0; k < SchroHipContext::kOvfRing; k++)
+      if (ring[k]) {
+        ring[k] = 0;
+        if (!first || ctx->ovf_epoch[k] < first)
+          first = ctx->ovf_epoch[k];
+        n++;
+      }
+    if (n)
+      return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "prediction_only OBMC batch %u%s met a DC value outside [-128, 127]: its prediction "
+          "does not fit 8 bits and the combined picture differs from the reference's; such pictures take the residual order "
+          "(schro_hip_obmc_prediction_epoch names a batch)", first, n > 1 ? " (and later ones)" : "");
   }
   return 0;
 }
@@ -480,6 +504,8 @@ context_new_unbound (int device)
     ctx->scratch_size_q[q] = 0;
     ctx->dc_epoch = 0;
     ctx->dc_gave_up = nullptr;
+    ctx->pred_epoch = 0;
+    memset (ctx->ovf_epoch, 0, sizeof (ctx->ovf_epoch));
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
   }

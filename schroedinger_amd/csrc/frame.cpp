@@ -534,12 +534,38 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
   (void) hipSetDevice (ctx->device);
   size_t mv_bytes = (size_t) 20 * p->x_num_blocks * p->y_num_blocks;
   void *d_mvs = nullptr;
+  // r05 -- the combine form routes itself.  A prediction that cannot be a u8 plane (weights with a gain above 1; a DC
+  // block whose value lies outside [-128, 127]: the reference's s16 block arithmetic carries it, schromotion8.c:542-568,
+  // and wraps) is answered BEFORE anything is launched: SCHRO_HIP_ENEEDS_RESIDUAL, and the caller runs the picture in
+  // the residual order (schrodecoder.c:1742-1760's stages the other way round: INTEGRATION 3).  Vectors that are already
+  // on the device cannot be looked at here; the launch flags them (schro_hip_obmc_batch, prediction_only).
+  if (!add && (p->picture_weight_1 < 0 || p->picture_weight_2 < 0
+          || p->picture_weight_1 + p->picture_weight_2 > (1 << p->picture_weight_bits)))
+    return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "motion_render (add = FALSE): picture weights %d, %d / 2^%d can predict beyond 8 bits: "
+        "this picture takes the residual order", p->picture_weight_1, p->picture_weight_2, p->picture_weight_bits);
   {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes (&attr, motion->motion_vectors) == hipSuccess && attr.type == hipMemoryTypeDevice) {
       d_mvs = motion->motion_vectors;
     } else {
       (void) hipGetLastError ();        // (an ordinary host pointer is "invalid value" to the query)
+      if (!add) {
+        // SchroMotionVector (schromotion.h:53-75): pred_mode in the two low bits of the first word, the DC
+        // values as three int16 at byte 12.  (Blocks on the picture's rim store their DC as a uint8_t and would
+        // fit; they are refused with the rest -- the residual order is exact for every picture.)
+        const unsigned char *mvb = (const unsigned char *) motion->motion_vectors;
+        const size_t nmv = (size_t) p->x_num_blocks * p->y_num_blocks;
+        for (size_t i = 0; i < nmv; i++) {
+          const unsigned char *r = mvb + 20 * i;
+          if (r[0] & 3)
+            continue;
+          int16_t dc[3];
+          memcpy (dc, r + 12, 6);
+          if ((unsigned) (dc[0] + 128) > 255u || (unsigned) (dc[1] + 128) > 255u || (unsigned) (dc[2] + 128) > 255u)
+            return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "motion_render (add = FALSE): block %zu has a DC value outside [-128, 127] "
+                "(%d, %d, %d): its prediction does not fit 8 bits, this picture takes the residual order", i, dc[0], dc[1], dc[2]);
+        }
+      }
       int r = push_big_table (ctx, motion->motion_vectors, mv_bytes, &d_mvs);
       if (r)
         return r;

@@ -281,7 +281,10 @@ out_round_pk (P x)
 // references) and how many of the lane's samples are inside the picture
 struct Combine {
   u32x2 pred;
-  int nvalid;
+  bool row_ok;                  // the row is inside the picture (wave-uniform)
+  bool full;                    // all 8 samples of the lane are: one 8-byte store
+  bool any_ragged;              // (wave-uniform) some lane of the wave has 1 .. 7 samples inside
+  int nvalid;                   // samples of the lane inside the picture (0 .. 8)
 };
 
 template < int F, bool HEDGE, int COH >
@@ -307,7 +310,13 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
     // reference's 16-bit wrapping add (orc_rrshift6_add_s16_2d: addw, convsuswb; the prediction is the (acc + 32) >> 6
     // of the OBMC launch, a u8 plane), or + 128 for a picture without references (orc_offsetconvert_u8_s16).
     // cmb.nvalid: how many of the lane's 8 samples of this row lie inside the picture.
-    if (store_lane && cmb.nvalid > 0) {
+    // r05: no per-lane branch and no loop in here.  r04 wrapped the epilogue in `if (lane stores)` and stored ragged lanes
+    // in a loop over their valid bytes: 16 divergent regions with a waterfall loop each per tile, 25 k lines of code,
+    // and every join a place where the prediction loads in flight were waited for.  Now every lane computes, a row
+    // outside the picture is a SCALAR branch, the full lanes store under the exec mask, and the byte stores of a
+    // ragged right edge (a picture width that is not a multiple of 8) sit behind a scalar test that is false for
+    // every tile of such pictures as 2160p and 1080p.
+    if (cmb.row_ok) {
       const uint32_t q[4] = { o.x, o.y, o.z, o.w };
       const uint32_t pw[4] = {
         __builtin_amdgcn_perm (0u, cmb.pred.x, 0x0c010c00u), __builtin_amdgcn_perm (0u, cmb.pred.x, 0x0c030c02u),
@@ -323,11 +332,18 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
       u32x2 b;
       b.x = __builtin_amdgcn_perm (v[1], v[0], 0x06040200u);
       b.y = __builtin_amdgcn_perm (v[3], v[2], 0x06040200u);
-      if (cmb.nvalid == 8) {
+      if (cmb.full) {
+#ifdef SCHRO_IWT_OUT_NT
+        __builtin_nontemporal_store (b, (SCHRO_GLOBAL u32x2 *) dst);
+#else
         gstore < u32x2 > (dst, b);
-      } else {
-        for (int e = 0; e < cmb.nvalid; e++)
-          gstore < uint8_t > (dst + e, (uint8_t) ((e < 4 ? b.x : b.y) >> (8 * (e & 3))));
+#endif
+      }
+      if (cmb.any_ragged) {
+#pragma unroll
+        for (int e = 0; e < 7; e++)
+          if (!cmb.full && e < cmb.nvalid)
+            gstore < uint8_t > (dst + e, (uint8_t) ((e < 4 ? b.x : b.y) >> (8 * (e & 3))));
       }
     }
   } else if (store_lane) {
@@ -405,31 +421,73 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane, WAIT wai
     // readable up to a multiple of 8 columns); a pair of rows is fetched while the pair before it is finished.
     const int x = 2 * cl, y0 = 2 * (r0 + H);
     const int nx = store_lane ? clampi (job.out_w - x, 0, 8) : 0;
-    char *dst = (char *) job.dst + (size_t) y0 * job.dst_stride + x;
-    const uint8_t *pp = job.pred ? job.pred + (size_t) y0 * job.pred_stride + x : nullptr;
+    const bool full = nx == 8;
+    const bool any_ragged = __builtin_amdgcn_readfirstlane ((int) (__ballot (nx > 0 && nx < 8) != 0)) != 0;
+    // every lane gets an address it may read (and, if it stores at all, write): lanes outside the picture take column 0
+    const int xa = nx > 0 ? x : 0;
+    char *dst = (char *) job.dst + (size_t) y0 *job.dst_stride + xa;
+    const bool has_pred = job.pred != nullptr;  // (uniform: a picture without references adds 128 instead)
+    const uint8_t *pp = job.pred + xa;
     const u32x2 k128 = (u32x2) { 0x80808080u, 0x80808080u };
+    // the lane's 8 prediction bytes of picture row y0 + 2 (i - H) + odd; rows below the picture read the last row
+    // (computed, never stored): the load is unconditional, its row index a scalar
     auto fetch = [&](int i, int odd) {
-      return pp && nx > 0 && y0 + 2 * (i - H) + odd < job.out_h ? gload < u32x2 > (pp + (size_t) (2 * (i - H) + odd) * job.pred_stride) : k128;
+      const int row = min (y0 + 2 * (i - H) + odd, job.out_h - 1);
+#ifdef SCHRO_IWT_PRED_NT
+      return has_pred ? __builtin_nontemporal_load ((const SCHRO_GLOBAL u32x2 *) (pp + (size_t) row * job.pred_stride)) : k128;
+#else
+      return has_pred ? gload < u32x2 > (pp + (size_t) row * job.pred_stride) : k128;
+#endif
     };
-    u32x2 p0 = fetch (H, 0), p1 = fetch (H, 1);
+    // r05 -- where the prediction's registers come from.  The vertical steps have just finished: of the tile's RP row
+    // pairs the H above and the H below the useful ones are dead now (16 H registers), and every finished pair gives
+    // another 8 back; a pair's two prediction rows take 4.  So the predictions of the first AHEAD pairs are asked for
+    // HERE, behind the vertical phase (a scheduling barrier keeps them from rising above it, where the whole tile is
+    // live), and RAMP more pairs each time a pair is done, until all are on their way.  AHEAD 4 is what fits 128
+    // registers without a spill for DD(9,7) (measured, 8 x 2160p finest level: AHEAD 1 / 2 / 3 / 4 = 0.0835 / 0.0787 /
+    // 0.0768 / 0.0762 ms; 8 with 13 spilled dwords 0.0838 = r04's kernel, which also branched per lane, see finish_row).
+    constexpr int NPAIR = RP - 2 * H;
+#ifdef SCHRO_IWT_PRED_AHEAD
+    constexpr int AHEAD = cmin (NPAIR, SCHRO_IWT_PRED_AHEAD);
+#else
+    constexpr int AHEAD = cmin (NPAIR, 4);
+#endif
+#ifdef SCHRO_IWT_PRED_RAMP
+    constexpr int RAMP = SCHRO_IWT_PRED_RAMP;
+#else
+    constexpr int RAMP = 2;
+#endif
+    u32x2 pr[NPAIR][2];
+    __builtin_amdgcn_sched_barrier (0);
+#pragma unroll
+    for (int j = 0; j < AHEAD; j++) {
+      pr[j][0] = fetch (H + j, 0);
+      pr[j][1] = fetch (H + j, 1);
+    }
+    __builtin_amdgcn_sched_barrier (0);
 #pragma unroll
     for (int i = H; i < RP - H; i++) {
-      const int y = y0 + 2 * (i - H);
-      const Combine c0 = { p0, y < job.out_h ? nx : 0 }, c1 = { p1, y + 1 < job.out_h ? nx : 0 };
-      if (i + 1 < RP - H) {
-        p0 = fetch (i + 1, 0);
-        p1 = fetch (i + 1, 1);
-      }
+      const int j = i - H;
+      const int y = y0 + 2 * j;
+      const Combine c0 = { pr[j][0], y < job.out_h, full, any_ragged, nx }, c1 = { pr[j][1], y + 1 < job.out_h, full, any_ragged, nx };
       finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst, c0);
       finish_row < F, HEDGE, COH > (O[i], is_first, is_last, store_lane, dst + job.dst_stride, c1);
       dst += 2 * (size_t) job.dst_stride;
-      // (one pair of rows ahead, no more: left alone the scheduler hoists every row's prediction load to the top --
-      // 32 registers beside a tile that fills the budget -- and spills 40)
+      // pairs fetched so far: AHEAD + RAMP j; now RAMP more
+#pragma unroll
+      for (int t = 0; t < RAMP; t++) {
+        const int nj = AHEAD + RAMP * j + t;
+        if (nj < NPAIR) {
+          pr[nj][0] = fetch (H + nj, 0);
+          pr[nj][1] = fetch (H + nj, 1);
+        }
+      }
+      // (no further ahead than that: left alone the scheduler hoists every row's prediction load to the top)
       __builtin_amdgcn_sched_barrier (0);
     }
   } else {
     char *dst = (char *) job.dst + (size_t) (2 * (r0 + H)) * job.dst_stride + (size_t) cl * 4;
-    const Combine none = { (u32x2) { 0u, 0u }, 0 };
+    const Combine none = { (u32x2) { 0u, 0u }, false, false, false, 0 };
 #pragma unroll
     for (int i = H; i < RP - H; i++) {
       finish_row < F, HEDGE, COH > (E[i], is_first, is_last, store_lane, dst, none);

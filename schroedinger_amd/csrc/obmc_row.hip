@@ -350,6 +350,23 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   const int e = s_item[min (it, hi - 1)];
   const auto & hb = s_hot[e & 0x1ff];
   const int row = e >> 9;
+#ifdef SCHRO_ROW_EARLY_W
+  // (experiment) the row's weights and accumulator address are read BEFORE the reference loads go out: their LDS
+  // round trip hides behind the memory latency instead of following it
+  int half_e;
+  uint32_t *aw_e = acc_word < G, UV > (acc, par, hb.x, hb.y + row, &half_e);
+  uint32_t w_e[2 * ND];
+  if constexpr (CLS != kREdge) {
+    const u32x2 *wp = reinterpret_cast < const u32x2 * >(s_wp + 2 * ND * row);
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const u32x2 q = wp[k];
+      w_e[2 * k] = q.x;
+      w_e[2 * k + 1] = q.y;
+    }
+    __builtin_amdgcn_sched_barrier (0);
+  }
+#endif
   uint32_t p[ND];
   if constexpr (CLS == kRDc) {
     // (DC values outside 0..255 are not in this class: rim)
@@ -384,8 +401,12 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   }
   if (it >= hi)
     return;
+#ifdef SCHRO_ROW_EARLY_W
+  uint32_t *aw = aw_e;
+#else
   int half;
   uint32_t *aw = acc_word < G, UV > (acc, par, hb.x, hb.y + row, &half);       // (block origins + par are even: half == 0)
+#endif
   // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go.  A word's two
   // 16-bit weights multiply the two bytes of a prediction byte pair: two neighbouring pixels, UV: the pixel's U and V
   uint32_t w[2 * ND];
@@ -399,6 +420,11 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     for (int k = 0; k < 2 * ND; k++)
       w[k] = __builtin_bit_cast (uint32_t, (u16x2) (__builtin_bit_cast (u16x2, wxf[k]) * __builtin_bit_cast (u16x2, wy2)));
   } else {
+#ifdef SCHRO_ROW_EARLY_W
+#pragma unroll
+    for (int k = 0; k < 2 * ND; k++)
+      w[k] = w_e[k];
+#else
     const u32x2 *wp = reinterpret_cast < const u32x2 * >(s_wp + 2 * ND * row);
 #pragma unroll
     for (int k = 0; k < ND; k++) {
@@ -406,6 +432,7 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
       w[2 * k] = q.x;
       w[2 * k + 1] = q.y;
     }
+#endif
   }
 #pragma unroll
   for (int k = 0; k < 2 * ND; k++) {
@@ -679,7 +706,9 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
   }
 }
 
-template < int ND, int NP, bool UV = false, int TH = kRTH >
+// NORES (r05): every job of the launch is a prediction_only job (no residual to add: the combine form's launches,
+// bench.py's headline).  The eight registers that carry the prefetched residual through the passes are not held at all.
+template < int ND, int NP, bool UV = false, int TH = kRTH, bool NORES = false >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow)
 {
@@ -952,7 +981,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     // The residual of the fast finish is asked for before the passes where the registers allow
     // (8 per lane, held through the passes): it streams from HBM, and fetched after the passes
     // its latency was the tile's to wait for.
-    constexpr bool kEarlyRes = ND >= 3 && NP == 1;
+    constexpr bool kEarlyRes = ND >= 3 && NP == 1 && !NORES;
     const bool fast = row_finish_is_fast < G > (job, io, x_lo, x_hi) && (!UV || row_finish_is_fast < G > (job, iov, x_lo, x_hi));
     constexpr int kRounds = kRFinishRounds < TH, G >;
     u32x4 res[UV ? 2 * kRounds : kRounds];
@@ -1017,7 +1046,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       }
     }
     RSTAMP (5);
-    if constexpr (!kEarlyRes) {
+    if constexpr (NORES) {
+#pragma unroll
+      for (int n = 0; n < (UV ? 2 * kRounds : kRounds); n++)
+        res[n] = (u32x4) { 0u, 0u, 0u, 0u };
+    } else if constexpr (!kEarlyRes) {
       if (fast)
         SCHRO_ROW_PREFETCH ();
     }
@@ -1073,6 +1106,21 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_4_2, 4, 4, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_2, 5, 2, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_3, 7, 3, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 4, 4, 1, true)
+// prediction_only launches (NORES, r05).  Without the residual's eight registers the 12-pixel-row kernel takes 60
+// VGPRs and -- compiled for eight waves -- 78 SGPRs: EIGHT workgroups per CU (LDS 8 x 19 776 B = 158 KB; a CU admits
+// floor (800 / (ceil (sgpr / 16) 16 + 16)) 256-thread workgroups: 7 at 81 .. 96 SGPRs).  8 x 2160p, same box: OBMC
+// 0.1706 -> 0.1674 ms per step; the weights read before the reference loads go out (-DSCHRO_ROW_EARLY_W): 0.1697 at
+// seven, 0.1668 .. 0.1703 at eight -- the launch is not waiting for LDS round trips.  The (U, V) kernel stays at seven:
+// 22 080 B of LDS and 89 SGPRs.
+#ifndef SCHRO_ROW_PRED_WAVES
+#define SCHRO_ROW_PRED_WAVES 8
+#endif
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_2_1, 6, 2, 1, false, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_3_1, SCHRO_ROW_PRED_WAVES, 3, 1, false, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_4_1, 4, 4, 1, false, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_2, 5, 2, 1, true, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, 7, 3, 1, true, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_4, 4, 4, 1, true, kRTH, true)
 #undef SCHRO_ROW_KERNEL
 
 typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *, uint32_t *);
@@ -1093,6 +1141,17 @@ launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
     case 32: k = obmc_row_kernel_3_2; break;
     case 41: k = obmc_row_kernel_4_1; break;
     case 42: k = obmc_row_kernel_4_2; break;
+  }
+  // a prediction_only launch (the caller passes its overflow word exactly then: every job's residual is NULL)
+  if (overflow) {
+    switch (nd * 10 + np) {
+      case 23: k = obmc_row_kernel_p_uv_2; break;
+      case 33: k = obmc_row_kernel_p_uv_3; break;
+      case 43: k = obmc_row_kernel_p_uv_4; break;
+      case 21: k = obmc_row_kernel_p_2_1; break;
+      case 31: k = obmc_row_kernel_p_3_1; break;
+      case 41: k = obmc_row_kernel_p_4_1; break;
+    }
   }
   if (!k)
     return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row x %d planes unsupported", nd, np);

@@ -1634,6 +1634,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   static const bool use_row = !SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL") || strcmp (SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
   std::vector < ObmcJob > all (nplanes);
   std::vector < int >key (nplanes), row_nd (nplanes);
+  uint32_t pred_epoch = 0;      // (r05: this call's number among the context's prediction_only calls, once it has one)
   for (int p = 0; p < nplanes; p++) {
     const SchroHipObmcPlane & pl = planes[p];
     // (residual NULL: nothing to add -- the prediction alone, clamped)
@@ -1771,7 +1772,15 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
         memset (ctx->dc_gave_up, 0, 64);
       }
-      overflow = ctx->dc_gave_up + 2;
+      // (one number and one ring word per prediction_only CALL: all its launches share them)
+      if (!pred_epoch) {
+        pred_epoch = ++ctx->pred_epoch;
+        const int slot = (int) (pred_epoch % SchroHipContext::kOvfRing);
+        // a word still raised by a batch nobody has asked about keeps naming THAT batch
+        if (!((volatile uint32_t *) ctx->dc_gave_up)[4 + slot])
+          ctx->ovf_epoch[slot] = pred_epoch;
+      }
+      overflow = ctx->dc_gave_up + 4 + pred_epoch % SchroHipContext::kOvfRing;
     }
     const int variant = uv ? 4 : nd ? 3 : ((key[first] >> 4) & 15);
     std::vector < ObmcJob > jobs;
@@ -1822,6 +1831,19 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       return r;
   }
   return 0;
+}
+
+}                               // extern "C"
+
+extern "C" {
+
+// r05: the number the LATEST prediction_only call of schro_hip_obmc_batch on this context was given (1, 2, ...; 0: none
+// yet).  A later SCHRO_HIP_ENEEDS_RESIDUAL from a synchronising call names the batch whose prediction did not fit
+// 8 bits by this number, so a host that pipelines pictures knows WHICH picture to repeat in the residual order.
+unsigned int
+schro_hip_obmc_prediction_epoch (SchroHipContext * ctx)
+{
+  return ctx ? ctx->pred_epoch : 0u;
 }
 
 }                               // extern "C"

@@ -22,6 +22,8 @@
 namespace schro {
 
 int set_error (int code, const char *fmt, ...);
+// the same, but never aborts: an answer the caller routes on (SCHRO_HIP_ENEEDS_RESIDUAL), not a trapped assertion
+int set_status (int code, const char *fmt, ...);
 
 static inline int
 div_up (int a, int b)
@@ -568,7 +570,13 @@ struct SchroHipContext {
   void *dc_edge_q[kQueues];
   size_t dc_edge_size_q[kQueues];
   uint32_t dc_epoch;
-  uint32_t *dc_gave_up;         // pinned host word the kernel writes a launch's epoch to when a strip gives up
+  uint32_t *dc_gave_up;         // pinned host words (16): [0] the epoch of a DC launch whose strip gave up, [1] of a chain
+                                // wavelet launch, [4 .. 15] r05: a ring of flags, one per prediction_only OBMC batch in turn
+  // r05: prediction_only OBMC batches are numbered (1, 2, ...); batch e raises word 4 + e % kOvfRing when one of its
+  // predictions does not fit 8 bits, and ovf_epoch[] remembers which batch a ring word was last handed to
+  static constexpr int kOvfRing = 12;
+  uint32_t pred_epoch;
+  uint32_t ovf_epoch[kOvfRing];
   int cus;                      // compute units of the device (launch shaping)
 };
 

@@ -122,12 +122,17 @@ def test_headline_size(ctx):
 
 def test_predictions_outside_8_bits_are_refused(ctx):
     # a DC value outside [-128, 127]: the reference's 16-bit arithmetic wraps; the u8 prediction plane cannot carry
-    # it -- the launch raises an error that the next synchronisation reports (the residual form stays exact)
+    # it.  Plane layer (the vectors are on the device): the launch raises a flag, the next synchronisation answers
+    # SCHRO_HIP_ENEEDS_RESIDUAL and names the prediction_only batch (the residual form stays exact)
     def widen(mv):
         dc = np.flatnonzero((mv["flags"] & 3) == 0)
         mv["v"][dc[::3], :3] = 300
-    with pytest.raises(sa.SchroHipError, match="does not fit"):
+    before = ctx.lib.schro_hip_obmc_prediction_epoch(ctx.h)
+    with pytest.raises(sa.SchroHipError, match="does not fit") as ei:
         run_case(ctx, 320, 240, 3, 0, edit_mv=widen)
+    assert ei.value.code == _lib.ENEEDS_RESIDUAL
+    epoch = ctx.lib.schro_hip_obmc_prediction_epoch(ctx.h)
+    assert epoch == before + 1 and ("batch %d " % epoch) in str(ei.value)
     ctx.synchronize()           # (reported once)
     # ... and weights whose prediction can leave 8 bits are refused at the call
     P = synth.motion_params(96, 64, 12, 8, 2, (2, 3, 1), (1, 1))
@@ -135,6 +140,68 @@ def test_predictions_outside_8_bits_are_refused(ctx):
     g, out = ctx.hp_plane(64, 96), ctx.plane(64, 96, np.uint8)
     with pytest.raises(sa.SchroHipError, match="prediction_only"):
         ctx.obmc_batch([sa.obmc_plane(d_mv, P, 0, g, g, None, out, prediction_only=True)])
+
+
+@pytest.mark.parametrize("case", ["dc", "gain"])
+def test_the_frame_layer_routes_such_pictures_before_it_launches(ctx, case):
+    """r05: schro_motion_render_hip (add = FALSE) looks at the host's vectors / weights and answers
+    SCHRO_HIP_ENEEDS_RESIDUAL BEFORE launching -- with stage completion OFF and abort-on-error ON (INTEGRATION 2's
+    settings: a deferred flag would have surfaced in a later picture's call, or aborted the process) -- and the picture
+    decoded in the residual order (inverse transform -> residual frame, motion render with add = TRUE) is the oracle's,
+    wrap-around and all (schromotion8.c:542-568, schrodecoder.c:1742-1760)."""
+    w, h, hs, vs, prec, filt, depth = 320, 240, 1, 1, 2, 0, 3
+    lib = ctx.lib
+    pd = [(h, w), (h >> vs, w >> hs), (h >> vs, w >> hs)]
+    iw = [(up(ph, depth), up(pw, depth)) for (ph, pw) in pd]
+    weights = (1, 1, 1) if case == "dc" else (2, 3, 1)
+    P = synth.motion_params(w, h, 12, 8, prec, weights, (hs, vs))
+    params = frames.make_params(wavelet_filter_index=filt, transform_depth=depth, iwt_luma_width=iw[0][1], iwt_luma_height=iw[0][0],
+                                iwt_chroma_width=iw[1][1], iwt_chroma_height=iw[1][0], num_refs=2,
+                                **{k: P[k] for k in ("xblen_luma", "yblen_luma", "xbsep_luma", "ybsep_luma", "mv_precision",
+                                                     "picture_weight_bits", "picture_weight_1", "picture_weight_2", "x_num_blocks", "y_num_blocks")})
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, seed=4)
+    if case == "dc":
+        dc = np.flatnonzero((mv["flags"] & 3) == 0)
+        assert len(dc) > 3
+        mv["v"][dc[1::2], 0] = 300          # luma DC beyond 8 bits ...
+        mv["v"][dc[0::2], 2] = -200         # ... and a V one below
+    resid = [synth.image_s(ih, iwd, np.int16, seed=20 + k) for k, (ih, iwd) in enumerate(iw)]
+    coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+    res_want = [O.inverse_iwt(c, depth, filt) for c in coeffs]
+    fmt16, fmt8 = frames.frame_format(np.int16, hs, vs), frames.frame_format(np.uint8, hs, vs)
+    transform_frame = frames.HostFrame(coeffs, hs, vs)
+    refs_np = [[synth.picture_u8(ph, pw, seed=40 + 10 * r + k) for k, (ph, pw) in enumerate(pd)] for r in range(2)]
+    refs = []
+    for r in range(2):
+        d = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(refs_np[r], hs, vs))
+        u = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+        sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
+        refs.append(u)
+    mc_tmp, out = frames.DeviceFrame(ctx, fmt8, w, h), frames.DeviceFrame(ctx, fmt8, w, h)
+    residual = frames.DeviceFrame(ctx, fmt16, iw[0][1], iw[0][0])
+    motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
+    epoch = lib.schro_hip_obmc_prediction_epoch(ctx.h)
+    sa.check(lib.schro_hip_context_set_stage_completion(ctx.h, 0))
+    lib.schro_hip_set_abort_on_error(1)
+    try:
+        rc = lib.schro_motion_render_hip(C.byref(motion), mc_tmp.ptr(), None, 0, None)
+    finally:
+        lib.schro_hip_set_abort_on_error(0)
+    assert rc == _lib.ENEEDS_RESIDUAL, rc
+    assert b"residual order" in lib.schro_hip_last_error()
+    assert lib.schro_hip_obmc_prediction_epoch(ctx.h) == epoch          # nothing was launched
+    # the residual order, still without stage completion: the calls only enqueue, one synchronisation at the end
+    dev_tf = frames.DeviceFrame(ctx, fmt16, iw[0][1], iw[0][0]).upload(transform_frame)
+    sa.check(lib.schro_frame_inverse_iwt_transform_hip(residual.ptr(), dev_tf.ptr(), C.byref(params)))
+    sa.check(lib.schro_motion_render_hip(C.byref(motion), None, residual.ptr(), 1, out.ptr()))
+    ctx.synchronize()           # (no flag: nothing to report)
+    sa.check(lib.schro_hip_context_set_stage_completion(ctx.h, 1))
+    got = out.download()
+    for k, (ph, pw) in enumerate(pd):
+        want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k]), O.UpComp(refs_np[1][k]), res_want[k], pw, ph)
+        assert np.array_equal(got[k], want), k
+    for f in (mc_tmp, out, residual, dev_tf) + tuple(refs):
+        f.unref()
 
 
 @pytest.mark.parametrize("hs,vs,prec,filt,depth", [(1, 1, 2, 0, 3), (1, 0, 1, 1, 4), (0, 0, 3, 6, 2)])
