@@ -275,41 +275,116 @@ def batch_kernels(c, b):
         c.obmc_batch(b.obmc_jobs)
 
 
-def cpu_baseline(wl, cores, reps=10):
+def cpu_baseline(wl, cores, reps=10, check=True):
     """The oracle on `cores` threads, `reps` pictures each (one picture per thread at a time:
-    the reference's own picture-level parallelism), also used to check the GPU output of
-    frame 0."""
+    the reference's own picture-level parallelism).  r05: the threads walk through EVERY picture the timed
+    steps kept in flight -- the `queues` batch sets x `frames` pictures, 16 by default -- and the first
+    result for each is kept: `check` compares all of them with what the device holds (every
+    timed output against the CPU restatement).  Returns (Mpix/s, pictures checked, pictures equal, one-thread Mpix/s)."""
     import oracle_lib as O      # cpu_baseline leg only
     O.lib()
-    ups = [[O.UpComp(p, upsample=False) for p in comps] for comps in wl.ref_np]
-    results = [None] * cores
+    ups = [[[O.UpComp(p, upsample=False) for p in comps] for comps in grp] for grp in wl.ref_np_all]
+    pics = [(s, f) for s in range(len(wl.sets)) for f in range(wl.frames)]
+    results = {}
+    lock = threading.Lock()
 
     def one(i, n=1):
         for rep in range(n):
-            f = (i + rep) % min(wl.frames, REF_GROUP)       # (pictures of the first reference group)
+            s, f = pics[(i + rep * cores) % len(pics)]
+            b = wl.sets[s]
+            g = min(f // REF_GROUP, wl.groups - 1)
             outs = []
             for k, (h, w) in enumerate(wl.dims):
-                res = O.inverse_iwt(wl.coeff_np[f][k], DEPTH, FILTER)
-                outs.append(O.motion_render(wl.mv_np[f], O.MotionParams(**wl.P), k, ups[0][k], ups[1][k],
+                res = O.inverse_iwt(b.coeff_np[f][k], DEPTH, FILTER)
+                outs.append(O.motion_render(b.mv_np[f], O.MotionParams(**wl.P), k, ups[g][0][k], ups[g][1][k],
                                             res, w, h))
-            if rep == 0 and i == 0:
-                results[i] = outs
+            with lock:
+                if (s, f) not in results:
+                    results[(s, f)] = outs
 
     t0 = time.perf_counter()
-    for comps in ups:                      # reference upsampling, once per reference
-        ths = [threading.Thread(target=lambda u=u: O.lib().oracle_upcomp_upsample(u.c)) for u in comps]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
+    for grp in ups:                        # reference upsampling, once per reference
+        for comps in grp:
+            ths = [threading.Thread(target=lambda u=u: O.lib().oracle_upcomp_upsample(u.c)) for u in comps]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
     ths = [threading.Thread(target=one, args=(i, reps)) for i in range(cores)]
     [t.start() for t in ths]
     [t.join() for t in ths]
     dt = time.perf_counter() - t0
-    ok = all(np.array_equal(wl.out[0][k].download(), results[0][k]) for k in range(3))
+    checked = equal = 0
+    if check:
+        for (s, f), outs in sorted(results.items()):
+            checked += 1
+            equal += all(np.array_equal(wl.sets[s].out[f][k].download(), outs[k]) for k in range(3))
     # one picture on one thread (upsampled references already there): the single-thread figure
     t1 = time.perf_counter()
     one(0)
     single = W * H / (time.perf_counter() - t1) / 1e6
-    return cores * reps * W * H / dt / 1e6, ok, single
+    return cores * reps * W * H / dt / 1e6, checked, equal, single
+
+
+def coherent_motion_field(nbx, nby, seed):
+    """A smooth field -- a pan plus a slow zoom, different for the two references -- with +-2 quarter-pels of
+    noise per block and the headline's mode mix: what a real encoder's vectors look like to the gather, next to
+    the headline's independent-per-block worst case."""
+    mv = synth.motion_field(nbx, nby, 64, seed=seed)
+    mode = mv["flags"] & 3
+    yy, xx = np.divmod(np.arange(nbx * nby), nbx)
+    n = synth.lcg(4 * nbx * nby, 77 + seed).reshape(4, -1) % 5 - 2
+    vec = np.stack([5 + xx // 64 + n[0], -7 + xx // 48 + n[1], 3 + yy // 64 + n[2], 9 - yy // 48 + n[3]], 1).astype(np.int16)
+    mv["v"] = np.where((mode == 0)[:, None], mv["v"], vec)
+    return mv
+
+
+def coherent_motion(wl, steps=24):
+    """The headline's step with coherent vectors instead of independent ones (outside the timed region; the L1-hit
+    sensitivity of the OBMC gather on record): the same pictures, references, coefficients and mode mix."""
+    import schroedinger_amd as sa
+    c = wl.ctx
+    c.select_queue(0)
+    c.synchronize()
+    saved = []
+    keep = []
+    for si, b in enumerate(wl.sets):
+        saved.append((b.pred_jobs, b.obmc_jobs))
+        pj = []
+        for f in range(wl.frames):
+            mv = coherent_motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 9000 + 50 * si + f)
+            d_mv = c.upload_bytes(mv)
+            keep.append(d_mv)
+            g = min(f // REF_GROUP, wl.groups - 1)
+            for k in range(3):
+                pj.append(sa.obmc_plane(d_mv, wl.P, k, b.hp[g][0][k], b.hp[g][1][k], None, b.iwt_combine[3 * f + k][2],
+                                        prediction_only=True))
+        b.pred_jobs = pj
+    for _ in range(6):
+        wl.step()
+    c.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    c.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    c.profile_enable(True)
+    c.profile_reset()
+    for _ in range(3):
+        wl.step(alone=True)
+    prof = c.profile_read()
+    c.profile_enable(False)
+    for b, (pj, oj) in zip(wl.sets, saved):
+        b.pred_jobs, b.obmc_jobs = pj, oj
+    # (back to the headline's pictures: the parity check that follows reads them)
+    for _ in range(len(wl.sets)):
+        wl.step()
+    c.synchronize()
+    for d in keep:
+        d.free()
+    return {"ms_per_step": round(dt * 1e3, 4), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
+            "obmc_ms_per_step": round(prof["obmc"][0] / 3, 4),
+            "vectors": "a pan + a slow zoom per reference, +-2 quarter-pels of noise per block, the headline's mode mix",
+            "note": "secondary figure, outside the timed region: the headline's vectors are independent per block "
+                    "(uniform in +-16 pel), the worst case for the gather"}
 
 
 def cpu_model():
@@ -380,6 +455,56 @@ def iiwt_1080p(ctx, frames=8, steps=30):
             "alg_GBs": round(4 * samples / (ms * 1e-3) / 1e9, 1),
             "frac_of_8TBs": round(4 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "two_batches_in_flight": {"ms": round(ms2, 4), "frac_of_8TBs": round(4 * samples / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
+def iiwt_2160p(wl, reps=20):
+    """north_star's own target on its own configuration: the plain 3-level DD(9,7) inverse wavelet of 8 x 2160p 4:2:0
+    s16 pictures into a residual frame (no prediction, no combine epilogue), outside the timed region -- tracked
+    beside kernels.iiwt_3_levels, which since r04 carries the add of the prediction in its finest level."""
+    c = wl.ctx
+    c.select_queue(0)
+    c.synchronize()
+    b0, b1 = wl.sets[0], wl.sets[-1]
+    samples = wl.frames * (W * H * 3 // 2)
+    for _ in range(4):
+        c.iiwt_batch(b0.iwt_pairs, DEPTH, FILTER)
+    c.profile_enable(True)
+    c.profile_reset()
+    for _ in range(reps):
+        c.iiwt_batch(b0.iwt_pairs, DEPTH, FILTER)
+    prof = c.profile_read()
+    c.profile_enable(False)
+    fin, coarse = prof["iiwt_finest"][0] / reps, prof["iiwt_coarse"][0] / reps
+    c.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.iiwt_batch(b0.iwt_pairs, DEPTH, FILTER)
+    c.synchronize()
+    wall1 = (time.perf_counter() - t0) * 1e3 / reps
+    for k in range(4):
+        c.select_queue(k % 2)
+        c.iiwt_batch((b1 if k % 2 else b0).iwt_pairs, DEPTH, FILTER)
+    c.select_queue(0)
+    c.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2 * reps):
+        c.select_queue(k % 2)
+        c.iiwt_batch((b1 if k % 2 else b0).iwt_pairs, DEPTH, FILTER)
+    c.select_queue(0)
+    c.synchronize()
+    wall2 = (time.perf_counter() - t0) * 1e3 / (2 * reps)
+    ms = fin + coarse
+
+    def frac(t, bytes_per_sample=4):
+        return round(bytes_per_sample * samples / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return {"workload": "3-level DD(9,7) IIWT, %d x 3840x2160 4:2:0 s16 per launch set, residual frame out" % wl.frames,
+            "kernels_ms": round(ms, 4), "finest_ms": round(fin, 4), "coarse_ms": round(coarse, 4),
+            "alg_GBs": round(4 * samples / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": frac(ms),
+            "read_frac_of_8TBs": frac(ms, 2), "Mpix_per_s": round(wl.frames * W * H / ms / 1e3, 1),
+            "wall_ms_one_batch": round(wall1, 4), "wall_frac_of_8TBs_one_batch": frac(wall1),
+            "wall_ms_two_batches_in_flight": round(wall2, 4), "wall_frac_of_8TBs_two_batches": frac(wall2),
+            "note": "kernels_ms: the three launches' own durations (per-launch events); 4 B per sample (2 read + 2 written), "
+                    "SURVEY 8(d); read_frac: the 2 B per sample read side alone"}
 
 
 def quantised_handover(h, w, depth, stride, seed):
@@ -787,6 +912,66 @@ def free_port():
         return s.getsockname()[1]
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (sysfs cpulist syntax)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(index, sysfs="/sys"):
+    """The NUMA node of the index-th AMD GPU (drm cards with vendor 0x1002, in PCI address order -- the order HIP
+    enumerates them in) and that node's CPUs, from sysfs alone: called BEFORE the first HIP call.  (None, []) when
+    the box does not say (no such card, numa_node -1, no cpulist)."""
+    import glob
+    import re
+    cards = []
+    for d in glob.glob(os.path.join(sysfs, "class", "drm", "card*")):
+        if not re.fullmatch(r"card\d+", os.path.basename(d)):
+            continue
+        dev = os.path.join(d, "device")
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip().lower() != "0x1002":
+                continue
+            node = int(open(os.path.join(dev, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            continue
+        cards.append((os.path.basename(os.path.realpath(dev)), node))
+    cards.sort()
+    if index < 0 or index >= len(cards) or cards[index][1] < 0:
+        return None, []
+    node = cards[index][1]
+    try:
+        cpus = parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")).read())
+    except (OSError, ValueError):
+        cpus = []
+    return node, cpus
+
+
+def bind_to_gpu_numa_node(index, sysfs="/sys", setaffinity=None, getaffinity=None):
+    """Bind this process (its threads are created later and inherit the mask) to the CPUs of the GPU's NUMA node,
+    intersected with what it may use already: the host side of a rank -- pinned buffers, enqueue thread, the
+    exec-domain threads -- then sits next to its GPU's PCIe root (the expected scaling limit is the
+    host side).  Returns what it did, for the bench line."""
+    setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
+    getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
+    node, cpus = gpu_numa_cpus(index, sysfs)
+    if node is None or not cpus:
+        return {"numa_node": node, "bound": False}
+    try:
+        allowed = sorted(set(cpus) & set(getaffinity()))
+        if not allowed:
+            return {"numa_node": node, "bound": False, "reason": "none of the node's CPUs is in this process's mask"}
+        setaffinity(allowed)
+    except (OSError, AttributeError) as e:
+        return {"numa_node": node, "bound": False, "reason": str(e)}
+    return {"numa_node": node, "bound": True, "cpus": len(allowed)}
+
+
 def spawn_ranks(n, argv, popen=None):
     """Start n rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, gloo
     rendezvous on 127.0.0.1), wait for all of them, return the largest exit code.  Rank 0's
@@ -842,6 +1027,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # r05: with several ranks on a node each rank's host threads go to its GPU's NUMA node -- before anything touches
+    # HIP (the runtime's own threads inherit the mask).  One rank keeps the whole mask (SCHRO_BENCH_NUMA=1 binds it too).
+    affinity = None
+    if (world > 1 or os.environ.get("SCHRO_BENCH_NUMA") == "1") and os.environ.get("SCHRO_BENCH_NUMA") != "0" \
+            and os.environ.get("SCHRO_BENCH_SHARE_DEVICE") != "1":
+        affinity = bind_to_gpu_numa_node(local_rank)
     import schroedinger_amd as sa
     ndev = sa.device_count()
     if ndev < 1:
@@ -900,6 +1091,25 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+
+    # r05: at N > 1 the host hand-over runs on every rank at once -- SURVEY 8(e): "expected scaling limit = host entropy
+    # decode and PCIe, not the kernels" -- and rank 0 reports the slowest rank's step (outside the timed region)
+    pcie_all = None
+    if world > 1 and not args.headline_only:
+        import torch
+        legs = {}
+        for name, quantised in (("pcie_inclusive", False), ("pcie_inclusive_quantised", True)):
+            wl.queues = 2
+            barrier()
+            r = pcie_pipeline(wl, quantised=quantised)
+            t = torch.tensor([r["ms_per_step"], -r["ms_per_step"], r["host_GBs"]], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r["ms_per_step"] = float(t[0])
+            r["fastest_rank_ms_per_step"] = -float(t[1])
+            r["Mpix_per_s"] = round(args.frames * world * W * H / (float(t[0]) * 1e-3) / 1e6, 1)
+            r["note"] = "max over %d ranks, every rank handing over at once; " % world + r["note"]
+            legs[name] = r
+        pcie_all = legs
 
     if rank == 0:
         pictures = args.frames * world * args.steps
@@ -997,8 +1207,13 @@ def main():
             "kernels": kernels,
             "pixel_path": pixel_path,
         }
+        if affinity is not None:
+            out["host_affinity"] = affinity
+        if pcie_all:
+            out.update(pcie_all)
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
+            out["iiwt_2160p"] = iiwt_2160p(wl)
             out["iiwt_1080p"] = iiwt_1080p(ctx)
             # ... and with 1 and 32 pictures per launch set (one batch in flight / two): where latency ends
             out["iiwt_1080p"]["pictures_per_launch_set"] = {
@@ -1021,9 +1236,12 @@ def main():
                 ts.append(ctx.timer_end())
             out["one_batch_in_flight"] = {"median_ms_per_step": round(float(np.median(ts)), 4),
                                           "Mpix_per_s": round(args.frames * W * H / float(np.median(ts)) / 1e3, 1)}
+        if world == 1 and not args.headline_only:
+            wl.queues = args.queues
+            out["coherent_motion"] = coherent_motion(wl)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share
-            v, ok, single = cpu_baseline(wl, cores)
+            v, checked, equal, single = cpu_baseline(wl, cores)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpix/s", "cores": cores,
                                    "kind": "port", "single_thread": round(single, 2),
                                    "cpu": cpu_model(), "host_cpus": os.cpu_count(),
@@ -1047,13 +1265,15 @@ def main():
             out["cpu_baseline"]["usable_cpus"] = nproc
             out["cpu_baseline"]["cgroup_cpu_quota"] = quota
             if nthr > cores:
-                v_all, _, _ = cpu_baseline(wl, nthr, reps=4)
+                v_all, _, _, _ = cpu_baseline(wl, nthr, reps=4, check=False)
                 out["cpu_baseline"]["all_cores"] = {"value": round(v_all, 2), "threads": nthr,
                                                     "sample": "%d pictures (%d threads x 4)" % (4 * nthr, nthr)}
             else:
                 out["cpu_baseline"]["all_cores"] = "the %d-thread figure: this process may use %d CPU(s)%s" % (
                     cores, nproc, ", its cgroup's quota is %d" % quota if quota else "")
-            out["parity"] = "bit-exact vs oracle on picture 0" if ok else "MISMATCH vs oracle"
+            want = len(wl.sets) * wl.frames
+            out["parity"] = ("bit-exact vs oracle on %d / %d pictures" % (equal, want) if equal == checked == want
+                             else "MISMATCH vs oracle: %d of %d pictures equal (%d of %d checked)" % (equal, checked, checked, want))
         if world == 1 and not args.headline_only:
             wl.queues = 2
             out["pcie_inclusive_quantised"] = pcie_pipeline(wl, quantised=True)
