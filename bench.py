@@ -370,6 +370,7 @@ def coherent_motion(wl, steps=24):
     c.profile_reset()
     for _ in range(3):
         wl.step(alone=True)
+    c.synchronize()             # (both kernel queues: profile_read waits for the selected one only)
     prof = c.profile_read()
     c.profile_enable(False)
     for b, (pj, oj) in zip(wl.sets, saved):

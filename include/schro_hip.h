@@ -835,6 +835,32 @@ int schro_frame_inverse_iwt_transform_combine_hip (SchroHipFrame * output_frame,
 int schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame,
     const void *slices, size_t slices_bytes, const SchroHipLowDelayParams * params);
 
+/* r05 -- the quantised hand-over behind the frame layer (VERDICT r04 "missing" 1): what a patched
+ * schro_decoder_decode_subband (schrodecoder.c:3525-3640) leaves behind for one picture instead of a dense
+ * coefficient frame.  Per component: the codeblock records in the decoder's order (their geometry from
+ * schro_hip_codeblock_layout with the DEVICE transform frame's stride; src_offset / src_bytes / quant_index filled
+ * in as schro_decoder_decode_codeblock goes, src_offset -1 for a zero codeblock, :3311-3322) and the quantised
+ * values of its non-zero codeblocks, row-major and tight, 1 / 2 / 4 bytes each (src_offset counts from the
+ * component's `values`).  INTEGRATION 3 shows the #ifdef HAVE_HIP branch. */
+typedef struct {
+  const SchroHipCodeblock *codeblocks[3];       /* HOST arrays (read during the call) */
+  int ncodeblocks[3];
+  const void *values[3];        /* values_on_device: device pointers (the host uploaded the picture's blob on the copy queue,
+                                 * INTEGRATION 3a); else host pointers, copied by the call (pinned memory if the copy is to be asynchronous) */
+  size_t values_bytes[3];
+  int values_on_device;
+} SchroHipQuantisedPicture;
+
+/* transform_frame: the picture's DEVICE transform frame (s16 or s32), filled completely: zero codeblocks are zero-filled,
+ * the others dequantised with the arithmetic of the decoder the picture takes (params->is_noarith on an s16 frame: the
+ * 16-bit Orc program of the VLC path, schroorc.orc:1098-1219; else C int, schrodecoder.c:3072-3079), and for a picture
+ * without references (params->num_refs == 0) the LL band of every component is DC-predicted (:3629-3636, :3219-3277).
+ * What follows is schro_frame_inverse_iwt_transform_hip (frame, transform_frame, params) as before.  The launch
+ * geometry is kept in a plan of the context's (schro_hip_dequant_plan_*), rebuilt when the picture geometry changes.
+ * Enqueued on the selected queue; complete on return unless stage completion is off. */
+int schro_hipframe_dequantise (SchroHipFrame * transform_frame, const SchroHipQuantisedPicture * quantised,
+    SchroHipParams * params);
+
 /* schro_upsampled_gpuframe_upsample (schrogpuframe.h:27) replacement:
  * dest (device, is_upsampled) <- half-pel images of src (device u8). */
 int schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src);

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "schro_hipframe_shift_right",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
-    "schro_hip_decode_lowdelay_transform_data",
+    "schro_hip_decode_lowdelay_transform_data", "schro_hipframe_dequantise",
     "schro_hip_obmc_batch", "schro_hip_obmc_prediction_epoch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",

@@ -505,6 +505,9 @@ context_new_unbound (int device)
     ctx->dc_epoch = 0;
     ctx->dc_gave_up = nullptr;
     ctx->pred_epoch = 0;
+    ctx->frame_dq_plan = nullptr;
+    ctx->dq_stage_q[q] = nullptr;
+    ctx->dq_stage_size_q[q] = 0;
     memset (ctx->ovf_epoch, 0, sizeof (ctx->ovf_epoch));
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
@@ -624,11 +627,17 @@ schro_hip_context_free (SchroHipContext * ctx)
   for (int q = 0; q < SchroHipContext::kQueues; q++)
     if (ctx->streams[q])
       (void) hipStreamSynchronize (ctx->streams[q]);
+  if (ctx->frame_dq_plan) {
+    schro_hip_dequant_plan_free (ctx->frame_dq_plan);
+    ctx->frame_dq_plan = nullptr;
+  }
   for (auto & s : ctx->slots)
     (void) hipFree (s.ptr);
   if (ctx->dc_gave_up)
     (void) hipHostFree (ctx->dc_gave_up);
   for (int q = 0; q < SchroHipContext::kQueues; q++) {
+    if (ctx->dq_stage_q[q])
+      (void) hipFree (ctx->dq_stage_q[q]);
     if (ctx->scratch_q[q])
       (void) hipFree (ctx->scratch_q[q]);
     if (ctx->dc_edge_q[q])

@@ -454,6 +454,88 @@ schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const
   return r ? r : rs;
 }
 
+// r05 -- schro_decoder_decode_subband's data-parallel half on the device, behind the frame layer: the picture arrives
+// as codeblock records + quantised values (include/schro_hip.h), leaves as the dense transform frame x_wavelet_transform
+// reads.  Reference: schrodecoder.c:3525-3640 (the codeblock loop), :3311-3322 (zero codeblocks), :3060-3083 / :3400-3451
+// (dequantisation), :3629-3636 + :3219-3277 (DC prediction of an intra picture's LL bands), :3280-3293 (codeblock counts).
+int
+schro_hipframe_dequantise (SchroHipFrame * transform_frame, const SchroHipQuantisedPicture * q, SchroHipParams * params)
+{
+  SCHRO_HIP_REQUIRE (transform_frame && frame_ctx (transform_frame) && q && params, "hipframe_dequantise: bad arguments "
+      "(the transform frame must be a device frame)");
+  SchroHipContext *ctx = frame_ctx (transform_frame);
+  const int bpp = format_bpp (transform_frame->format);
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "hipframe_dequantise: the transform frame must be s16 or s32");
+  (void) hipSetDevice (ctx->device);
+  const int arith = params->is_noarith && bpp == 2 ? 1 : 0;
+  const int intra = params->num_refs == 0;
+  SchroHipDequantPlane planes[3];
+  size_t stage_bytes = 0;
+  for (int k = 0; k < 3; k++) {
+    SCHRO_HIP_REQUIRE (q->codeblocks[k] && q->ncodeblocks[k] > 0 && (q->values[k] || q->values_bytes[k] == 0),
+        "hipframe_dequantise: component %d has no codeblock records (or values_bytes without values)", k);
+    stage_bytes += (q->values_bytes[k] + 255) & ~(size_t) 255;
+  }
+  // host-side values: staged in a buffer of the selected queue (the queue's order keeps a later call's copy behind this
+  // call's kernel); a host that pipelines uploads the picture's blob itself, on the copy queue, and passes device pointers
+  char *stage = nullptr;
+  if (!q->values_on_device && stage_bytes) {
+    void *&buf = ctx->dq_stage_q[ctx->cur];
+    size_t & size = ctx->dq_stage_size_q[ctx->cur];
+    if (size < stage_bytes) {
+      if (buf) {
+        SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+        SCHRO_HIP_CHECK (hipFree (buf));
+        buf = nullptr;
+        size = 0;
+      }
+      SCHRO_HIP_CHECK (hipMalloc (&buf, stage_bytes + stage_bytes / 4));
+      size = stage_bytes + stage_bytes / 4;
+    }
+    stage = (char *) buf;
+  }
+  size_t off = 0;
+  for (int k = 0; k < 3; k++) {
+    SchroHipDequantPlane & pl = planes[k];
+    pl.dst = transform_frame->components[k].data;
+    pl.codeblocks = q->codeblocks[k];
+    pl.ncodeblocks = q->ncodeblocks[k];
+    pl.is_intra = intra;
+    if (q->values_on_device || !q->values_bytes[k]) {
+      pl.values = q->values[k];
+    } else {
+      SCHRO_HIP_CHECK (hipMemcpyAsync (stage + off, q->values[k], q->values_bytes[k], hipMemcpyHostToDevice, ctx->stream));
+      pl.values = stage + off;
+      off += (q->values_bytes[k] + 255) & ~(size_t) 255;
+    }
+  }
+  // the plan of this picture geometry: kept while pictures of the same geometry follow each other
+  int r = SCHRO_HIP_EINVAL;
+  if (ctx->frame_dq_plan)
+    r = schro_hip_dequant_plan_matches (ctx->frame_dq_plan, planes, 3, bpp, arith) ? 0 : SCHRO_HIP_EINVAL;
+  if (r) {
+    if (ctx->frame_dq_plan)
+      schro_hip_dequant_plan_free (ctx->frame_dq_plan);
+    ctx->frame_dq_plan = schro_hip_dequant_plan_new (ctx, planes, 3, bpp, arith);
+    if (!ctx->frame_dq_plan)
+      return SCHRO_HIP_EINVAL;
+  }
+  r = schro_hip_dequant_plan_run (ctx->frame_dq_plan, planes, 3);
+  if (!r && intra) {
+    SchroHipDcPlane ll[3];
+    for (int k = 0; k < 3; k++) {
+      const SchroHipFrameData & c = transform_frame->components[k];
+      const int w = k ? params->iwt_chroma_width : params->iwt_luma_width, h = k ? params->iwt_chroma_height : params->iwt_luma_height;
+      ll[k].data = c.data;
+      ll[k].stride = c.stride << params->transform_depth;        // schro_subband_get_frame_data, schroparams.c:319-352
+      ll[k].width = w >> params->transform_depth;
+      ll[k].height = h >> params->transform_depth;
+    }
+    r = schro_hip_dc_predict_batch (ctx, ll, 3, bpp);
+  }
+  return stage_done (ctx, r);
+}
+
 int
 schro_upsampled_hipframe_upsample (SchroHipFrame * dest, SchroHipFrame * src)
 {

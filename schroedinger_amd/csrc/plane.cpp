@@ -1113,6 +1113,28 @@ schro_hip_dequant_plan_new (SchroHipContext * ctx, const SchroHipDequantPlane * 
   return plan;
 }
 
+// whether `planes` are pictures of the plan's geometry (frame layer: one plan per context, rebuilt when this says no)
+bool
+schro_hip_dequant_plan_matches (const SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes, int bpp, int arith)
+{
+  if (!plan || plan->bpp != bpp || plan->arith != arith || nplanes != (int) plan->ncb.size ())
+    return false;
+  size_t rec = 0;
+  for (int p = 0; p < nplanes; p++) {
+    if (planes[p].ncodeblocks != plan->ncb[p])
+      return false;
+    const SchroHipCodeblock *g = plan->geo.data () + rec, *c = planes[p].codeblocks;
+    unsigned bad = 0;
+    for (int k = 0; k < planes[p].ncodeblocks; k++)
+      bad |= (unsigned) (c[k].dst_offset ^ g[k].dst_offset) | (unsigned) (c[k].dst_stride ^ g[k].dst_stride)
+          | (unsigned) (c[k].width ^ g[k].width) | (unsigned) (c[k].height ^ g[k].height);
+    if (bad)
+      return false;
+    rec += (size_t) planes[p].ncodeblocks;
+  }
+  return true;
+}
+
 void
 schro_hip_dequant_plan_free (SchroHipDequantPlan * plan)
 {

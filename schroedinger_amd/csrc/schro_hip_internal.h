@@ -437,6 +437,10 @@ int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsi
     int *edge_pitch, uint32_t * epoch);
 // non-zero (the launch's epoch) once a dc_skew_kernel strip has given up waiting: reported by the next call
 int dc_gave_up (SchroHipContext * ctx);
+}
+// (plane.cpp, beside the plan's other entry points; not part of the public header)
+extern "C" bool schro_hip_dequant_plan_matches (const SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes, int bpp, int arith);
+namespace schro {
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 int launch_dequant_plan (hipStream_t stream, const DequantGeo * d_geo, int njobs, int total_tiles,
     const SchroHipCodeblock * d_recs, const DequantPlaneDyn * d_planes, int bpp, int arith);
@@ -574,6 +578,10 @@ struct SchroHipContext {
                                 // wavelet launch, [4 .. 15] r05: a ring of flags, one per prediction_only OBMC batch in turn
   // r05: prediction_only OBMC batches are numbered (1, 2, ...); batch e raises word 4 + e % kOvfRing when one of its
   // predictions does not fit 8 bits, and ovf_epoch[] remembers which batch a ring word was last handed to
+  // r05: the frame layer's dequantisation plan (schro_hipframe_dequantise): one geometry at a time
+  struct SchroHipDequantPlan *frame_dq_plan;
+  void *dq_stage_q[kQueues];    // staging of host-side quantised values, one per queue (in-order reuse)
+  size_t dq_stage_size_q[kQueues];
   static constexpr int kOvfRing = 12;
   uint32_t pred_epoch;
   uint32_t ovf_epoch[kOvfRing];

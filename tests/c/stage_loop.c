@@ -9,12 +9,21 @@
  *   (ii) INTEGRATION.md 3a: the same stage calls with stage completion OFF
  *        (schro_hip_context_set_stage_completion), frames that cross the boundary in the pinned host domain
  *        (schro_memory_domain_new_hip_host), three pictures in flight, each with its copies and stages in
- *        order on a queue of its own; the host waits only for the download of the picture it hands on.
+ *        order on a queue of its own; the host waits only for the download of the picture it hands on;
+ *   (iii) r05 -- (ii) with the QUANTISED hand-over: what goes up per picture is not the dense
+ *        transform frame but what a patched schro_decoder_decode_subband keeps (schrodecoder.c:3525-3640): the
+ *        codeblock records and one blob of the non-zero codeblocks' quantised values, and
+ *        schro_hipframe_dequantise fills the device transform frame in front of x_wavelet_transform.
+ *
+ * The three passes decode the SAME pictures: the coefficient frames of (i) and (ii) are the quantised sets of (iii),
+ * dequantised once by the library at set-up and brought down (the test checks them against the oracle's
+ * dequantisation of the dumped records and values).
  *
  * Pictures: W x H 4:2:0, 3-level DD(9,7) residual, 12x12/8x8 quarter-pel OBMC from two references that change
  * every 8 pictures (BASELINE config 3's shape; bench.py's workload).  Inputs are synthetic (an LCG, below);
  * with DUMP = 1 the inputs and every decoded picture of both passes go to DIR for tests/test_gpu_c_harness.py
- * to compare with the oracle.  Prints one JSON line.
+ * to compare with the oracle.  Prints one JSON line.  (Pass (iii) as bench.py's quantised leg makes its codeblocks:
+ * up to 8 x 8 per sub-band, 25 - 75 % of the detail bands' codeblocks zero, two-sided geometric values of one byte.)
  *
  *   stage_loop DIR W H NPICTURES DUMP */
 #include <stdio.h>
@@ -165,20 +174,74 @@ main (int argc, char **argv)
   /* ---- inputs, in pinned host frames (pass (i) would work from pageable memory as well) ---- */
   SchroHipFrame *h_coeffs[NSETS], *h_refs[2 * 64];
   uint8_t *h_mvs[NSETS];
+  /* the quantised form of each coefficient set: per component the codeblock records (geometry from
+   * schro_hip_codeblock_layout with the device transform frame's stride), all three components' values in ONE
+   * pinned blob */
+  SchroHipCodeblock *q_recs[NSETS][3];
+  int q_nrec[3];
+  uint8_t *q_blob[NSETS];
+  size_t q_off[NSETS][3], q_bytes[NSETS][3], q_total[NSETS], q_cap = 0;
+  for (int k = 0; k <= DEPTH; k++)
+    params.horiz_codeblocks[k] = params.vert_codeblocks[k] = 8;
   lcg_state = 1;
   for (int s = 0; s < NSETS; s++) {
     h_coeffs[s] = domain_frame (host_domain, fmt16, 2, params.iwt_luma_width, params.iwt_luma_height);
+    size_t cap = 0;
+    for (int k = 0; k < 3; k++)
+      cap += (size_t) h_coeffs[s]->components[k].width * h_coeffs[s]->components[k].height * 2 + 256;
+    q_blob[s] = (uint8_t *) host_domain->alloc ((int) cap);
+    size_t pos = 0;
     for (int k = 0; k < 3; k++) {
-      SchroHipFrameData *c = &h_coeffs[s]->components[k];
-      for (int y = 0; y < c->height; y++) {
-        int16_t *row = (int16_t *) ((char *) c->data + (size_t) y * c->stride);
-        for (int x = 0; x < c->width; x++) {
-          const uint32_t v = lcg ();
-          /* small detail coefficients, larger ones in the depth-3 LL band */
-          row[x] = (y % 8 == 0 && x < c->width / 8) ? (int16_t) (((v >> 6) & 0x3ff) - 512) : (int16_t) ((v & 0x3f) - 32);
+      const SchroHipFrameData *c = &h_coeffs[s]->components[k];        /* (the device transform frames have the same strides) */
+      const int n = schro_hip_codeblock_layout (c->width, c->height, DEPTH, params.horiz_codeblocks, params.vert_codeblocks,
+          c->stride, 2, NULL, 0);
+      q_recs[s][k] = (SchroHipCodeblock *) malloc (sizeof (SchroHipCodeblock) * (size_t) n);
+      q_nrec[k] = schro_hip_codeblock_layout (c->width, c->height, DEPTH, params.horiz_codeblocks, params.vert_codeblocks,
+          c->stride, 2, q_recs[s][k], n);
+      pos = (pos + 255) & ~(size_t) 255;
+      q_off[s][k] = pos;
+      const size_t base = pos;
+      int rec = 0;
+      for (int index = 0; index < 1 + 3 * DEPTH; index++) {
+        const int level = index == 0 ? 0 : (index - 1) / 3;
+        const int per = params.horiz_codeblocks[index == 0 ? 0 : level + 1] * params.vert_codeblocks[index == 0 ? 0 : level + 1];
+        /* zero codeblocks: none in the LL band, 25 .. 75 % of the detail bands' towards the finest level */
+        const uint32_t p_zero = index == 0 ? 0 : (uint32_t) (25 * level + 25 > 75 ? 75 : 25 * level + 25);
+        for (int b = 0; b < per; b++, rec++) {
+          SchroHipCodeblock *cb = &q_recs[s][k][rec];
+          cb->quant_index = (unsigned char) (index == 0 ? 4 : 6 + 3 * level + (b & 3));   /* (several quantisers per sub-band: codeblock_mode_index 1) */
+          if (cb->width == 0 || cb->height == 0 || lcg () % 100 < p_zero)
+            continue;           /* src_offset stays -1: a zero codeblock */
+          const int wide = index == 0;  /* the LL band's values take two bytes */
+          pos = (pos + 1) & ~(size_t) 1;
+          cb->src_offset = (int) (pos - base);
+          cb->src_bytes = wide ? 2 : 1;
+          for (int i = 0; i < cb->width * cb->height; i++) {
+            /* two-sided geometric: most values 0 or +-1 */
+            uint32_t v = lcg ();
+            int mag = 0;
+            while ((v & 3) == 3 && mag < 30) {
+              mag++;
+              v >>= 2;
+            }
+            if (wide)
+              mag = (int) (lcg () % 120);
+            const int val = (lcg () & 1) ? -mag : mag;
+            if (wide) {
+              const int16_t v16 = (int16_t) val;
+              memcpy (q_blob[s] + pos, &v16, 2);
+              pos += 2;
+            } else {
+              q_blob[s][pos++] = (uint8_t) (int8_t) val;
+            }
+          }
         }
       }
+      q_bytes[s][k] = pos - base;
     }
+    q_total[s] = pos;
+    if (pos > q_cap)
+      q_cap = pos;
     /* SchroMotionVector records (schromotion.h:20-37): flags @0 (pred_mode in bits 0-1); @12 the union of
      * dx[2], dy[2] and dc[3]; modes 5 / 45 / 15 / 35 %, vectors uniform in +-64 quarter pels */
     h_mvs[s] = (uint8_t *) host_domain->alloc ((int) (20 * nmv));
@@ -206,15 +269,6 @@ main (int argc, char **argv)
       }
     }
   }
-  if (dump) {
-    for (int s = 0; s < NSETS; s++) {
-      write_file (dir, "%s/coeffs%d.bin", s, h_coeffs[s]->regions[0], frame_bytes (h_coeffs[s]));
-      write_file (dir, "%s/mvs%d.bin", s, h_mvs[s], 20 * nmv);
-    }
-    for (int r = 0; r < 2 * ngroups; r++)
-      write_file (dir, "%s/ref%d.bin", r, h_refs[r]->regions[0], frame_bytes (h_refs[r]));
-  }
-
   /* ---- device frames: SLOTS pictures' worth + two reference sets ---- */
   SchroHipFrame *d_transform[SLOTS], *d_frame[SLOTS], *d_out[SLOTS], *h_out[SLOTS], *d_ref[2][2], *d_up[2][2];
   void *d_mv[SLOTS];
@@ -232,10 +286,44 @@ main (int argc, char **argv)
       if (!d_up[g][r])
         return 1;
     }
-  uint32_t *sums[2];
+  /* ---- set-up: the dense coefficient frames of passes (i) and (ii) ARE the quantised sets, dequantised by the
+   * library (the contract form of the call: host values, complete on return) and brought down ---- */
+  void *d_vals[SLOTS];
+  for (int s = 0; s < SLOTS; s++)
+    d_vals[s] = domain->alloc ((int) q_cap);
+  for (int s = 0; s < NSETS; s++) {
+    SchroHipQuantisedPicture qp;
+    memset (&qp, 0, sizeof (qp));
+    for (int k = 0; k < 3; k++) {
+      qp.codeblocks[k] = q_recs[s][k];
+      qp.ncodeblocks[k] = q_nrec[k];
+      qp.values[k] = q_blob[s] + q_off[s][k];
+      qp.values_bytes[k] = q_bytes[s][k];
+    }
+    qp.values_on_device = 0;
+    CHECK (schro_hipframe_dequantise (d_transform[0], &qp, &params));
+    CHECK (schro_hipframe_to_cpu (h_coeffs[s], d_transform[0]));
+  }
+  if (dump) {
+    for (int s = 0; s < NSETS; s++) {
+      write_file (dir, "%s/coeffs%d.bin", s, h_coeffs[s]->regions[0], frame_bytes (h_coeffs[s]));
+      write_file (dir, "%s/mvs%d.bin", s, h_mvs[s], 20 * nmv);
+      write_file (dir, "%s/qblob%d.bin", s, q_blob[s], q_total[s]);
+      for (int k = 0; k < 3; k++) {
+        char name[64];
+        snprintf (name, sizeof (name), "%%s/qrec%%d_%d.bin", k);
+        write_file (dir, name, s, q_recs[s][k], sizeof (SchroHipCodeblock) * (size_t) q_nrec[k]);
+      }
+    }
+    for (int r = 0; r < 2 * ngroups; r++)
+      write_file (dir, "%s/ref%d.bin", r, h_refs[r]->regions[0], frame_bytes (h_refs[r]));
+  }
+
+  uint32_t *sums[3];
   sums[0] = (uint32_t *) calloc (npic, 4);
   sums[1] = (uint32_t *) calloc (npic, 4);
-  double ms[2];
+  sums[2] = (uint32_t *) calloc (npic, 4);
+  double ms[3];
 
   /* ---- pass (i): the reference's contract ---- */
   for (int rep = 0; rep < 2; rep++) {           /* (first repetition, untimed: warm-up -- job tables, allocator -- and the checks) */
@@ -280,7 +368,15 @@ main (int argc, char **argv)
    * at that and the others at 1.04 with the reference uploads behind a wait that joined the queues. */
   enum { UP = 0, DONE = SLOTS, DOWN = 2 * SLOTS };      /* marks: + slot (16 marks: SLOTS <= 5) */
   CHECK (schro_hip_context_set_stage_completion (ctx, 0));
-  double waited = 0, t_up = 0, t_stage = 0, t_down = 0;      /* where the host's time goes in the timed repetition */
+  /* pass (iii) is the same loop with the quantised hand-over: the blob of the picture's quantised values goes up instead of
+   * the dense transform frame (16 - 20 % of its bytes here), and schro_hipframe_dequantise -- with the values where the
+   * copy queue put them -- stands in front of the transform.  The codeblock records are host arrays: the call copies them
+   * into the context's pinned table ring, from where a kernel brings them over (no copy-engine call of its own). */
+  double host_ms[3][4];         /* [pass][waited, uploads, stages, download]: where the host's time goes in the timed repetition */
+  memset (host_ms, 0, sizeof (host_ms));
+  for (int pass = 1; pass <= 2; pass++) {
+  const int quant = pass == 2;
+  double waited = 0, t_up = 0, t_stage = 0, t_down = 0;
   for (int rep = 0; rep < 2; rep++) {
     CHECK (schro_hip_synchronize (ctx));
     waited = t_up = t_stage = t_down = 0;
@@ -294,9 +390,9 @@ main (int argc, char **argv)
         CHECK (schro_hip_queue_mark_synchronize (ctx, DOWN + s2));
         waited += now_ms () - tw;
         if (rep == 0) {
-          sums[1][k - LAG] = checksum (h_out[s2]);
+          sums[pass][k - LAG] = checksum (h_out[s2]);
           if (dump)
-            write_file (dir, "%s/out_pipelined%d.bin", k - LAG, h_out[s2]->regions[0], frame_bytes (h_out[s2]));
+            write_file (dir, quant ? "%s/out_quantised%d.bin" : "%s/out_pipelined%d.bin", k - LAG, h_out[s2]->regions[0], frame_bytes (h_out[s2]));
         }
       }
       if (k < npic) {
@@ -305,7 +401,10 @@ main (int argc, char **argv)
         /* the transform frame and the vectors up (pinned host memory); a group's first picture also brings the new
          * references (a decoder has them on the device already) */
         CHECK (schro_hip_context_select_queue (ctx, SCHRO_HIP_QUEUE_H2D));
-        CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
+        if (quant)
+          CHECK (schro_hip_upload_2d_async (ctx, d_vals[s], (int) q_total[set], q_blob[set], (int) q_total[set], (int) q_total[set], 1));
+        else
+          CHECK (schro_frame_to_hip_async (d_transform[s], h_coeffs[set]));
         CHECK (schro_hip_upload_2d_async (ctx, d_mv[s], (int) (20 * nmv), h_mvs[set], (int) (20 * nmv), (int) (20 * nmv), 1));
         if (k % GROUP == 0)
           for (int r = 0; r < 2; r++)
@@ -320,6 +419,19 @@ main (int argc, char **argv)
             d_up[g & 1][r]->upsample_done = 0;
             CHECK (schro_upsampled_hipframe_upsample (d_up[g & 1][r], d_ref[g & 1][r]));     /* x_upsample */
           }
+        if (quant) {
+          /* what schro_decoder_decode_subband left behind for this picture */
+          SchroHipQuantisedPicture qp;
+          memset (&qp, 0, sizeof (qp));
+          for (int c = 0; c < 3; c++) {
+            qp.codeblocks[c] = q_recs[set][c];
+            qp.ncodeblocks[c] = q_nrec[c];
+            qp.values[c] = (const char *) d_vals[s] + q_off[set][c];
+            qp.values_bytes[c] = q_bytes[set][c];
+          }
+          qp.values_on_device = 1;
+          CHECK (schro_hipframe_dequantise (d_transform[s], &qp, &params));
+        }
         CHECK (schro_frame_inverse_iwt_transform_hip (d_frame[s], d_transform[s], &params));  /* x_wavelet_transform */
         SchroHipMotion motion;
         memset (&motion, 0, sizeof (motion));
@@ -347,16 +459,33 @@ main (int argc, char **argv)
     }
     CHECK (schro_hip_context_select_queue (ctx, 0));
     CHECK (schro_hip_synchronize (ctx));
-    ms[1] = (now_ms () - t0) / npic;
+    ms[pass] = (now_ms () - t0) / npic;
+  }
+  host_ms[pass][0] = waited / npic;
+  host_ms[pass][1] = t_up / npic;
+  host_ms[pass][2] = t_stage / npic;
+  host_ms[pass][3] = t_down / npic;
   }
   int same = 1;
+  size_t dense_bytes = frame_bytes (h_coeffs[0]), q_sum = 0;
+  for (int s = 0; s < NSETS; s++) {
+    q_sum += q_total[s];
+    for (int k = 0; k < 3; k++)
+      q_sum += sizeof (SchroHipCodeblock) * (size_t) q_nrec[k];
+  }
   for (int k = 0; k < npic; k++)
-    same &= sums[0][k] == sums[1][k];
+    same &= sums[0][k] == sums[1][k] && sums[0][k] == sums[2][k];
   printf ("{\"width\": %d, \"height\": %d, \"pictures\": %d, \"contract_ms_per_picture\": %.4f, \"pipelined_ms_per_picture\": %.4f, "
-      "\"contract_Mpix_per_s\": %.1f, \"pipelined_Mpix_per_s\": %.1f, \"pictures_in_flight\": %d, \"passes_agree\": %s, "
+      "\"quantised_pipelined_ms_per_picture\": %.4f, "
+      "\"contract_Mpix_per_s\": %.1f, \"pipelined_Mpix_per_s\": %.1f, \"quantised_pipelined_Mpix_per_s\": %.1f, "
+      "\"pictures_in_flight\": %d, \"passes_agree\": %s, "
+      "\"quantised_share_of_dense_coefficient_bytes\": %.3f, "
       "\"pipelined_host_ms_per_picture\": {\"waiting_for_a_finished_picture\": %.4f, \"enqueue_uploads\": %.4f, "
+      "\"enqueue_stages\": %.4f, \"enqueue_download\": %.4f}, "
+      "\"quantised_pipelined_host_ms_per_picture\": {\"waiting_for_a_finished_picture\": %.4f, \"enqueue_uploads\": %.4f, "
       "\"enqueue_stages\": %.4f, \"enqueue_download\": %.4f}}\n", w, h, npic,
-      ms[0], ms[1], (double) w * h / ms[0] / 1e3, (double) w * h / ms[1] / 1e3, SLOTS, same ? "true" : "false",
-      waited / npic, t_up / npic, t_stage / npic, t_down / npic);
+      ms[0], ms[1], ms[2], (double) w * h / ms[0] / 1e3, (double) w * h / ms[1] / 1e3, (double) w * h / ms[2] / 1e3, SLOTS,
+      same ? "true" : "false", (double) q_sum / NSETS / (double) dense_bytes,
+      host_ms[1][0], host_ms[1][1], host_ms[1][2], host_ms[1][3], host_ms[2][0], host_ms[2][1], host_ms[2][2], host_ms[2][3]);
   return same ? 0 : 3;
 }

@@ -67,10 +67,13 @@ def test_c_caller_decodes_an_inter_picture(tmp_path, w, h, chroma, prec, blk, fi
 
 def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
     """tests/c/stage_loop.c: a sequence of inter pictures through the frame layer (i) under the reference's
-    contract -- one picture at a time, every stage call complete on return, host frames and vectors -- and
+    contract -- one picture at a time, every stage call complete on return, host frames and vectors --,
     (ii) pipelined as INTEGRATION.md 3a describes (stage completion off, pinned host frames, copy queues,
-    three pictures in flight, marks).  Every picture of both passes equals the oracle's.  (bench.py runs the
-    same program at 2160p for its frame_layer_2160p figures.)"""
+    three pictures in flight, marks), and (iii, r05) pipelined with the QUANTISED hand-over: codeblock records + a blob of
+    quantised values per picture through schro_hipframe_dequantise (schrodecoder.c:3525-3640's data-parallel half on the
+    device).  The dense coefficient frames of (i) and (ii) are the quantised sets dequantised by the library: they must equal
+    the oracle's dequantisation of the dumped records and values.  Every picture of the three passes equals the
+    oracle's.  (bench.py runs the same program at 2160p for its frame_layer_2160p figures.)"""
     import json
     import schroedinger_amd as sa
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "c")])
@@ -92,6 +95,44 @@ def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
         assert o == a.size
         return out
     coeffs = [planes("coeffs%d.bin" % s, np.int16) for s in range(4)]
+    # the quantised sets -> the oracle's dequantisation (oracle_dequant.c: schrodecoder.c:3060-3083, the arithmetic-coded
+    # path's C int arithmetic; inter pictures: schro_table_offset_3_8) must give exactly those coefficient frames
+    CB = np.dtype([("dst_offset", "<i4"), ("dst_stride", "<i4"), ("width", "<i4"), ("height", "<i4"), ("src_offset", "<i4"),
+                   ("src_bytes", "u1"), ("quant_index", "u1"), ("pad", "u1", 2)])
+    assert CB.itemsize == 24
+    n_zero = n_all = 0
+    for s in range(4):
+        blob = np.fromfile(tmp_path / ("qblob%d.bin" % s), np.uint8)
+        off = 0
+        for c, (ph, pw) in enumerate(dims):
+            recs = np.fromfile(tmp_path / ("qrec%d_%d.bin" % (s, c)), CB)
+            assert len(recs) == 8 * 8 * (1 + 3 * depth)
+            stride = (pw * 2 + 15) & ~15                # the C caller's frames: ROUND_UP_16 (width * 2), schroframe.c:60-191
+            plane = np.zeros((ph, stride // 2), np.int16)
+            # the component's values start at the next multiple of 256 of the blob (the C caller's layout)
+            off = (off + 255) & ~255
+            used = 0
+            for r in recs:
+                n_all += 1
+                if r["width"] == 0 or r["height"] == 0:
+                    continue
+                y0, x0 = divmod(int(r["dst_offset"]), stride)
+                x0 //= 2
+                step = int(r["dst_stride"]) // stride
+                dst = plane[y0:y0 + step * int(r["height"]):step, x0:x0 + int(r["width"])]
+                q = None
+                if r["src_offset"] >= 0:
+                    dt = {1: np.int8, 2: np.int16}[int(r["src_bytes"])]
+                    nb = int(r["width"]) * int(r["height"]) * int(r["src_bytes"])
+                    a = off + int(r["src_offset"])
+                    q = blob[a:a + nb].view(dt).reshape(int(r["height"]), int(r["width"]))
+                    used = max(used, int(r["src_offset"]) + nb)
+                else:
+                    n_zero += 1
+                O.dequant_codeblock(dst, q, int(r["quant_index"]), False, 0)
+            off += used
+            assert np.array_equal(plane[:, :pw], coeffs[s][c]), ("dequantised coefficients", s, c)
+    assert 0.2 < n_zero / n_all < 0.7, (n_zero, n_all)
     mvs = [np.fromfile(tmp_path / ("mvs%d.bin" % s), sa.MV_DTYPE) for s in range(4)]
     assert mvs[0].size == P["x_num_blocks"] * P["y_num_blocks"]
     res = [[O.inverse_iwt(c, depth, filt) for c in cs] for cs in coeffs]
@@ -101,7 +142,7 @@ def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
         g, s = k // 8, k % 4
         want = [O.motion_render(mvs[s], O.MotionParams(**P), c, ups[2 * g][c], ups[2 * g + 1][c], res[s][c], dims[c][1], dims[c][0])
                 for c in range(3)]
-        for mode in ("contract", "pipelined"):
+        for mode in ("contract", "pipelined", "quantised"):
             got = planes("out_%s%d.bin" % (mode, k), np.uint8)
             for c in range(3):
                 assert np.array_equal(got[c], want[c]), (mode, k, c)
