@@ -38,7 +38,12 @@
 #define GROUP 8                 /* pictures that share a pair of references */
 #define DEPTH 3
 #ifndef SLOTS
-#define SLOTS 3                 /* pictures in flight in pass (ii) */
+/* pictures in flight in passes (ii) and (iii).  r05: five (three before).  The host hands over picture k - LAG before it enqueues
+ * picture k; with three slots the download of picture k - 1 was enqueued only after the wait for picture k - 2's, so the
+ * device-to-host engine idled while the host enqueued -- the quantised pass, whose bound is that engine (12.4 MB per 2160p
+ * picture against 7 MB up), measured 0.374 / 0.319 / 0.299 ms per picture with 3 / 4 / 5 slots; the dense pass is the
+ * upload's 0.585 whatever the slots.  (Marks: 3 per slot, 16 per context.) */
+#define SLOTS 5
 #endif
 #define LAG (SLOTS - 1)        /* the host hands over picture k - LAG before it enqueues picture k */
 

@@ -82,7 +82,7 @@ def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
     p = subprocess.run([exe, str(tmp_path), str(w), str(h), str(npic), "1"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["passes_agree"] and line["pictures"] == npic and line["pictures_in_flight"] == 3
+    assert line["passes_agree"] and line["pictures"] == npic and line["pictures_in_flight"] == 5
     P = synth.motion_params(w, h, 12, 8, 2, (1, 1, 1), (1, 1))
     dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
 
