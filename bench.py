@@ -759,11 +759,12 @@ def lowdelay_8k(ctx, npic=4, steps=8):
         pics = []
         for _ in range(npic):
             pics.append((ctx.upload_bytes(data), [ctx.plane(h, w, np.int32) for (h, w) in dims],
-                         [ctx.plane(h, w, np.int32) for (h, w) in dims]))
-        return pics, [(sl, co) for sl, co, _ in pics], [(c, p) for _, co, px in pics for c, p in zip(co, px)]
+                         [ctx.plane(h, w, np.int32) for (h, w) in dims], ctx.plane(Hl, 16 * (-(-Wl // 6)), np.uint8)))
+        return (pics, [(sl, co) for sl, co, _, _ in pics], [(c, p) for _, co, px, _ in pics for c, p in zip(co, px)],
+                [(px, 1, 0, v210, Wl, Hl) for _, _, px, v210 in pics], [(co, 1, 0, v210, Wl, Hl) for _, co, _, v210 in pics])
     nq = int(os.environ.get("SCHRO_BENCH_LD_QUEUES", "3"))
     sets = [batch() for _ in range(nq)]
-    pics, jobs, pairs = sets[0]
+    pics, jobs, pairs, packs, fused = sets[0]
     ctx.select_queue(0)
     ctx.lowdelay_batch(jobs, P)
     ctx.synchronize()
@@ -788,25 +789,56 @@ def lowdelay_8k(ctx, npic=4, steps=8):
         ctx.lowdelay_batch(jobs, P)
         ctx.iiwt_batch(pairs, depth, filt)
     prof = ctx.profile_read()
+    # r05: the copy-out the application receives (v210, 10-bit 4:2:2: schrodecoder.c:2011-2052) -- as its own pass over the
+    # pixel frame, and as the epilogue of the transform (schro_hip_iiwt_pack_v210_batch: no pixel frame)
+    ctx.profile_reset()
+    for _ in range(steps):
+        ctx.pack_v210_batch(packs)
+    prof_pack = ctx.profile_read()
+    two_pass_bytes = pics[0][3].download()[:64].copy()
+    ctx.profile_reset()
+    for _ in range(steps):
+        ctx.iiwt_pack_v210_batch(fused, depth, filt)
+    prof_fused = ctx.profile_read()
     ctx.profile_enable(False)
+    fused_equal = bool(np.array_equal(pics[0][3].download()[:64], two_pass_bytes))
+
+    def run(step, reps):
+        for k in range(4):
+            step(k)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            step(k)
+        ctx.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / reps
 
     def step(k):
-        _, jobs_q, pairs_q = sets[k % nq]
+        _, jobs_q, pairs_q, _, _ = sets[k % nq]
         ctx.select_queue(k % nq)
         ctx.lowdelay_batch(jobs_q, P)
         ctx.iiwt_batch(pairs_q, depth, filt)
-    for k in range(4):
-        step(k)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for k in range(2 * steps):
-        step(k)
-    ctx.synchronize()
-    wall = (time.perf_counter() - t0) * 1e3 / (2 * steps)
+
+    def step_two_pass(k):
+        _, jobs_q, pairs_q, packs_q, _ = sets[k % nq]
+        ctx.select_queue(k % nq)
+        ctx.lowdelay_batch(jobs_q, P)
+        ctx.iiwt_batch(pairs_q, depth, filt)
+        ctx.pack_v210_batch(packs_q)
+
+    def step_fused(k):
+        _, jobs_q, _, _, fused_q = sets[k % nq]
+        ctx.select_queue(k % nq)
+        ctx.lowdelay_batch(jobs_q, P)
+        ctx.iiwt_pack_v210_batch(fused_q, depth, filt)
+    wall = run(step, 2 * steps)
+    wall_two = run(step_two_pass, 2 * steps)
+    wall_fused = run(step_fused, 2 * steps)
     ctx.select_queue(0)
-    for pics_q, _, _ in sets:
-        for sl, co, px in pics_q:
+    for pics_q, _, _, _, _ in sets:
+        for sl, co, px, v210 in pics_q:
             sl.free()
+            v210.free()
             [p.free() for p in co + px]
     samples = sum(h * w for h, w in dims)
     per = {k: ms / steps / npic for k, (ms, n) in prof.items() if n}
@@ -823,7 +855,18 @@ def lowdelay_8k(ctx, npic=4, steps=8):
                         "iiwt_3_levels": round(8 * samples / (max(iiwt, 1e-9) * 1e-3) / 1e9, 1)},
             "iiwt_frac_of_8TBs": round(8 * samples / (max(iiwt, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "compressed_MB_per_picture": round(data.size / 1e6, 1), "coefficient_MB_per_picture": round(4 * samples / 1e6, 1),
-            "sample_slices_vs_writer": "bit-exact" if ok else "MISMATCH"}
+            "sample_slices_vs_writer": "bit-exact" if ok else "MISMATCH",
+            # r05: with the v210 copy-out (what an application receives).  Fused: slices + DC + (three Haar levels with the copy-out
+            # as their epilogue); two passes: + the s32 pixel frame written, read back and packed
+            "ms_per_picture_with_copy_out": round(wall_fused / npic, 4),
+            "Mpix_per_s_with_copy_out": round(Wl * Hl * npic / wall_fused / 1e3, 1),
+            "ms_per_picture_two_passes_with_copy_out": round(wall_two / npic, 4),
+            "copy_out_kernels_ms_per_picture": {"pack_v210_from_the_pixel_frame": round(prof_pack.get("convert", (0, 0))[0] / steps / npic, 4),
+                                                "haar_3_levels_with_v210_epilogue": round(prof_fused.get("iiwt_finest", (0, 0))[0] / steps / npic, 4)},
+            "copy_out_alg_GBs": {"haar_3_levels_with_v210_epilogue":
+                                 round((4 * samples + 16 * (-(-Wl // 6)) * Hl) / (max(prof_fused.get("iiwt_finest", (0, 0))[0], 1e-9) / steps / npic * 1e-3) / 1e9, 1)},
+            "v210_MB_per_picture": round(16 * (-(-Wl // 6)) * Hl / 1e6, 1),
+            "fused_first_bytes_equal_two_passes": fused_equal}
 
 
 def frame_layer_2160p(npic=24):
@@ -832,7 +875,8 @@ def frame_layer_2160p(npic=24):
     x_upsample (2 references per 8 pictures) -> x_render_motion -> x_combine -- (i) under the reference's
     contract (one picture at a time, every stage call complete on return, host transform frames and vector
     arrays: schroasync-pthread.c:320-328) and (ii) as INTEGRATION.md 3a pipelines them (stage completion off,
-    pinned host frames, copy queues, three pictures in flight).  Both include the host hand-over (25 MB of
+    pinned host frames, copy queues, five pictures in flight) and (iii, r05) the same with the quantised hand-over
+    (schro_hipframe_dequantise: 17 % of the dense coefficient bytes cross the bus).  All include the host hand-over (25 MB of
     coefficients up, 12 MB of picture down per picture): compare with pcie_inclusive, not with `value`."""
     import subprocess
     import tempfile

@@ -307,6 +307,24 @@ int schro_hip_pack_u8_batch (SchroHipContext * ctx,
 int schro_hip_pack_v210_batch (SchroHipContext * ctx,
     const SchroHipPackPlane * planes, int nplanes, int src_bpp);
 
+/* r05 -- the inverse wavelet of an intra picture AND its v210 copy-out as one call (the reference's chain:
+ * x_wavelet_transform, schrodecoder.c:1855-1886, then schro_frame_convert (output_picture, frame) in x_combine, :2011-2052 ->
+ * schrovirtframe.c:1438-1537, :943-991).  dst receives exactly the bytes of schro_hip_iiwt_batch into a pixel frame followed by
+ * schro_hip_pack_v210_batch from it.  Where the transform is the three-level s32 Haar (filters 3, 4) of a 4:2:2 picture whose
+ * size is a multiple of 48 x 8 (BASELINE config 5: 7680 x 4320) the copy-out is the transform kernel's epilogue and the pixel
+ * frame never exists (per 8K picture 353 MB of memory traffic instead of 883 MB); every other case runs the two passes. */
+typedef struct {
+  const void *src[3];           /* the coefficient planes Y, U, V (device, s16 or s32), in-place sub-band layout */
+  int src_stride[3];
+  int width, height;            /* luma transform size (a multiple of 2^depth); chroma: >> h_shift, >> v_shift */
+  int h_shift, v_shift;         /* 1, 0: v210 is a 4:2:2 format and s16 / s32 frames are not resampled (as schro_hip_pack_v210_batch) */
+  uint8_t *dst;                 /* v210: 16 bytes per 6 pixels, dst_stride bytes per row */
+  int dst_stride;
+  int out_width, out_height;    /* the picture inside the transform's size */
+} SchroHipIwtPackPicture;
+int schro_hip_iiwt_pack_v210_batch (SchroHipContext * ctx, const SchroHipIwtPackPicture * pictures, int npictures, int depth,
+    int filter, int bytes_per_sample);
+
 /* The remaining packed destinations of schro_frame_convert (schroframe.c:886-895, 957-968),
  * chosen by `format` of each plane:
  *   SCHRO_HIP_FORMAT_v216  from a 4:2:2 source brought to s16; pack_v216
@@ -828,6 +846,12 @@ int schro_frame_inverse_iwt_transform_hip (SchroHipFrame * frame,
  * NULL for a picture without references (+ 128, :1788-1790).  The residual picture never exists in memory. */
 int schro_frame_inverse_iwt_transform_combine_hip (SchroHipFrame * output_frame, SchroHipFrame * transform_frame,
     SchroHipParams * params, SchroHipFrame * prediction);
+/* r05: the same for a picture WITHOUT references whose output picture is v210 (BASELINE config 5): x_wavelet_transform and
+ * the schro_frame_convert of x_combine (schrodecoder.c:2011-2052) in one call -- `packed` a device frame of format v210,
+ * transform_frame a device s16 / s32 4:2:2 frame; schro_hipframe_to_cpu (output_picture, packed) follows.  Same bytes as
+ * schro_frame_inverse_iwt_transform_hip + schro_hipframe_convert; the pixel frame is not written where
+ * schro_hip_iiwt_pack_v210_batch's fused kernel applies. */
+int schro_frame_inverse_iwt_transform_convert_hip (SchroHipFrame * packed, SchroHipFrame * transform_frame, SchroHipParams * params);
 
 /* schro_decoder_decode_lowdelay_transform_data (picture), schrolowdelay.c:746-762, with
  * picture->transform_frame on the device: `slices` is picture->lowdelay_buffer->data (host),

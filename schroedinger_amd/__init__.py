@@ -367,6 +367,23 @@ class Context:
             a.width, a.height, a.format = w, h, FORMAT_V210
         check(self.lib.schro_hip_pack_v210_batch(self.h, arr, n, bpp))
 
+    def iiwt_pack_v210_batch(self, jobs, depth, filt):
+        """r05: the inverse wavelet and the v210 copy-out in one call.  jobs: (coefficient planes [Y, U, V] DevicePlanes of one
+        dtype, h_shift, v_shift, dst DevicePlane of bytes, picture width, picture height) per picture."""
+        n = len(jobs)
+        arr = (_lib.IwtPackPicture * n)()
+        bpp = jobs[0][0][0].dtype.itemsize
+        for a, (planes, hs, vs, dst, w, h) in zip(arr, jobs):
+            for k in range(3):
+                assert planes[k].dtype.itemsize == bpp
+                a.src[k] = planes[k].ptr
+                a.src_stride[k] = planes[k].stride
+            a.width, a.height = planes[0].width, planes[0].height
+            a.h_shift, a.v_shift = hs, vs
+            a.dst, a.dst_stride = dst.ptr, dst.stride
+            a.out_width, a.out_height = w, h
+        check(self.lib.schro_hip_iiwt_pack_v210_batch(self.h, arr, n, depth, filt, bpp))
+
     def pack_wide_batch(self, jobs):
         """jobs: (planes [Y, U, V] DevicePlanes of one dtype, h_shift, v_shift, dst DevicePlane of
         bytes, width, height, format (FORMAT_V216 / FORMAT_ARGB / FORMAT_AY64)) per picture."""

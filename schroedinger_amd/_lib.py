@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_iiwt_batch", "schro_hip_convert_u8_batch", "schro_hip_upsample_batch",
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_upsampled_pair_bytes",
     "schro_hip_upsampled_pair_download", "schro_hip_pack_u8_batch",
-    "schro_hip_pack_v210_batch", "schro_hip_pack_wide_batch", "schro_hip_shift_right_batch",
+    "schro_hip_pack_v210_batch", "schro_hip_iiwt_pack_v210_batch", "schro_hip_pack_wide_batch", "schro_hip_shift_right_batch",
     "schro_hipframe_shift_right",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_obmc_batch", "schro_hip_obmc_prediction_epoch",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
-    "schro_frame_inverse_iwt_transform_hip", "schro_frame_inverse_iwt_transform_combine_hip", "schro_upsampled_hipframe_upsample",
+    "schro_frame_inverse_iwt_transform_hip", "schro_frame_inverse_iwt_transform_combine_hip", "schro_frame_inverse_iwt_transform_convert_hip", "schro_upsampled_hipframe_upsample",
     "schro_motion_render_hip", "schro_hipframe_convert",
 ]
 
@@ -70,6 +70,12 @@ class PackPlane(C.Structure):
                 ("src_h_shift", C.c_int), ("src_v_shift", C.c_int),
                 ("dst", C.c_void_p), ("dst_stride", C.c_int),
                 ("width", C.c_int), ("height", C.c_int), ("format", C.c_int)]
+
+
+class IwtPackPicture(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("src_stride", C.c_int * 3), ("width", C.c_int), ("height", C.c_int),
+                ("h_shift", C.c_int), ("v_shift", C.c_int), ("dst", C.c_void_p), ("dst_stride", C.c_int),
+                ("out_width", C.c_int), ("out_height", C.c_int)]
 
 
 class LowDelayParams(C.Structure):
@@ -334,6 +340,8 @@ def load():
     L.schro_hip_pack_u8_batch.restype = i
     L.schro_hip_pack_v210_batch.argtypes = [vp, C.POINTER(PackPlane), i, i]
     L.schro_hip_pack_v210_batch.restype = i
+    L.schro_hip_iiwt_pack_v210_batch.argtypes = [vp, C.POINTER(IwtPackPicture), i, i, i, i]
+    L.schro_hip_iiwt_pack_v210_batch.restype = i
     L.schro_hip_lowdelay_arith.argtypes = [C.POINTER(LowDelayParams), i]
     L.schro_hip_lowdelay_arith.restype = i
     L.schro_hip_lowdelay_batch.argtypes = [vp, C.POINTER(LowDelayPicture), i, C.POINTER(LowDelayParams), i]
@@ -378,6 +386,8 @@ def load():
     L.schro_frame_inverse_iwt_transform_combine_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
                                                                  C.POINTER(Params), C.POINTER(Frame)]
     L.schro_frame_inverse_iwt_transform_combine_hip.restype = i
+    L.schro_frame_inverse_iwt_transform_convert_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame), C.POINTER(Params)]
+    L.schro_frame_inverse_iwt_transform_convert_hip.restype = i
     L.schro_upsampled_hipframe_upsample.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
     L.schro_upsampled_hipframe_upsample.restype = i
     L.schro_motion_render_hip.argtypes = [C.POINTER(Motion), C.POINTER(Frame), C.POINTER(Frame), i,

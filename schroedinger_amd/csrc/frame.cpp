@@ -419,6 +419,39 @@ schro_frame_inverse_iwt_transform_combine_hip (SchroHipFrame * output_frame, Sch
   return inverse_iwt_transform (output_frame, transform_frame, params, prediction ? 1 : 2, prediction);
 }
 
+// r05 -- x_wavelet_transform and x_combine's schro_frame_convert into a v210 output picture in one call, for a picture
+// without references (schrodecoder.c:1855-1886 + :2011-2052; the > 8-bit shift of :2013-2019 is 0 when the stream's depth
+// is the output's): `packed` is a DEVICE frame of format v210, the transform frame a device s16 / s32 4:2:2 frame.  The
+// pixel frame (picture->frame) is not written where the fused kernel applies (schro_hip_iiwt_pack_v210_batch).
+int
+schro_frame_inverse_iwt_transform_convert_hip (SchroHipFrame * packed, SchroHipFrame * transform_frame, SchroHipParams * params)
+{
+  SCHRO_HIP_REQUIRE (packed && transform_frame && params && frame_ctx (packed) && transform_frame->domain == packed->domain,
+      "inverse_iwt_transform_convert: the packed frame and the transform frame must live in the same device domain");
+  SCHRO_HIP_REQUIRE (packed->format == SCHRO_HIP_FORMAT_v210, "inverse_iwt_transform_convert: the destination must be a v210 frame "
+      "(other formats: schro_frame_inverse_iwt_transform_hip + schro_hipframe_convert)");
+  SchroHipContext *ctx = frame_ctx (packed);
+  const int bpp = format_bpp (transform_frame->format);
+  SCHRO_HIP_REQUIRE (bpp == 2 || bpp == 4, "inverse_iwt_transform_convert: the transform frame must be s16 or s32");
+  SchroHipIwtPackPicture pic;
+  for (int k = 0; k < 3; k++) {
+    pic.src[k] = transform_frame->components[k].data;
+    pic.src_stride[k] = transform_frame->components[k].stride;
+  }
+  pic.width = params->iwt_luma_width;
+  pic.height = params->iwt_luma_height;
+  pic.h_shift = SCHRO_HIP_FORMAT_H_SHIFT (transform_frame->format);
+  pic.v_shift = SCHRO_HIP_FORMAT_V_SHIFT (transform_frame->format);
+  SCHRO_HIP_REQUIRE (pic.width <= transform_frame->components[0].width && pic.height <= transform_frame->components[0].height
+      && (params->iwt_chroma_width << pic.h_shift) == pic.width && (params->iwt_chroma_height << pic.v_shift) == pic.height,
+      "inverse_iwt_transform_convert: the frame is smaller than params' transform size (or the chroma size is not the luma size shifted)");
+  pic.dst = (uint8_t *) packed->components[0].data;
+  pic.dst_stride = packed->components[0].stride;
+  pic.out_width = packed->width;
+  pic.out_height = packed->height;
+  return stage_done (ctx, schro_hip_iiwt_pack_v210_batch (ctx, &pic, 1, params->transform_depth, params->wavelet_filter_index, bpp));
+}
+
 int
 schro_hip_decode_lowdelay_transform_data (SchroHipFrame * transform_frame, const void *slices,
     size_t slices_bytes, const SchroHipLowDelayParams * params)

@@ -93,6 +93,17 @@ struct IwtJob {
   int pad2;
 };
 
+// r05: the three-level s32 Haar transform of a 4:2:2 picture with the v210 copy-out as its epilogue (iiwt_haar.hip)
+struct HaarPackJob {
+  const void *src[3];           // the coefficient planes (Y, U, V), in-place sub-band layout
+  int src_stride[3];
+  int w, h;                     // luma transform size = picture size (chroma: w / 2 x h)
+  uint8_t *dst;                 // v210 rows: 16 bytes per 6 pixels
+  int dst_stride;
+  int tiles_x;                  // workgroups per strip of 8 rows
+  int tile_base;
+};
+
 struct ConvertJob {
   const void *src;
   uint8_t *dst;
@@ -441,6 +452,10 @@ int dc_gave_up (SchroHipContext * ctx);
 // (plane.cpp, beside the plan's other entry points; not part of the public header)
 extern "C" bool schro_hip_dequant_plan_matches (const SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes, int bpp, int arith);
 namespace schro {
+// iiwt_haar.hip, r05
+bool iiwt_haar3_v210_ok (const HaarPackJob & j);
+int iiwt_haar3_v210_strip_width ();
+int launch_iiwt_haar3_v210 (hipStream_t stream, const HaarPackJob * d_jobs, int njobs, int total_tiles, int filter);
 int launch_dequant (hipStream_t stream, const DequantJob * d_jobs, int njobs, int total_tiles, int bpp, int arith);
 int launch_dequant_plan (hipStream_t stream, const DequantGeo * d_geo, int njobs, int total_tiles,
     const SchroHipCodeblock * d_recs, const DequantPlaneDyn * d_planes, int bpp, int arith);

@@ -8,7 +8,7 @@
  *        x_combine (:1888-2118) -> schro_hipframe_to_cpu;
  *   (ii) INTEGRATION.md 3a: the same stage calls with stage completion OFF
  *        (schro_hip_context_set_stage_completion), frames that cross the boundary in the pinned host domain
- *        (schro_memory_domain_new_hip_host), three pictures in flight, each with its copies and stages in
+ *        (schro_memory_domain_new_hip_host), SLOTS pictures in flight, each with its copies and stages in
  *        order on a queue of its own; the host waits only for the download of the picture it hands on;
  *   (iii) r05 -- (ii) with the QUANTISED hand-over: what goes up per picture is not the dense
  *        transform frame but what a patched schro_decoder_decode_subband keeps (schrodecoder.c:3525-3640): the

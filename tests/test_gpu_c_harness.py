@@ -69,7 +69,7 @@ def test_c_caller_decodes_a_sequence_both_ways(tmp_path):
     """tests/c/stage_loop.c: a sequence of inter pictures through the frame layer (i) under the reference's
     contract -- one picture at a time, every stage call complete on return, host frames and vectors --,
     (ii) pipelined as INTEGRATION.md 3a describes (stage completion off, pinned host frames, copy queues,
-    three pictures in flight, marks), and (iii, r05) pipelined with the QUANTISED hand-over: codeblock records + a blob of
+    five pictures in flight, marks), and (iii, r05) pipelined with the QUANTISED hand-over: codeblock records + a blob of
     quantised values per picture through schro_hipframe_dequantise (schrodecoder.c:3525-3640's data-parallel half on the
     device).  The dense coefficient frames of (i) and (ii) are the quantised sets dequantised by the library: they must equal
     the oracle's dequantisation of the dumped records and values.  Every picture of the three passes equals the

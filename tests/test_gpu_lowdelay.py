@@ -297,10 +297,60 @@ def test_config5_whole_pixel_path_8k(ctx):
     ctx.pack_v210_batch([(px, 1, 0, v210, W, H)])
     got_px = [p.download() for p in px]
     got_v210 = v210.download()
-    for p in [d, v210] + co + px:
+    # r05 -- the fused route: the three Haar levels with the copy-out as their epilogue, no pixel frame
+    fused = ctx.plane(H, 16 * (-(-W // 6)), np.uint8).fill(0xa5)
+    ctx.iiwt_pack_v210_batch([(co, 1, 0, fused, W, H)], depth, filt)
+    got_fused = fused.download()
+    for p in [d, v210, fused] + co + px:
         p.free()
     want_co = decode_cpu(data, P, 4)
     want_px = [O.inverse_iwt(c, depth, filt) for c in want_co]
     for k in range(3):
         assert np.array_equal(got_px[k], want_px[k]), "component %d after the inverse wavelet" % k
-    assert np.array_equal(got_v210, O.pack_v210(want_px, 1, 0, W, H))
+    want_v210 = O.pack_v210(want_px, 1, 0, W, H)
+    assert np.array_equal(got_v210, want_v210), "two passes"
+    assert np.array_equal(got_fused, want_v210), "fused"
+
+
+@pytest.mark.parametrize("filt", [3, 4])
+def test_transform_and_v210_copy_out_in_one_call(ctx, filt):
+    """r05: schro_hip_iiwt_pack_v210_batch == schro_hip_iiwt_batch + schro_hip_pack_v210_batch == the oracle's chain, on the
+    fused kernel (s32 Haar, depth 3, 4:2:2, sizes that are multiples of 48 x 8: one strip piece, several, a partial last one;
+    full-range values: the s32 -> s16 truncation and the 10-bit clamp) and on the two-pass fallback (other sizes, depths,
+    filters, sample sizes, chroma formats, pictures smaller than the transform)."""
+    def run(w, h, depth, f, dtype, hs, vs, ow=None, oh=None, full=False, batch=1):
+        ow, oh = ow or w, oh or h
+        dims = [(h, w), (h >> vs, w >> hs), (h >> vs, w >> hs)]
+        jobs, wants, keep = [], [], []
+        for n in range(batch):
+            if full:
+                co = [synth.lcg(a * b, 7 + 3 * n + k).astype(np.int64).reshape(a, b) for k, (a, b) in enumerate(dims)]
+                co = [((c * 2654435761) % (1 << 20) - (1 << 19)).astype(dtype) for c in co]
+            else:
+                co = [O.forward_iwt((synth.image_s(a, b, dtype, seed=5 + 3 * n + k).astype(np.int64) * 3).astype(dtype), depth, f)
+                      for k, (a, b) in enumerate(dims)]
+            d_co = [ctx.upload(c) for c in co]
+            dst = ctx.plane(oh, 16 * (-(-ow // 6)), np.uint8).fill(0x3c)
+            jobs.append((d_co, hs, vs, dst, ow, oh))
+            px = [O.inverse_iwt(c, depth, f) for c in co]
+            wants.append(O.pack_v210([p[:(oh if k == 0 else -(-oh >> vs)), :(ow if k == 0 else -(-ow >> hs))] for k, p in enumerate(px)],
+                                     hs, vs, ow, oh))
+            keep += d_co + [dst]
+        ctx.iiwt_pack_v210_batch(jobs, depth, f)
+        for n, (j, want) in enumerate(zip(jobs, wants)):
+            assert np.array_equal(j[3].download(), want), (w, h, depth, f, np.dtype(dtype).name, hs, vs, ow, oh, n)
+        [p.free() for p in keep]
+    # the fused kernel
+    run(48, 8, 3, filt, np.int32, 1, 0)
+    run(960, 64, 3, filt, np.int32, 1, 0)
+    run(1920, 1080 // 8 * 8, 3, filt, np.int32, 1, 0, batch=2)         # two strip pieces per row, the second one partial... (1920 = 2 x 960)
+    run(1104, 72, 3, filt, np.int32, 1, 0, full=True)                   # 960 + 144: a partial piece; values beyond 16 bits
+    run(2064, 40, 3, filt, np.int32, 1, 0, batch=3)
+    # the two passes: not depth 3, s16, a width that is no multiple of 48, a picture inside the transform, another filter
+    run(96, 32, 2, filt, np.int32, 1, 0)
+    run(96, 32, 3, filt, np.int16, 1, 0)
+    run(64, 32, 3, filt, np.int32, 1, 0)
+    with pytest.raises(sa.SchroHipError, match="4:2:2"):
+        run(96, 32, 3, filt, np.int32, 1, 1)
+    run(96, 32, 3, filt, np.int32, 1, 0, ow=90, oh=30)
+    run(96, 32, 3, 1, np.int32, 1, 0)

@@ -184,6 +184,42 @@ def test_copy_out_of_deep_frames(ctx):
             dev.unref()
 
 
+@pytest.mark.parametrize("w,h,dtype,filt,depth", [(96, 48, np.int32, 3, 3), (1008, 40, np.int32, 3, 3), (96, 48, np.int16, 0, 2),
+                                                  (100, 36, np.int32, 4, 3)])
+def test_transform_and_copy_out_of_an_intra_picture_in_one_stage_call(ctx, w, h, dtype, filt, depth):
+    """r05: schro_frame_inverse_iwt_transform_convert_hip (packed, transform_frame, params) -- x_wavelet_transform and the
+    schro_frame_convert of x_combine for a picture without references and a v210 output picture (schrodecoder.c:1855-1886,
+    :2011-2052) -- equals the two stage calls and the oracle's chain; on the fused kernel (s32 Haar, depth 3, multiples of
+    48 x 8) and on the two-pass route (everything else, incl. a picture smaller than the padded transform)."""
+    lib = ctx.lib
+    iw, ih = -(-w // (1 << depth)) * (1 << depth), -(-h // (1 << depth)) * (1 << depth)
+    icw, ich = -(-(-(-w // 2)) // (1 << depth)) * (1 << depth), ih
+    if (icw << 1) != iw:        # (keep the chroma transform size = the luma size shifted: what the entry asks for)
+        iw = icw << 1
+    dims_t = [(ih, iw), (ich, icw), (ich, icw)]
+    co = [O.forward_iwt((synth.image_s(a, b, dtype, seed=11 + k).astype(np.int64) * 5).astype(dtype), depth, filt) for k, (a, b) in enumerate(dims_t)]
+    params = frames.make_params(wavelet_filter_index=filt, transform_depth=depth, iwt_luma_width=iw, iwt_luma_height=ih,
+                                iwt_chroma_width=icw, iwt_chroma_height=ich, num_refs=0)
+    fmt = frames.frame_format(dtype, 1, 0)
+    tf = frames.DeviceFrame(ctx, fmt, iw, ih).upload(frames.HostFrame(co, 1, 0))
+    px = [O.inverse_iwt(c, depth, filt) for c in co]
+    want = O.pack_v210([px[0][:h, :w], px[1][:h, :-(-w // 2)], px[2][:h, :-(-w // 2)]], 1, 0, w, h)
+    out = frames.DeviceFrame(ctx, 0x106, w, h)
+    sa.check(lib.schro_frame_inverse_iwt_transform_convert_hip(out.ptr(), tf.ptr(), C.byref(params)))
+    assert np.array_equal(out.download(), want)
+    # the two stage calls it replaces
+    frame = frames.DeviceFrame(ctx, fmt, w, h) if (w, h) == (iw, ih) else None
+    if frame is not None:
+        out2 = frames.DeviceFrame(ctx, 0x106, w, h)
+        sa.check(lib.schro_frame_inverse_iwt_transform_hip(frame.ptr(), tf.ptr(), C.byref(params)))
+        sa.check(lib.schro_hipframe_convert(out2.ptr(), frame.ptr()))
+        assert np.array_equal(out2.download(), want)
+        frame.unref()
+        out2.unref()
+    out.unref()
+    tf.unref()
+
+
 @pytest.mark.parametrize("hs,vs,prec", [(1, 1, 2), (1, 0, 1), (0, 0, 0), (1, 1, 3)])
 def test_zero_residual_picture_has_no_frame_to_add(ctx, hs, vs, prec):
     """schrodecoder.c:1800, :1861, :1904-1906: a zero_residual picture runs no wavelet stage and its GPU paths
