@@ -350,7 +350,10 @@ def test_transform_and_v210_copy_out_in_one_call(ctx, filt):
     run(96, 32, 2, filt, np.int32, 1, 0)
     run(96, 32, 3, filt, np.int16, 1, 0)
     run(64, 32, 3, filt, np.int32, 1, 0)
+    co = [ctx.plane(32, 96, np.int32), ctx.plane(16, 48, np.int32), ctx.plane(16, 48, np.int32)]
+    dst = ctx.plane(32, 16 * 16, np.uint8)
     with pytest.raises(sa.SchroHipError, match="4:2:2"):
-        run(96, 32, 3, filt, np.int32, 1, 1)
+        ctx.iiwt_pack_v210_batch([(co, 1, 1, dst, 96, 32)], 3, filt)
+    [p.free() for p in co + [dst]]
     run(96, 32, 3, filt, np.int32, 1, 0, ow=90, oh=30)
     run(96, 32, 3, 1, np.int32, 1, 0)
