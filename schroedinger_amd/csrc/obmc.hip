@@ -920,8 +920,9 @@ obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y)
   (void) xoff;
   if (variant >= 1) {
     const int tw = variant >= 3 ? obmc_row_tile_width (variant == 4) : kFTW;
+    const int th = variant >= 3 ? obmc_row_tile_height () : kFTH;
     *tiles_x = (w + tw - 1) / tw;
-    *tiles_y = (h + kFTH - 1) / kFTH;
+    *tiles_y = (h + th - 1) / th;
   } else {
     *tiles_x = (w + kTW - 1) / kTW;
     *tiles_y = (h + kTH - 1) / kTH;

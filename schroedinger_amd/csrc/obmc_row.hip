@@ -40,7 +40,10 @@ namespace schro {
 namespace {
 
 constexpr int kRThreads = 256;
-constexpr int kRTH = 32;                // output tile height: obmc_tiles (variant >= 1); the kernels take it as TH
+#ifndef SCHRO_ROW_TH
+#define SCHRO_ROW_TH 32
+#endif
+constexpr int kRTH = SCHRO_ROW_TH;      // output tile height: obmc_tiles (variants 3, 4); the kernels take it as TH
 // What depends on the row length (ND dwords of prediction per block row) and on the form of the job:
 //   UV = false: one plane (or the U and the V plane one after the other, NP == 2); a prediction byte is a pixel,
 //     an accumulator word holds two pixels; the tile is 128 pixels wide;
@@ -52,16 +55,20 @@ template < int ND, bool UV > struct RowGeo {
   // accumulator pixels in front of the tile (+ 1 when block origins are odd): a block starts at most
   // xblen - 1 pixels in front of it.  Rows of 8 pixels and shorter (ND <= 2: 8/4 block sets, chroma planes on
   // their own; UV: at most 8 pixels = 16 bytes): 8, else 16.
-  static constexpr int kMargin = (UV || ND <= 2) ? 8 : 16;
-  // accumulator row in 32-bit words: (17 + 128 + 16) / 2 -> 81, (9 + 128 + 8) / 2 -> 73, UV 8 + 64 + 8 = 80 --
+  // r05, UV rows of up to 6 pixels (ND <= 3): 5 -- with 73 + 2 words a tile's tables fit an EIGHTH of a CU's LDS
+  static constexpr int kMargin = UV ? (ND <= 3 ? 5 : 8) : (ND <= 2 ? 8 : 16);
+  // accumulator row in 32-bit words: (17 + 128 + 16) / 2 -> 81, (9 + 128 + 8) / 2 -> 73, UV 8 + 64 + 8 = 80 (r05, rows of up to 6 pixels: 5 + 64 + 5 = 74) --
   // made ODD: the lanes of a pass are rows of blocks whose origins are multiples of 4 words apart, so with
   // the r02 pitch of 84 every address of an accumulate had the same word index mod 4 and 64 lanes met in 8
   // of the 32 banks (7.2 extra cycles per ds_add, simulated; 2.3 with 85)
-  static constexpr int kAccW = UV ? 81 : (ND <= 2 ? 73 : 85);
+  static constexpr int kAccW = UV ? (ND <= 3 ? 75 : 81) : (ND <= 2 ? 73 : 85);
   // blocks whose footprint meets a tile and their (block, row) items (8-pixel rows and shorter are the
   // small, many blocks of chroma planes and of the 8/4 block set; a 64-pixel UV tile of 6 x 6 blocks
   // every 4 pixels meets 18 x 10 of them)
-  static constexpr int kBlk = ND <= 2 ? 344 : (UV ? 192 : 128), kItem = ND <= 2 ? 1792 : (UV ? 1152 : 1024);
+  // (for a tile of kRTH rows: the caps grow with the tile's height)
+  // (UV, 6 x 6 blocks every 4 pixels: 18 x 10 blocks meet a 64 x 32 tile, 18 x 52 of their rows)
+  static constexpr int kBlk = ND <= 2 ? 344 : (UV ? (ND == 3 ? 180 : 192) : 128) * kRTH / 32,
+      kItem = ND <= 2 ? 1792 : (UV ? (ND == 3 ? 960 : 1152) : 1024) * kRTH / 32;
   // (row, pixel pair | UV: pixel) weight words: 2 * ND per row (zero beyond the block), 32 rows
   static constexpr int kWCap = 32 * 2 * ND;
   static constexpr bool kPadBlk = UV || ND > 2;        // block records of nine words (see RowBlkT)
@@ -1091,8 +1098,19 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 // The 12-pixel-row kernel takes 69 registers: seven waves per SIMD at 19.8 KB of LDS; the
 // 6-pixel-row kernels (chroma planes on their own: 344 blocks, a 73-word accumulator pitch) run five
 // or six workgroups per CU; the UV kernels are the 12-byte-row kernel on 64-pixel tiles.
+// r05: the prediction-only (U, V) kernel of 6-pixel rows at EIGHT workgroups per CU as well: its tables were trimmed to
+// 20 464 B (accumulator margin 5 and pitch 75, 180 blocks, 960 items: what 6 x 6 blocks every 4 pixels need) and the
+// compiler keeps it to 78 SGPRs at this occupancy (12 of them parked in VGPR lanes).  OBMC per 8 x 2160p step 0.1662 -> 0.1639 ms.
+#ifndef SCHRO_ROW_UV_WAVES
+#define SCHRO_ROW_UV_WAVES 8
+#endif
+#ifdef SCHRO_ROW_UV_SGPR
+#define SCHRO_ROW_SGPR_ATTR(name) __attribute__ ((amdgpu_num_sgpr (sizeof (#name) == sizeof ("obmc_row_kernel_p_uv_3") ? SCHRO_ROW_UV_SGPR : 102)))
+#else
+#define SCHRO_ROW_SGPR_ATTR(name)
+#endif
 #define SCHRO_ROW_KERNEL(name, waves, ...) \
-__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (waves, waves))) \
+__global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (waves, waves))) SCHRO_ROW_SGPR_ATTR (name) \
 void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow) \
 { \
   obmc_row_body < __VA_ARGS__ > (jobs, njobs, order, overflow); \
@@ -1119,7 +1137,7 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_p_2_1, 6, 2, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_3_1, SCHRO_ROW_PRED_WAVES, 3, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_4_1, 4, 4, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_2, 5, 2, 1, true, kRTH, true)
-SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, 7, 3, 1, true, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, SCHRO_ROW_UV_WAVES, 3, 1, true, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_4, 4, 4, 1, true, kRTH, true)
 #undef SCHRO_ROW_KERNEL
 
@@ -1195,6 +1213,12 @@ obmc_row_nd (const ObmcJob & j, bool uv)
   if (nbi * nbj > blk_cap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > item_cap)
     return 0;
   return nd;
+}
+
+int
+obmc_row_tile_height ()
+{
+  return kRTH;
 }
 
 // the row kernels' tile width (obmc_tiles): 128 pixels, (U, V) pairs 64

@@ -469,6 +469,7 @@ int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
 int obmc_row_nd (const ObmcJob & job, bool uv);
 int obmc_row_tile_width (bool uv);
+int obmc_row_tile_height ();
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
     int max_planes, const uint32_t * d_order, uint32_t * overflow);
 // fills the item-kernel geometry fields of a job (obmc.hip)
