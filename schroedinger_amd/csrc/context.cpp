@@ -1,6 +1,6 @@
 // context.cpp -- the C ABI of libschro_hip.so (include/schro_hip.h), first part: errors, the context and its
 // memory domain (SchroMemoryDomain-shaped), queues / marks / copies, job-table caches, per-launch profiling.
-// (r04: api.cpp split by layer -- context.cpp, plane.cpp: the batched plane-level launches, frame.cpp: the
+// (r04: api.cpp split by layer -- context.cpp, plane.cpp (r05: plane_iiwt / _frameops / _lowdelay / _obmc.cpp): the batched plane-level launches, frame.cpp: the
 // SchroFrame-shaped stage boundary.)  Host logic only; the kernels are in the .hip files.
 
 #include "schro_hip_internal.h"

@@ -1,7 +1,7 @@
 // frame.cpp -- the C ABI of libschro_hip.so (include/schro_hip.h), third part: the frame layer -- the reference's
 // own objects (SchroFrame / SchroParams / SchroMotion-shaped) and the stage calls a patched schrodecoder.c makes
 // (schro_frame_inverse_iwt_transform_hip, schro_upsampled_hipframe_upsample, schro_motion_render_hip,
-// schro_hipframe_convert ...), built on the plane layer (plane.cpp).
+// schro_hipframe_convert ...), built on the plane layer (plane_*.cpp, iiwt_pack.cpp).
 
 #include "schro_hip_internal.h"
 

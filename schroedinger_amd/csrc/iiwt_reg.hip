@@ -58,7 +58,7 @@ namespace {
 // of the SAME launch, possibly on another XCD (each XCD has its own L2).  The STORES are agent-scope atomics
 // (relaxed: global_store ... sc1, written through to the memory side); the loads are ordinary: a consumer reads
 // a line of an LL image only after the whole producer tile rows that hold it have counted themselves done --
-// the images' rows are whole 128-byte lines (plane.cpp) -- so no cache of its XCD can hold an older copy from
+// the images' rows are whole 128-byte lines (plane_iiwt.cpp) -- so no cache of its XCD can hold an older copy from
 // this launch, and every launch starts with clean caches.
 // (Loads as agent-scope atomics too -- no argument needed -- cost the transform of 8 x 2160p 0.03 ms.)
 

@@ -449,7 +449,7 @@ int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsi
 // non-zero (the launch's epoch) once a dc_skew_kernel strip has given up waiting: reported by the next call
 int dc_gave_up (SchroHipContext * ctx);
 }
-// (plane.cpp, beside the plan's other entry points; not part of the public header)
+// (plane_lowdelay.cpp, beside the plan's other entry points; not part of the public header)
 extern "C" bool schro_hip_dequant_plan_matches (const SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes, int bpp, int arith);
 namespace schro {
 // iiwt_haar.hip, r05
@@ -524,7 +524,7 @@ struct SchroHipContext {
     bool copy_pending;
   };
   static constexpr int kArgSlots = 256;        // kArgSlots / kQueues per queue
-  static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in plane.cpp)
+  static constexpr size_t kArgSlotBytes = 64u << 10;   // >= kMaxJobs OBMC jobs (static_assert in plane_obmc.cpp)
   char *h_args;                 // kArgSlots pinned mirrors
   char *d_args;
   ArgSlot arg_slots[kArgSlots];
@@ -539,7 +539,7 @@ struct SchroHipContext {
   std::vector < EvPair > ev_pool;
   size_t ev_used;
 
-  // OBMC tile orders (plane.cpp obmc_tile_order): device tables of job << 16 | tile, cached by
+  // OBMC tile orders (plane_obmc.cpp obmc_tile_order): device tables of job << 16 | tile, cached by
   // the geometry and references of the launch they were built for
   struct OrderSlot {
     uint64_t hash;
@@ -553,7 +553,7 @@ struct SchroHipContext {
   static constexpr int kOrderSlots = 16;        // kOrderSlots / kQueues per queue
   OrderSlot order_slots[kOrderSlots];
 
-  // the register wavelet's chain form (plane.cpp iiwt_chain): tile orders cached by the batch's geometry, and per
+  // the register wavelet's chain form (plane_iiwt.cpp iiwt_chain): tile orders cached by the batch's geometry, and per
   // queue the ticket + counters its launches synchronise through (left zero by every launch)
   struct ChainSlot {
     uint64_t hash;
@@ -619,7 +619,7 @@ int big_table_commit (SchroHipContext * ctx, size_t bytes);
 // rows of row_bytes bytes, host <-> device or device -> device, enqueued on the selected queue (context.cpp)
 int copy_2d_async (SchroHipContext * ctx, void *dst, int dst_stride, const void *src, int src_stride, int row_bytes,
     int height, hipMemcpyKind kind);
-// v216 / ARGB / AY64 (plane.cpp)
+// v216 / ARGB / AY64 (plane_frameops.cpp)
 bool is_wide_format (int format);
 // the launches made while a scope is open are timed under its kernel class (when profiling is on)
 struct ProfileScope {
