@@ -274,9 +274,10 @@ namespace schro {
 // chains with it): same format, size and layout -- plain or upsampled --, one
 // hipMemcpyPeerAsync per component on the destination context's host-to-device COPY queue, behind
 // `wait_for` (the owner's event: all the work that writes `src`); `done` is recorded behind the copies
-// and the destination's kernel queues wait for it.  This function waits for nothing itself (r04) -- but on
-// ROCm 7.2 an asynchronous copy enqueued behind an event that has not fired returns only when it has,
-// so with an unfired `wait_for` the CALLER sits inside hipMemcpyPeerAsync until the producer's work is done.
+// and the destination's kernel queues wait for it.  Nothing is waited for on the host (r04).  (ROCm 7.2 holds the
+// caller of an asynchronous copy from / to pinned HOST memory behind an unfired event; this PEER copy
+// measured 22 us in the call with 7 ms of producer work outstanding -- two contexts on one device,
+// profiles/r05_peer_copy_hip_trace.txt; between two real devices unmeasured.)
 SchroHipFrame *
 frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done)
 {

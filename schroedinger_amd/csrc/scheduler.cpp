@@ -31,11 +31,13 @@
 // queues, a picture on another device makes its copy queue WAIT for the event (hipStreamWaitEvent), issues
 // the peer copy asynchronously and makes its kernel queues wait for the copy -- the scheduler itself waits
 // for no device on the path, so a device can have any number of reference pictures in flight
-// (refs_in_flight_max counts them from events of its own).  One caveat, measured in r04: on ROCm 7.2 an
-// asynchronous copy enqueued behind an event that has not fired returns to its caller only when the event
-// has, so the worker of the device that NEEDS a foreign frame can sit inside the peer-copy call for the rest
-// of the producer's picture (it would run its pictures in coded order anyway; no other device's worker is
-// held).  r03 drained the whole device after every reference picture and copied synchronously (the
+// (refs_in_flight_max counts them from events of its own).  One caveat: on ROCm 7.2 an asynchronous copy
+// from / to pinned HOST memory enqueued behind an event that has not fired returns to its caller only when the
+// event has.  The PEER copy of a reference does not: measured under rocprofv3 --hip-trace with two contexts on one
+// device, the worker spends 22 us in hipMemcpyPeerAsync while 7 ms of the producer's work are outstanding
+// (profiles/r05_peer_copy_hip_trace.txt; a copy between two real devices is unmeasured -- were it to hold the
+// caller, it would hold the worker of the device that NEEDS the frame, which runs its pictures in coded order
+// anyway).  r03 drained the whole device after every reference picture and copied synchronously (the
 // reference's precedent: schrogpuframe.c:480-609).
 // r05: (1) after `ready` is recorded on queue 0 the context's second kernel queue waits for it as
 // well, and every picture function starts with queue 0 selected -- so a dependent on the same device follows
@@ -72,8 +74,8 @@ namespace schro {
 // context.cpp: queue 0 of the context waits for its other queues, then `ev` is recorded on it
 int context_join_queues (SchroHipContext * ctx, hipEvent_t ev);
 // frame.cpp: a copy of `src` on dst_ctx's device, enqueued on its host-to-device copy queue behind `wait_for`;
-// `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  No explicit wait (the runtime may hold
-// the caller inside the copy call until `wait_for` has fired: see the note on r04 above).
+// `done` is recorded behind the copy and dst_ctx's kernel queues wait for it.  Nothing is waited for (measured: 22 us
+// in the call behind an unfired `wait_for`, see the note on r04 above).
 SchroHipFrame *frame_copy_to_async (SchroHipContext * dst_ctx, SchroHipFrame * src, hipEvent_t wait_for, hipEvent_t done);
 // context.cpp: a context that does not become the calling thread's domain
 SchroHipContext *context_new_unbound (int device);
@@ -291,8 +293,7 @@ worker (SchroHipScheduler * s, int index)
       if (s->virtual_devices) {
         m.moved = m.frame;
       } else {
-        // the copy waits for the owner's `ready` on this device's copy queue (no explicit host wait; the runtime may
-        // keep this thread inside the copy call until the event has fired)
+        // the copy waits for the owner's `ready` on this device's copy queue; this thread does not (measured, see above)
         if (hipEventCreateWithFlags (&m.done, hipEventDisableTiming) != hipSuccess)
           m.done = nullptr;
         m.moved = m.done ? schro::frame_copy_to_async (d.ctx, (SchroHipFrame *) m.frame, m.ready, m.done) : nullptr;
