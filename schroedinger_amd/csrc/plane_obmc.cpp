@@ -463,6 +463,39 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       tile_base += j.tiles_x * tiles_y;
       jobs.push_back (j);
     }
+    // r05, experiments build only (SCHRO_HIP_OBMC_STRIP=1): the 12 / 8 block set on one-byte planes by the strip kernel,
+    // accumulator in registers (obmc_strip.hip: bit-exact, 2.5 x slower -- the gather's lines from L2 are the bound, not the
+    // LDS tile); its waves take strips of 15 block columns x segments of 8 block rows
+#ifndef SCHRO_OBMC_STRIP
+#define SCHRO_OBMC_STRIP 0
+#endif
+#ifndef SCHRO_OBMC_STRIP_SEG
+#define SCHRO_OBMC_STRIP_SEG 8
+#endif
+    static const bool use_strip = SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP")) != 0 : SCHRO_OBMC_STRIP != 0;
+    bool strip = use_strip && row && !paired && !uv && nd == 3;
+    for (size_t k = 0; strip && k < jobs.size (); k++)
+      strip = obmc_strip_ok (jobs[k]);
+    if (strip) {
+      const int seg_rows = SCHRO_OBMC_STRIP_SEG;
+      int wave_base = 0;
+      for (ObmcJob & j : jobs) {
+        int strips, segs;
+        obmc_strip_tiles (j, seg_rows, &strips, &segs);
+        j.tiles_x = strips;
+        j.tile_base = wave_base;
+        wave_base += strips * segs;
+      }
+      void *d_sjobs;
+      int rs = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_sjobs);
+      if (rs)
+        return rs;
+      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
+      rs = launch_obmc_strip (ctx->stream, (const ObmcJob *) d_sjobs, (int) jobs.size (), wave_base, seg_rows, pred_only, overflow, ctx->cus);
+      if (rs)
+        return rs;
+      continue;
+    }
     void *d_jobs;
     int r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
     if (r)

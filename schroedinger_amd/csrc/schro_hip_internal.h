@@ -468,6 +468,11 @@ int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order, uint32_t * overflow);
 // row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
 int obmc_row_nd (const ObmcJob & job, bool uv);
+// obmc_strip.hip (r05): the register-accumulator form for the 12 / 8 block set
+bool obmc_strip_ok (const ObmcJob & j);
+void obmc_strip_tiles (const ObmcJob & j, int seg_rows, int *strips, int *segs);
+int launch_obmc_strip (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_items, int seg_rows, bool nores, uint32_t * overflow,
+    int cus);
 int obmc_row_tile_width (bool uv);
 int obmc_row_tile_height ();
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,

@@ -8,7 +8,7 @@ mkdir -p ../../build/v_$name
 for f in context.cpp plane_iiwt.cpp plane_frameops.cpp plane_lowdelay.cpp plane_obmc.cpp iiwt_pack.cpp frame.cpp scheduler.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. "$@" -x hip -c $f -o ../../build/v_$name/${f%.*}.o &
 done
-for f in iiwt.hip iiwt_reg.hip iiwt_haar.hip frameops.hip obmc.hip obmc_row.hip lowdelay.hip dequant.hip; do
+for f in iiwt.hip iiwt_reg.hip iiwt_haar.hip frameops.hip obmc.hip obmc_row.hip obmc_strip.hip lowdelay.hip dequant.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. "$@" -c $f -o ../../build/v_$name/${f%.*}.o &
 done
 for j in $(jobs -p); do wait $j || { echo "build_variant: compile failed"; exit 1; }; done

@@ -11,7 +11,9 @@ with the same oracle on the whole case matrix of its test file:
     slice_run_kernel, dc_predict_kernel instead of dc_skew_kernel) -- in the product library those switches are inert;
   * SCHRO_HIP_OBMC_KERNEL=item: obmc.hip's item kernel for every default-weight case (also out of pair images);
   * SCHRO_HIP_OBMC_MERGE=2: U + V planes of one-component images as one job (obmc_row_kernel_*_2) always;
-  * SCHRO_HIP_IIWT_CHAIN=1: every level of the register wavelet in one launch (r04, iiwt_reg.hip).
+  * SCHRO_HIP_IIWT_CHAIN=1: every level of the register wavelet in one launch (r04, iiwt_reg.hip);
+  * SCHRO_HIP_OBMC_STRIP=1: the 12 / 8 block set's luma planes by the strip kernel (r05, obmc_strip.hip: accumulator in
+    registers, no LDS tile -- a third formulation of the same arithmetic; measured 2.5 x slower).
 """
 import os
 import subprocess
@@ -52,4 +54,9 @@ def test_u_and_v_planes_always_one_job():
 
 def test_register_wavelet_chain_form():
     out = run(["test_gpu_iiwt.py", "test_gpu_stream.py", "test_gpu_fuzz.py"], env={"SCHRO_HIP_IIWT_CHAIN": "1"})
+    assert "passed" in out
+
+
+def test_strip_kernel_takes_the_12_8_luma_planes():
+    out = run(["test_gpu_obmc.py", "test_gpu_combine.py", "test_gpu_stream.py", "test_gpu_fuzz.py"], env={"SCHRO_HIP_OBMC_STRIP": "1"})
     assert "passed" in out
