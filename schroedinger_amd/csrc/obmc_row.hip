@@ -739,8 +739,14 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const uint32_t entry = order ? order[bid] : 0u;        // (a uniform address: a scalar load)
   const ObmcJob job = jobs[order ? (int) (entry >> 16) : find_job (jobs, njobs, bid)];
   // scratch runs (SCHRO_HIP_OBMC_STAMPS): cycles since the workgroup started, per phase
+  // (r05: experiments build only -- each stamp is a handful of scalar instructions and a branch in EVERY wave: OBMC per
+  // 8 x 2160p step 0.1640 -> 0.1616 ms without them)
+#ifdef SCHRO_HIP_EXPERIMENTS
 #define RSTAMP(n) do { if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) \
     job.stamps[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime () - t_start; } while (0)
+#else
+#define RSTAMP(n) do { } while (0)
+#endif
   RSTAMP (7);                   // (the job is here)
   const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
   const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
@@ -790,6 +796,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       mv_pre[2] = gload < uint32_t > (mvp + 16);
     }
     RSTAMP (10);                // (accumulator cleared, ramps, the vectors asked for)
+    // (r05, measured slower: the vectors asked for first and the weight tables made from weight_1d in front of this ONE
+    // barrier, the ramps' round trip through LDS and the phase behind the barrier gone -- 0.1655 against 0.1611 ms per step)
     __syncthreads ();           // ramps, counters
     RSTAMP (8);
     // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
@@ -1082,12 +1090,16 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
   }
   RSTAMP (9);
+#ifdef SCHRO_HIP_EXPERIMENTS
   if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) {   // absolute start / end, where it ran
     job.stamps[blockIdx.x * 16 + 12] = t_start;
     job.stamps[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime ();
     job.stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg ((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
     job.stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg ((20 << 0) | (0 << 6) | (31 << 11));     // XCC_ID
   }
+#else
+  (void) t_start;
+#endif
 #undef RSTAMP
 }
 

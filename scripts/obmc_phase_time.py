@@ -39,6 +39,12 @@ def main():
             mode = mv["flags"] & 3
             if kind == "const":
                 vec = np.tile(np.array([5, -7, 3, 9], np.int16), (mv.shape[0], 1))
+            elif kind == "zero":        # every window right behind its block, one tap: the most line sharing there is
+                vec = np.zeros((mv.shape[0], 4), np.int16)
+            elif kind == "even":        # the bench's independent vectors rounded to half-pel positions of even parity: one tap each
+                vec = (mv["v"] & ~np.int16(3)).astype(np.int16)
+            elif kind == "odd":         # ... and with every tap needed (all four quarter-pel taps of both references)
+                vec = (mv["v"] | np.int16(1)).astype(np.int16)
             else:           # a pan + a slow zoom, +-1 quarter pel of noise
                 yy, xx = np.divmod(np.arange(nbx * nby), nbx)
                 n = synth.lcg(4 * nbx * nby, 77 + f).reshape(4, -1) % 3 - 1
@@ -47,7 +53,7 @@ def main():
             mv["v"] = np.where((mode == 0)[:, None], mv["v"], vec)
             d_mv = ctx.upload_bytes(mv)
             for k in range(3):
-                jobs.append(sa.obmc_plane(d_mv, wl.P, k, b.hp[0][k], b.hp[1][k], b.iwt_pairs[3 * f + k][1], b.out[f][k]))
+                jobs.append(sa.obmc_plane(d_mv, wl.P, k, b.hp[0][0][k], b.hp[0][1][k], None, b.iwt_combine[3 * f + k][2], prediction_only=True))
     which = os.environ.get("PLANES", "luma,chroma").split(",")
     sets = (("luma", [j for i, j in enumerate(jobs) if i % 3 == 0]), ("chroma", [j for i, j in enumerate(jobs) if i % 3]))
     for name, sel in sets:
@@ -60,7 +66,7 @@ def main():
         for _ in range(20):
             ctx.obmc_batch(sel)
         ctx.synchronize()
-        print(kind, name, "%.4f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+        print(kind, name, "%.4f ms" % ((time.perf_counter() - t0) / 20 * 1e3), flush=True)
     sa._lib.load().schro_hip_obmc_stamps_dump()
 
 
