@@ -38,16 +38,15 @@
 // MEASURED (r05, 8 x 2160p luma, prediction only): bit-exact on every test of tests/test_gpu_obmc.py / _combine / _fuzz /
 // _stream -- and 2.5 x SLOWER than the row kernel: 0.25 - 0.27 ms per launch against 0.105 (one item per wave, 8 waves per
 // SIMD, 8976 waves on 8192 slots: 0.286; items dealt statically, both references' loads in flight, the next block's
-// vectors prefetched: 0.25 at 5 waves per SIMD, 0.27 at 6).  Why, and what it says about the row kernel's bound: a step
-// covers FOUR rows of a window -- 1.75 lines of 128 bytes per tap plane where the row kernel's twelve consecutive lanes
-// touch 3.75 per twelve rows (x 1.4) --, every lane loads all eight taps (x 2.7 against the 2.9 taps a block needs on
-// average; a tap a block does not use repeats the first tap's address, but the repeat is issued before the first has
-// landed and goes to L2 as well), and a wave's step reads ~170 lines = 21 KB: with 20 - 32 waves per CU nothing survives
-// in the 32 KB L1.  The launch moves ~3 x the row kernel's lines from L2 and takes 2.5 x its time: the row kernel's
-// 12.3 M lines per luma launch in 0.105 ms (14 TB/s) ARE its bound -- the rate at which an MI355X's L2 hands lines to
-// the L1s of gathering CUs (MI355X_MICROARCH.md: 16.8 - 18.8 TB/s for an L2-resident table) --, not instruction issue,
-// not occupancy, not the LDS tile.  With the unused taps masked off the form would still move 1.4 x the lines.  It stays
-// in the experiments build (SCHRO_HIP_OBMC_STRIP=1) as the third formulation the parity tests can compare.
+// vectors prefetched: 0.25 at 5 waves per SIMD, 0.27 at 6).  Why: a step covers FOUR rows of a window -- 1.75 lines of 128
+// bytes per tap plane where the row kernel's twelve consecutive lanes touch 3.75 per twelve rows (x 1.4) --, every lane
+// loads all eight taps (x 2.7 against the 2.9 taps a block needs on average; a tap a block does not use repeats the first
+// tap's address, but the repeat is issued before the first has landed and goes to L2 as well), and a wave's step reads
+// ~170 lines = 21 KB: with 20 - 32 waves per CU nothing survives in the 32 KB L1.  The launch moves ~3 x the row kernel's
+// lines from L2 and every step is a full memory round trip with ~165 vector instructions behind it.  (The row kernel itself is
+// NOT bound by its lines: with every window on one tap its luma launch takes 0.088 ms whether the windows share lines or
+// not, HISTORY.md section 8.)  With the unused taps masked off this form would still move 1.4 x the lines.  It stays in the
+// experiments build (SCHRO_HIP_OBMC_STRIP=1) as the third formulation the parity tests can compare.
 
 #include "schro_hip_internal.h"
 #include "obmc_common.h"
