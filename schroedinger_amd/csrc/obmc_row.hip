@@ -797,22 +797,26 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
     RSTAMP (10);                // (accumulator cleared, ramps, the vectors asked for)
     // (r05, measured slower: the vectors asked for first and the weight tables made from weight_1d in front of this ONE
-    // barrier, the ramps' round trip through LDS and the phase behind the barrier gone -- 0.1655 against 0.1611 ms per step)
+    // barrier, the ramps' round trip through LDS and the phase behind the barrier gone -- 0.1655 against 0.1611 ms per step;
+    // the tables made by the HOST, one per block geometry of a launch, and copied in by the tile: 0.1655 against 0.1616)
     __syncthreads ();           // ramps, counters
     RSTAMP (8);
-    // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
-    // 2 * ND words, zero beyond the block's width.  UV: a word per pixel, its weight for both components
-    for (int i = tid; i < yblen * 2 * ND && i < G::kWCap; i += kRThreads) {
-      const int r = i / (2 * ND), pr = i - r * (2 * ND);
-      if constexpr (UV)
-        s_wp[i] = pr < xblen ? (uint32_t) (s_wx[pr] * s_wy[r]) * 0x00010001u : 0u;
-      else
-        s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
-    }
-    // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
-    // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
-    // its first 2 * offset weights, the last one everything from the block step on
-    if (tid < 32 + 128) {
+    // r05: the tables are the work of the LAST two waves -- the decode below keeps the first two busy (108 blocks of a
+    // 128 x 32 tile of 12 / 8 blocks) and was waiting behind 2.2 k cycles of tables in exactly those waves
+    if (tid >= kRThreads / 2) {
+      const int t2 = tid - kRThreads / 2;
+      // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
+      // 2 * ND words, zero beyond the block's width.  UV: a word per pixel, its weight for both components
+      for (int i = t2; i < yblen * 2 * ND && i < G::kWCap; i += kRThreads / 2) {
+        const int r = i / (2 * ND), pr = i - r * (2 * ND);
+        if constexpr (UV)
+          s_wp[i] = pr < xblen ? (uint32_t) (s_wx[pr] * s_wy[r]) * 0x00010001u : 0u;
+        else
+          s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
+      }
+      // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
+      // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
+      // its first 2 * offset weights, the last one everything from the block step on
       auto folded = [](const int *w1, int idx, int blen, int bsep, int off, int type) {
         if (idx >= blen)
           return 0;
@@ -823,16 +827,18 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
           w += w1[2 * (blen - off) - idx - 1];
         return w;
       };
-      if (tid < 32) {
-        const int type = tid >> 3, pr = tid & 7;
-        if constexpr (UV)       // (rows of up to 8 pixels: 8 words per edge type, as for 16 pixels in pairs)
-          s_wp[G::kWCap + tid] = (uint32_t) folded (s_wx, pr, xblen, job.xbsep, job.xoff, type) * 0x00010001u;
-        else
-          s_wp[G::kWCap + tid] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
-              | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
-      } else {
-        const int type = (tid - 32) >> 5, r = (tid - 32) & 31;
-        s_wp[G::kWCap + tid] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
+      for (int k = t2; k < 32 + 128; k += kRThreads / 2) {
+        if (k < 32) {
+          const int type = k >> 3, pr = k & 7;
+          if constexpr (UV)       // (rows of up to 8 pixels: 8 words per edge type, as for 16 pixels in pairs)
+            s_wp[G::kWCap + k] = (uint32_t) folded (s_wx, pr, xblen, job.xbsep, job.xoff, type) * 0x00010001u;
+          else
+            s_wp[G::kWCap + k] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
+                | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
+        } else {
+          const int type = (k - 32) >> 5, r = (k - 32) & 31;
+          s_wp[G::kWCap + k] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
+        }
       }
     }
     RSTAMP (1);
@@ -945,13 +951,16 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   {
     const int lane = tid & 63;
     const int cnt = lane < kRSlots ? s_icnt[lane] : 0;
+    // (r05: the scan in the lanes' own data path -- row_shr 1, 2, 4, 8 inside rows of 16 lanes, then lane 15 broadcast
+    // into the row behind it: five additions where five __shfl_up were five LDS round trips and 45 instructions, in
+    // EVERY wave of a launch that is bound by its vector instructions)
+    static_assert (kRSlots <= 32, "the scan covers two rows of 16 lanes");
     int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      const int up = __shfl_up (incl, d);
-      if (lane >= d)
-        incl += up;
-    }
+    incl += __builtin_amdgcn_update_dpp (0, incl, 0x111, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp (0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp (0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp (0, incl, 0x118, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp (0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
     sbase = incl - cnt;
   }
   int ibase[kRRim + 1];         // first item of each class
@@ -967,8 +976,22 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       continue;
     const int rows = (int) s_hot[blk].fr, ra = rows & 0xff, n = (rows >> 8) & 0xff;
     uint16_t *ip = s_item + ib + (meta >> 5);
-    for (int r = 0; r < n; r++)
-      ip[r] = (uint16_t) (blk | ((ra + r) << 9));
+    // (r05: four items per write -- the compiler's own vectorisation of the plain loop cost 85 instructions for 12 rows;
+    // LDS takes the two-byte-aligned words as they come)
+    typedef uint32_t u32_a2 __attribute__ ((aligned (2), may_alias));
+    typedef u32x2 u32x2_a2 __attribute__ ((aligned (2), may_alias));
+    uint32_t pair = (uint32_t) (blk | (ra << 9)) * 0x00010001u + 0x02000000u;      // rows ra, ra + 1
+    int r = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (; r + 4 <= n; r += 4, pair += 0x08000800u)
+      *reinterpret_cast < u32x2_a2 * >(ip + r) = (u32x2) { pair, pair + 0x04000400u };
+    if (n & 2) {
+      *reinterpret_cast < u32_a2 * >(ip + r) = pair;
+      r += 2;
+      pair += 0x04000400u;
+    }
+    if (n & 1)
+      ip[r] = (uint16_t) pair;
   }
   const bool exact = __builtin_amdgcn_readfirstlane (s_wide) != 0;      // a DC value outside 0..255 in the tile: 16-bit sums may wrap
   const int nrim = __builtin_amdgcn_readfirstlane (s_nrim);

@@ -77,6 +77,14 @@ schro_hip_obmc_stamps_dump (void)
     fprintf (stderr, "stamp %d: median %llu  p10 %llu  p90 %llu  p99 %llu  max %llu  mean %llu  (n=%zu)\n", n, v[v.size () / 2],
         v[v.size () / 10], v[v.size () * 9 / 10], v[v.size () * 99 / 100], v.back (), sum / v.size (), v.size ());
   }
+  // where wave 0 of a workgroup ran (HW_ID: wave 0-3, simd 4-5)
+  {
+    unsigned long simd[4] = { 0, 0, 0, 0 };
+    for (int b = 0; b < 16384; b++)
+      if (h[b * 16 + 9])
+        simd[(h[b * 16 + 14] >> 4) & 3]++;
+    fprintf (stderr, "wave 0 of a workgroup on SIMD 0 / 1 / 2 / 3: %lu %lu %lu %lu\n", simd[0], simd[1], simd[2], simd[3]);
+  }
   // occupancy: workgroup lifetimes against the span of the workgroups that ran on the same CU
   // (HW_ID: cu 8-11, sh 12, se 13-15; XCC_ID 0-3)
   std::vector < std::pair < int, int > >by_cu;
