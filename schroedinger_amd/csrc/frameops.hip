@@ -110,6 +110,11 @@ void convert_kernel (const ConvertJob * __restrict__ jobs, int njobs)
 
 // (tile height, a multiple of 16: 8 x 2160p upsample 0.0570 ms per step at 16, 0.0565 at 32, 0.0648 at 64 --
 // the kernel is bound by its writes, two homes per column)
+// (r05, VERDICT r04 item 7 -- reads before writes: a workgroup took G tiles below one another and asked for the next
+// tile's source chunks, 16 bytes per lane held in registers, before it filtered and stored the current one; 58 VGPRs,
+// still eight waves.  8 x 2160p upsample per step: G = 1 0.0627, 2 0.0683, 4 0.0810, 8 0.1106 ms -- the two launches
+// of a step are 4 and 2 rounds of workgroups long, and fewer, longer workgroups lose more at their ends than the
+// ordered reads gain.  Not kept.)
 constexpr int kUpTW = 128, kUpTH = 16;
 
 typedef short short2v __attribute__ ((ext_vector_type (2)));
