@@ -755,6 +755,30 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
+  // (scratch builds: what do N more vector / scalar instructions per wave cost?  r05, 8 x 2160p, OBMC per step: product
+  // 0.1586, +70 vector instructions 0.1599, +140 (a fifth of a wave's 716) 0.1609, +140 scalar (a third of its 431)
+  // 0.1622 ms -- 0.01 % per instruction: the launch is bound by neither issue stream.  What does move it, luma launch of
+  // 8 pictures (scripts/obmc_phase_time.py MOTION=...): one tap, windows right behind their blocks 0.076 ms; all four
+  // taps 0.106 (0.010 per tap, the same with the windows' 12 rows starting on a band of 4 plane rows or in the middle
+  // of one); independent windows instead: one tap 0.088, four 0.122 (0.012 .. 0.016 for the lines that miss the L2).)
+#ifdef SCHRO_ROW_DUMMY_VALU
+  {
+    int x = tid;
+#pragma unroll
+    for (int i = 0; i < SCHRO_ROW_DUMMY_VALU; i++)
+      asm volatile ("v_add_u32 %0, %0, 1":"+v" (x));
+    asm volatile (""::"v" (x));
+  }
+#endif
+#ifdef SCHRO_ROW_DUMMY_SALU
+  {
+    int x = bid;
+#pragma unroll
+    for (int i = 0; i < SCHRO_ROW_DUMMY_SALU; i++)
+      asm volatile ("s_add_u32 %0, %0, 1":"+s" (x)::"scc");
+    asm volatile (""::"s" (x));
+  }
+#endif
   constexpr int kAccQuads = (TH * G::kAccW + 3) / 4;   // the accumulator tile is cleared 16 bytes at a time
   for (int it = tid; it < kAccQuads; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };

@@ -43,6 +43,10 @@ def main():
                 vec = np.zeros((mv.shape[0], 4), np.int16)
             elif kind == "y2":          # ... two rows down: the 12 rows of a window start on a band of 4 plane rows (zero: in the middle of one)
                 vec = np.tile(np.array([0, 8, 0, 8], np.int16), (mv.shape[0], 1))
+            elif kind == "q11":         # all four quarter-pel taps of windows right behind their blocks
+                vec = np.tile(np.array([1, 1, 1, 1], np.int16), (mv.shape[0], 1))
+            elif kind == "q19":         # ... and two rows down (band-aligned windows)
+                vec = np.tile(np.array([1, 9, 1, 9], np.int16), (mv.shape[0], 1))
             elif kind == "even":        # the bench's independent vectors rounded to half-pel positions of even parity: one tap each
                 vec = (mv["v"] & ~np.int16(3)).astype(np.int16)
             elif kind == "odd":         # ... and with every tap needed (all four quarter-pel taps of both references)
