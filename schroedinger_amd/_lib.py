@@ -103,6 +103,12 @@ class DequantPlane(C.Structure):
                 ("ncodeblocks", C.c_int), ("is_intra", C.c_int)]
 
 
+class QuantisedPicture(C.Structure):
+    """SchroHipQuantisedPicture (include/schro_hip.h): a picture's codeblock records and quantised values per component."""
+    _fields_ = [("codeblocks", C.POINTER(Codeblock) * 3), ("ncodeblocks", C.c_int * 3), ("values", C.c_void_p * 3),
+                ("values_bytes", C.c_size_t * 3), ("values_on_device", C.c_int)]
+
+
 class DcPlane(C.Structure):
     _fields_ = [("data", C.c_void_p), ("stride", C.c_int), ("width", C.c_int), ("height", C.c_int)]
 
@@ -386,6 +392,8 @@ def load():
     L.schro_frame_inverse_iwt_transform_combine_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
                                                                  C.POINTER(Params), C.POINTER(Frame)]
     L.schro_frame_inverse_iwt_transform_combine_hip.restype = i
+    L.schro_hipframe_dequantise.argtypes = [C.POINTER(Frame), C.POINTER(QuantisedPicture), C.POINTER(Params)]
+    L.schro_hipframe_dequantise.restype = i
     L.schro_frame_inverse_iwt_transform_convert_hip.argtypes = [C.POINTER(Frame), C.POINTER(Frame), C.POINTER(Params)]
     L.schro_frame_inverse_iwt_transform_convert_hip.restype = i
     L.schro_upsampled_hipframe_upsample.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]

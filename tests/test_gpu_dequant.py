@@ -261,3 +261,79 @@ def test_a_plan_reused_over_different_pictures(ctx):
         plan.free()
         for p in planes + keep + keep0:
             p.free()
+
+
+@pytest.mark.parametrize("dtype,noarith,num_refs,on_device", [(np.int16, 0, 0, 0), (np.int16, 1, 1, 1), (np.int32, 0, 0, 1),
+                                                            (np.int16, 0, 2, 0), (np.int32, 1, 0, 0)])
+def test_the_frame_layer_takes_codeblock_records_and_values(ctx, dtype, noarith, num_refs, on_device):
+    """r05: schro_hipframe_dequantise (transform_frame, quantised, params) -- what a patched schro_decoder_decode_subband
+    (schrodecoder.c:3525-3640) leaves behind for a picture: zero codeblocks zero-filled, the others dequantised with the
+    decoder's arithmetic (the 16-bit Orc program only for is_noarith on an s16 frame), the LL bands of a picture without
+    references DC-predicted (:3629-3636).  Values from host memory (staged by the call) and from the device; pictures of two
+    geometries after one another (the context's plan is rebuilt, then kept)."""
+    import ctypes as C
+    from schroedinger_amd import _lib, frames
+    lib = ctx.lib
+    rng = np.random.default_rng(5 + num_refs)
+    intra = num_refs == 0
+    arith = 1 if noarith and dtype == np.int16 else 0
+    for (iw, ih, depth) in [(96, 64, 2), (96, 64, 2), (352, 288, 3)]:
+        dims = [(ih, iw), (ih // 2, iw // 2), (ih // 2, iw // 2)]
+        tf = frames.DeviceFrame(ctx, frames.frame_format(dtype, 1, 1), iw, ih)
+        # the frame starts from a pattern: every sample is written
+        tf.upload(frames.HostFrame([np.full(d, 0x1234, dtype) for d in dims], 1, 1))
+        params = frames.make_params(is_noarith=noarith, transform_depth=depth, num_refs=num_refs, iwt_luma_width=iw,
+                                    iwt_luma_height=ih, iwt_chroma_width=iw // 2, iwt_chroma_height=ih // 2)
+        qp = _lib.QuantisedPicture()
+        keep, want = [], []
+        for k, (h, w) in enumerate(dims):
+            quant = rng.integers(-300, 301, (h, w)).astype(np.int32)
+            quant[rng.random((h, w)) < 0.6] = 0
+            records = synthetic_records(h, w, depth, rng)
+            blob, cbs = pack_codeblocks((h, w), np.dtype(dtype).itemsize, tf.c.components[k].stride, depth, quant, records)
+            tab = sa.Context.codeblock_table(cbs)
+            qp.codeblocks[k] = C.cast(tab, C.POINTER(_lib.Codeblock))
+            qp.ncodeblocks[k] = len(cbs)
+            if on_device:
+                dev = ctx.upload_bytes(blob)
+                qp.values[k] = dev.ptr
+                keep.append(dev)
+            else:
+                qp.values[k] = blob.ctypes.data
+            qp.values_bytes[k] = blob.size
+            keep += [tab, blob]
+            ref = np.zeros((h, w), dtype)
+            for (index, x0, y0, x1, y1, zero, qi) in records:
+                band, qb = D.subband_view(ref, depth, index), D.subband_view(quant, depth, index)
+                if x1 > x0 and y1 > y0:
+                    O.dequant_codeblock(band[y0:y1, x0:x1], None if zero else qb[y0:y1, x0:x1], qi, 1 if intra else 0, arith)
+            if intra:
+                ll = D.subband_view(ref, depth, 0)
+                ll[...] = O.dc_predict(ll)
+            want.append(ref)
+        qp.values_on_device = on_device
+        sa.check(lib.schro_hipframe_dequantise(tf.ptr(), C.byref(qp), C.byref(params)))
+        got = tf.download()
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), (iw, ih, k)
+        tf.unref()
+        for d in keep:
+            if hasattr(d, "free"):
+                d.free()
+
+
+def test_the_frame_layer_refuses_what_is_not_a_quantised_picture(ctx):
+    import ctypes as C
+    from schroedinger_amd import _lib, frames
+    lib = ctx.lib
+    params = frames.make_params(transform_depth=1, num_refs=1, iwt_luma_width=32, iwt_luma_height=32, iwt_chroma_width=16,
+                                iwt_chroma_height=16)
+    tf = frames.DeviceFrame(ctx, frames.frame_format(np.int16, 1, 1), 32, 32)
+    qp = _lib.QuantisedPicture()
+    assert lib.schro_hipframe_dequantise(tf.ptr(), C.byref(qp), C.byref(params)) == -1       # no records
+    assert b"codeblock" in lib.schro_hip_last_error()
+    u8 = frames.DeviceFrame(ctx, frames.frame_format(np.uint8, 1, 1), 32, 32)
+    assert lib.schro_hipframe_dequantise(u8.ptr(), C.byref(qp), C.byref(params)) == -1       # a u8 frame
+    assert lib.schro_hipframe_dequantise(None, C.byref(qp), C.byref(params)) == -1
+    tf.unref()
+    u8.unref()
