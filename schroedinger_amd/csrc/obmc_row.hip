@@ -72,6 +72,9 @@ template < int ND, bool UV > struct RowGeo {
   // (row, pixel pair | UV: pixel) weight words: 2 * ND per row (zero beyond the block), 32 rows
   static constexpr int kWCap = 32 * 2 * ND;
   static constexpr bool kPadBlk = UV || ND > 2;        // block records of nine words (see RowBlkT)
+  // r05: the weight table of a plane geometry, made on the HOST (plane_obmc.cpp: obmc_row_weight_table) and copied into
+  // LDS by the tile: kWCap (row, pair) words, 32 folded x pairs, 128 folded y weights, the two ramps (16 + 32 ints)
+  static constexpr int kWTab = kWCap + 32 + 128 + 16 + 32;
 };
 // Item classes (one straight-line pass body each): both references / the first / the second / DC /
 // edge (windows clamped vertically and / or folded weights, any mode: still a row per lane) / rim (DC
@@ -621,7 +624,9 @@ row_finish_plain (const ObmcJob & job, const PlaneIO & io, int cb, const uint32_
   }
 }
 
-template < int TH, typename G >
+// NOCLAMP (r05): a prediction alone whose tile holds no DC value outside 0 .. 255 -- the weights of the blocks over a
+// pixel add up to 64 and every prediction sample is a byte, so (sum + 32) >> 6 is one too: no clamp
+template < int TH, typename G, bool NOCLAMP = false >
 __device__ __forceinline__ void
 row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, int tid, int x_lo, int y_lo,
     int x_hi, int y_hi, bool fast, const u32x4 * res)
@@ -659,7 +664,8 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
       for (int k = 0; k < 4; k++) {
         s16x2 v = (__builtin_bit_cast (s16x2, av[k]) + (short) 32) >> 6;
         v = v + __builtin_bit_cast (s16x2, rv[k]);
-        v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+        if constexpr (!NOCLAMP)
+          v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
         t[k] = __builtin_bit_cast (uint32_t, v);
       }
       u32x2 o;
@@ -674,7 +680,7 @@ row_finish (const ObmcJob & job, const PlaneIO & io, uint32_t * acc, int par, in
 
 // UV: a lane takes 8 pixels of one row of BOTH planes: eight accumulator words (U sum low, V sum high),
 // 16 bytes of each plane's residual (res[2 n], res[2 n + 1]), 8 bytes of each plane's picture
-template < int TH, typename G >
+template < int TH, typename G, bool NOCLAMP = false >
 __device__ __forceinline__ void
 row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, int tid, int x_lo, int y_lo, int y_hi, const u32x4 * res)
 {
@@ -696,7 +702,8 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
       const uint32_t r = __builtin_amdgcn_perm (rvw[k >> 1], ruw[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u);
       s16x2 v = (__builtin_bit_cast (s16x2, ap[k]) + (short) 32) >> 6;
       v = v + __builtin_bit_cast (s16x2, r);
-      v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
+      if constexpr (!NOCLAMP)
+        v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s16x2) (short) 0), (s16x2) (short) 255);
       t[k] = __builtin_bit_cast (uint32_t, v);
     }
     // t[k] = (U_k, 0, V_k, 0) -> (U0 U1 V0 V1), (U2 U3 V2 V3) -> U0 .. U3 | V0 .. V3
@@ -717,27 +724,41 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
 // bench.py's headline).  The eight registers that carry the prefetched residual through the passes are not held at all.
 template < int ND, int NP, bool UV = false, int TH = kRTH, bool NORES = false >
 __device__ __forceinline__ void
-obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow)
+obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow,
+    const uint32_t * __restrict__ wtabs)
 {
   typedef RowGeo < ND, UV > G;
   static_assert (!UV || NP == 1, "a UV job is one virtual plane of (U, V) samples");
   constexpr int kRTW = G::kTW, ps = UV ? 1 : 0;
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * G::kAccW + 3];
-  __shared__ int s_wx[16], s_wy[32];    // (obmc_row_nd: blocks up to 16 x 32)
+  // (r05: s_wp | s_wx | s_wy are ONE block, copied from the job's weight table, see below)
   constexpr int kRBlkCap = G::kBlk, kRItemCap = G::kItem;
   typedef RowBlkT < G::kPadBlk > RowBlk;
   __shared__ RowBlk s_hot[kRBlkCap];            // the tile's blocks, in raster order
   __shared__ uint16_t s_meta[kRBlkCap];         // slot | first item within the slot << 5
   __shared__ uint16_t s_rim[kRBlkCap];          // the picture-rim blocks
   __shared__ uint16_t s_item[kRItemCap];
-  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[G::kWCap + 32 + 128];      // + folded x pairs, folded y (edge class)
+  __shared__ __attribute__ ((aligned (16))) uint32_t s_wp[G::kWTab];   // (row, pair) weights + folded x pairs, folded y (edge class) + the ramps
+  const int *const s_wx = reinterpret_cast < const int * >(s_wp + G::kWCap + 160), *const s_wy = s_wx + 16;    // (obmc_row_nd: blocks up to 16 x 32)
   __shared__ int s_icnt[kRSlots];               // items of each slot
   __shared__ int s_nrim, s_wide;
 
   const uint64_t t_start = __builtin_amdgcn_s_memtime ();
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
-  const uint32_t entry = order ? order[bid] : 0u;        // (a uniform address: a scalar load)
-  const ObmcJob job = jobs[order ? (int) (entry >> 16) : find_job (jobs, njobs, bid)];
+  // r05: a tile's record from the host's order table (plane_obmc.cpp: obmc_tile_order) -- four words: job << 16 | tile,
+  // x_lo | y_lo << 16, first block column | first block row << 16, block columns | block rows << 8 | ceil (2^16 /
+  // block columns) << 16 -- one scalar load where every wave worked the same five divisions out (~90 scalar
+  // instructions and a dozen branches of a wave's 430).  The experiments build keeps the arithmetic for runs without
+  // the table (SCHRO_HIP_OBMC_ORDER=0).
+#ifdef SCHRO_HIP_EXPERIMENTS
+  const bool have_rec = order != nullptr;
+#else
+  constexpr bool have_rec = true;
+#endif
+  const u32x4 rec = have_rec ? *reinterpret_cast < const u32x4 * >(order + 4 * (size_t) bid) : (u32x4) { 0u, 0u, 0u, 0u };   // (a uniform address: a scalar load)
+  const uint32_t entry = rec.x;
+  const int ji = have_rec ? (int) (entry >> 16) : find_job (jobs, njobs, bid);
+  const ObmcJob job = jobs[ji];
   // scratch runs (SCHRO_HIP_OBMC_STAMPS): cycles since the workgroup started, per phase
   // (r05: experiments build only -- each stamp is a handful of scalar instructions and a branch in EVERY wave: OBMC per
   // 8 x 2160p step 0.1640 -> 0.1616 ms without them)
@@ -748,10 +769,14 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #define RSTAMP(n) do { } while (0)
 #endif
   RSTAMP (7);                   // (the job is here)
-  const int t = order ? (int) (entry & 0xffffu) : bid - job.tile_base;
-  const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
   const int tid = threadIdx.x;
-  const int x_lo = tx * kRTW, y_lo = ty * TH;
+  int x_lo = (int) (rec.y & 0xffffu), y_lo = (int) (rec.y >> 16);
+  if (!have_rec) {
+    const int t = bid - job.tile_base;
+    const int ty = mdiv (t, job.tiles_x, job.m_tiles_x), tx = t - ty * job.tiles_x;
+    x_lo = tx * kRTW;
+    y_lo = ty * TH;
+  }
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
@@ -782,10 +807,14 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   constexpr int kAccQuads = (TH * G::kAccW + 3) / 4;   // the accumulator tile is cleared 16 bytes at a time
   for (int it = tid; it < kAccQuads; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
-  if (tid < job.xblen)
-    s_wx[tid] = weight_1d (tid, job.xblen, job.xoff, job.m_xramp);
-  if (tid >= 64 && tid - 64 < job.yblen)
-    s_wy[tid - 64] = weight_1d (tid - 64, job.yblen, job.yoff, job.m_yramp);
+  // r05: the plane geometry's weights come ready-made from the host (the job's `ipw` names its table in `wtabs`,
+  // obmc_row_weight_table below).  The two waves that do not decode ask for it here, 16 bytes per lane, and put it into
+  // LDS behind the first barrier, beside the decode: no ramps through LDS and no table arithmetic (~120 branchy
+  // instructions in two waves).  (Waited for in front of that barrier by every lane it was slower: 0.1655 against 0.1616.)
+  static_assert (G::kWTab % 4 == 0 && G::kWTab / 4 <= kRThreads / 2, "a quad of the weight table per lane of the last two waves");
+  u32x4 wq = (u32x4) { 0u, 0u, 0u, 0u };
+  if (tid >= kRThreads / 2 && tid - kRThreads / 2 < G::kWTab / 4)
+    wq = gload < u32x4 > (wtabs + (size_t) job.ipw * G::kWTab + 4 * (tid - kRThreads / 2));
   if (tid >= 128 && tid < 128 + kRSlots)
     s_icnt[tid - 128] = 0;
   if (tid == 192) {
@@ -800,15 +829,21 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   {
     // ---- decode: every block whose footprint meets the tile, one per thread and round -----
     const int xbsep = job.xbsep, ybsep = job.ybsep, xoff = job.xoff, yoff = job.yoff, prec = job.prec;
-    const int i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
-    const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
-    const int j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
-    const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
-    const int nbi = i_hi - i_lo + 1, nbj = j_hi - j_lo + 1;
-    nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
+    // (obmc_row_tile_record below is the same arithmetic on the host)
+    int i_lo = (int) (rec.z & 0xffffu), j_lo = (int) (rec.z >> 16), nbi = (int) (rec.w & 0xffu), nbj = (int) ((rec.w >> 8) & 0xffu);
     // (blk / nbi as (blk * ceil (2^16 / nbi)) >> 16: exact while blk * nbi < 2^16 -- here blk < kRBlkCap <= 344 and nbi <= 66)
     static_assert (kRBlkCap * 128 < 65536, "the 16-bit block-row division below");
-    const uint32_t m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+    uint32_t m16_nbi = rec.w >> 16;
+    if (!have_rec) {
+      i_lo = max (0, mdiv (x_lo + xoff - xblen + 2 * xbsep, xbsep, job.m_xbsep) - 1);
+      const int i_hi = min (job.nbx - 1, mdiv (x_hi - 1 + xoff, xbsep, job.m_xbsep));
+      j_lo = max (0, mdiv (y_lo + yoff - yblen + 2 * ybsep, ybsep, job.m_ybsep) - 1);
+      const int j_hi = min (job.nby - 1, mdiv (y_hi - 1 + yoff, ybsep, job.m_ybsep));
+      nbi = i_hi - i_lo + 1;
+      nbj = j_hi - j_lo + 1;
+      m16_nbi = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+    }
+    nblk = nbi > 0 && nbj > 0 ? min (nbi * nbj, kRBlkCap) : 0;   // (the host sends larger geometries to obmc.hip)
     const int gh = 2 * job.h - 2;       // last valid half-pel sample row
     // the motion vectors of the first round start their way from memory beside the set-up
     uint32_t mv_pre[3] = { 0u, 0u, 0u };
@@ -821,50 +856,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     }
     RSTAMP (10);                // (accumulator cleared, ramps, the vectors asked for)
     // (r05, measured slower: the vectors asked for first and the weight tables made from weight_1d in front of this ONE
-    // barrier, the ramps' round trip through LDS and the phase behind the barrier gone -- 0.1655 against 0.1611 ms per step;
-    // the tables made by the HOST, one per block geometry of a launch, and copied in by the tile: 0.1655 against 0.1616)
-    __syncthreads ();           // ramps, counters
+    // barrier, the ramps' round trip through LDS and the phase behind the barrier gone -- 0.1655 against 0.1611 ms per step)
+    __syncthreads ();           // counters, the accumulator
     RSTAMP (8);
-    // r05: the tables are the work of the LAST two waves -- the decode below keeps the first two busy (108 blocks of a
-    // 128 x 32 tile of 12 / 8 blocks) and was waiting behind 2.2 k cycles of tables in exactly those waves
-    if (tid >= kRThreads / 2) {
-      const int t2 = tid - kRThreads / 2;
-      // wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
-      // 2 * ND words, zero beyond the block's width.  UV: a word per pixel, its weight for both components
-      for (int i = t2; i < yblen * 2 * ND && i < G::kWCap; i += kRThreads / 2) {
-        const int r = i / (2 * ND), pr = i - r * (2 * ND);
-        if constexpr (UV)
-          s_wp[i] = pr < xblen ? (uint32_t) (s_wx[pr] * s_wy[r]) * 0x00010001u : 0u;
-        else
-          s_wp[i] = pr < (xblen >> 1) ? (uint32_t) (s_wx[2 * pr] * s_wy[r]) | ((uint32_t) (s_wx[2 * pr + 1] * s_wy[r]) << 16) : 0u;
-      }
-      // 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding,
-      // schromotion8.c:673-693, by edge type instead of by pixel): the first block row / column folds
-      // its first 2 * offset weights, the last one everything from the block step on
-      auto folded = [](const int *w1, int idx, int blen, int bsep, int off, int type) {
-        if (idx >= blen)
-          return 0;
-        int w = w1[idx];
-        if ((type & 1) && idx < 2 * off)
-          w += w1[2 * off - idx - 1];
-        if ((type & 2) && idx >= bsep)
-          w += w1[2 * (blen - off) - idx - 1];
-        return w;
-      };
-      for (int k = t2; k < 32 + 128; k += kRThreads / 2) {
-        if (k < 32) {
-          const int type = k >> 3, pr = k & 7;
-          if constexpr (UV)       // (rows of up to 8 pixels: 8 words per edge type, as for 16 pixels in pairs)
-            s_wp[G::kWCap + k] = (uint32_t) folded (s_wx, pr, xblen, job.xbsep, job.xoff, type) * 0x00010001u;
-          else
-            s_wp[G::kWCap + k] = (uint32_t) folded (s_wx, 2 * pr, xblen, job.xbsep, job.xoff, type)
-                | ((uint32_t) folded (s_wx, 2 * pr + 1, xblen, job.xbsep, job.xoff, type) << 16);
-        } else {
-          const int type = (k - 32) >> 5, r = (k - 32) & 31;
-          s_wp[G::kWCap + k] = (uint32_t) folded (s_wy, r, yblen, job.ybsep, job.yoff, type);
-        }
-      }
-    }
+    if (tid >= kRThreads / 2 && tid - kRThreads / 2 < G::kWTab / 4)
+      reinterpret_cast < u32x4 * >(s_wp)[tid - kRThreads / 2] = wq;      // (read in the passes, two barriers on)
     RSTAMP (1);
     for (int blk = tid; blk < nblk; blk += kRThreads) {
       const int bj = nbi == 1 ? blk : (int) (((uint32_t) blk * m16_nbi) >> 16);
@@ -1121,13 +1117,19 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     RSTAMP (6);
     if constexpr (UV) {
       if (fast) {
-        row_finish_uv < TH, G > (io, iov, acc, tid, x_lo, y_lo, y_hi, res);
+        if (NORES && !exact)
+          row_finish_uv < TH, G, NORES > (io, iov, acc, tid, x_lo, y_lo, y_hi, res);
+        else
+          row_finish_uv < TH, G > (io, iov, acc, tid, x_lo, y_lo, y_hi, res);
       } else {
         row_finish_plain < TH, G, true > (job, io, 0, acc, par, tid, x_lo, y_lo, x_hi, y_hi);
         row_finish_plain < TH, G, true > (job, iov, 1, acc, par, tid, x_lo, y_lo, x_hi, y_hi);
       }
     } else {
-      row_finish < TH, G > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+      if (NORES && !exact)
+        row_finish < TH, G, NORES > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
+      else
+        row_finish < TH, G > (job, io, acc, par, tid, x_lo, y_lo, x_hi, y_hi, fast, res);
     }
     if (pl + 1 < nplanes) {     // the job's next plane starts from a zero accumulator
       __syncthreads ();
@@ -1170,9 +1172,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #endif
 #define SCHRO_ROW_KERNEL(name, waves, ...) \
 __global__ __launch_bounds__ (kRThreads) __attribute__ ((amdgpu_waves_per_eu (waves, waves))) SCHRO_ROW_SGPR_ATTR (name) \
-void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow) \
+void name (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow, \
+    const uint32_t * __restrict__ wtabs) \
 { \
-  obmc_row_body < __VA_ARGS__ > (jobs, njobs, order, overflow); \
+  obmc_row_body < __VA_ARGS__ > (jobs, njobs, order, overflow, wtabs); \
 }
 SCHRO_ROW_KERNEL (obmc_row_kernel_2_1, 6, 2, 1)
 SCHRO_ROW_KERNEL (obmc_row_kernel_2_2, 6, 2, 2)
@@ -1200,12 +1203,12 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, SCHRO_ROW_UV_WAVES, 3, 1, true, kRTH, 
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_4, 4, 4, 1, true, kRTH, true)
 #undef SCHRO_ROW_KERNEL
 
-typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *, uint32_t *);
+typedef void (*RowKernel) (const ObmcJob *, int, const uint32_t *, uint32_t *, const uint32_t *);
 
 // np: planes per job (1, 2); 3: (U, V) pairs from pair images
 int
 launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int np, const uint32_t * d_order,
-    uint32_t * overflow)
+    uint32_t * overflow, const uint32_t * d_wtabs)
 {
   RowKernel k = nullptr;
   switch (nd * 10 + np) {
@@ -1234,7 +1237,7 @@ launch_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_til
     return set_error (SCHRO_HIP_EINVAL, "obmc (row): %d dwords per row x %d planes unsupported", nd, np);
   // scratch runs: SCHRO_HIP_OBMC_LDS_PAD = bytes of unused dynamic LDS per workgroup (fewer workgroups per CU)
   static const int lds_pad = SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_LDS_PAD")) : 0;
-  SCHRO_LAUNCH (k, dim3 (total_tiles), dim3 (kRThreads), (size_t) lds_pad, stream, d_jobs, njobs, d_order, overflow);
+  SCHRO_LAUNCH (k, dim3 (total_tiles), dim3 (kRThreads), (size_t) lds_pad, stream, d_jobs, njobs, d_order, overflow, d_wtabs);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "obmc (row) launch: %s", hipGetErrorString (e));
@@ -1274,6 +1277,94 @@ obmc_row_nd (const ObmcJob & j, bool uv)
   return nd;
 }
 
+// r05: the weight table a row kernel of `nd` dwords per row copies into LDS for a job of this block geometry (RowGeo::kWTab
+// words; the kernels made it themselves until r05, 2.2 k cycles of every tile's 25 k):
+//   [0, 64 nd)       wx * wy of every (block row, pixel pair), two 16-bit products per word (<= 64 each); rows of
+//                    2 * nd words, zero beyond the block's width.  uv: a word per pixel, its weight for both components
+//   [64 nd, +32)     folded x weights by edge type (4 x 8 words, pairs as above)
+//   [.. , +128)      folded y weights by edge type (4 x 32)
+//   [.. , +16), +32  the two ramps, obmc_weight_1d (schromotion.c:40-69)
+// Folded: the 1-D weights of blocks that hang over the picture's rim (accumulate_slow's folding, schromotion8.c:673-693,
+// by edge type instead of by pixel): the first block row / column folds its first 2 * offset weights, the last one
+// everything from the block step on.
+int
+obmc_row_weight_words (int nd)
+{
+  return 64 * nd + 32 + 128 + 16 + 32;
+}
+
+void
+obmc_row_weight_table (const ObmcJob & j, int nd, bool uv, uint32_t * out)
+{
+  auto ramp = [](int x, int offset) { return offset == 1 ? (x == 0 ? 3 : 5) : 1 + (6 * x + offset - 1) / (2 * offset - 1); };
+  auto weight = [&](int i, int blen, int offset) {
+    if (offset == 0)
+      return 8;
+    if (i < 2 * offset)
+      return ramp (i, offset);
+    if (blen - 1 - i < 2 * offset)
+      return ramp (blen - 1 - i, offset);
+    return 8;
+  };
+  int wx[16] = { 0 }, wy[32] = { 0 };
+  for (int i = 0; i < j.xblen && i < 16; i++)
+    wx[i] = weight (i, j.xblen, j.xoff);
+  for (int i = 0; i < j.yblen && i < 32; i++)
+    wy[i] = weight (i, j.yblen, j.yoff);
+  auto folded = [](const int *w1, int idx, int blen, int bsep, int off, int type) {
+    if (idx >= blen)
+      return 0;
+    int w = w1[idx];
+    if ((type & 1) && idx < 2 * off)
+      w += w1[2 * off - idx - 1];
+    if ((type & 2) && idx >= bsep)
+      w += w1[2 * (blen - off) - idx - 1];
+    return w;
+  };
+  const int wcap = 64 * nd;
+  for (int i = 0; i < wcap; i++) {
+    const int r = i / (2 * nd), pr = i - r * (2 * nd);
+    uint32_t v = 0;
+    if (r < j.yblen) {
+      if (uv)
+        v = pr < j.xblen ? (uint32_t) (wx[pr] * wy[r]) * 0x00010001u : 0u;
+      else
+        v = pr < (j.xblen >> 1) ? (uint32_t) (wx[2 * pr] * wy[r]) | ((uint32_t) (wx[2 * pr + 1] * wy[r]) << 16) : 0u;
+    }
+    out[i] = v;
+  }
+  for (int t = 0; t < 32; t++) {
+    const int type = t >> 3, pr = t & 7;
+    out[wcap + t] = uv ? (uint32_t) folded (wx, pr, j.xblen, j.xbsep, j.xoff, type) * 0x00010001u
+        : (uint32_t) folded (wx, 2 * pr, j.xblen, j.xbsep, j.xoff, type) | ((uint32_t) folded (wx, 2 * pr + 1, j.xblen, j.xbsep, j.xoff, type) << 16);
+  }
+  for (int t = 0; t < 128; t++)
+    out[wcap + 32 + t] = (uint32_t) folded (wy, t & 31, j.yblen, j.ybsep, j.yoff, t >> 5);
+  for (int i = 0; i < 16; i++)
+    out[wcap + 160 + i] = (uint32_t) wx[i];
+  for (int i = 0; i < 32; i++)
+    out[wcap + 176 + i] = (uint32_t) wy[i];
+}
+
+// r05: the record of tile (tx, ty) of a job in a row launch's order table (the kernels' decode set-up, done once per
+// geometry on the host): x_lo | y_lo << 16, i_lo | j_lo << 16, nbi | nbj << 8 | ceil (2^16 / nbi) << 16 -- the blocks
+// [i_lo, i_lo + nbi) x [j_lo, j_lo + nbj) are the ones whose footprint meets the tile
+void
+obmc_row_tile_record (const ObmcJob & j, bool uv, int tx, int ty, uint32_t * rec)
+{
+  const int tw = uv ? RowGeo < 3, true >::kTW : RowGeo < 3, false >::kTW;
+  const int x_lo = tx * tw, y_lo = ty * kRTH, x_hi = std::min (x_lo + tw, j.w), y_hi = std::min (y_lo + kRTH, j.h);
+  const int i_lo = std::max (0, (x_lo + j.xoff - j.xblen + 2 * j.xbsep) / j.xbsep - 1);
+  const int i_hi = std::min (j.nbx - 1, (x_hi - 1 + j.xoff) / j.xbsep);
+  const int j_lo = std::max (0, (y_lo + j.yoff - j.yblen + 2 * j.ybsep) / j.ybsep - 1);
+  const int j_hi = std::min (j.nby - 1, (y_hi - 1 + j.yoff) / j.ybsep);
+  const int nbi = std::max (0, std::min (255, i_hi - i_lo + 1)), nbj = std::max (0, std::min (255, j_hi - j_lo + 1));
+  const uint32_t m16 = nbi > 1 ? (65536u + (uint32_t) nbi - 1u) / (uint32_t) nbi : 0u;
+  rec[0] = (uint32_t) x_lo | ((uint32_t) y_lo << 16);
+  rec[1] = (uint32_t) i_lo | ((uint32_t) j_lo << 16);
+  rec[2] = (uint32_t) nbi | ((uint32_t) nbj << 8) | (m16 << 16);
+}
+
 int
 obmc_row_tile_height ()
 {
@@ -1289,9 +1380,9 @@ obmc_row_tile_width (bool uv)
 
 int
 launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd, int planes_per_job,
-    const uint32_t * d_order, uint32_t * overflow)   // planes_per_job 3: (U, V) pairs from pair images
+    const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs)   // planes_per_job 3: (U, V) pairs from pair images
 {
-  return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order, overflow);
+  return launch_row (stream, d_jobs, njobs, total_tiles, nd, planes_per_job, d_order, overflow, d_wtabs);
 }
 
 }                               // namespace schro

@@ -131,12 +131,14 @@ schro_hip_obmc_stamps_dump (void)
 
 static int
 obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int variant, int total,
-    const uint32_t ** d_order)
+    const uint32_t ** d_order, int row_uv = -1)  // row_uv >= 0: a row launch (1: of (U, V) pairs) -- FOUR words per tile, obmc_row_tile_record
 {
   *d_order = nullptr;
   static const bool enabled = !SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER") || atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER")) != 0;
   if (!enabled || variant < 1 || jobs.empty () || jobs.size () > 0xffff)
     return 0;
+  const bool row = row_uv >= 0;
+  const size_t words = row ? 4 : 1;     // per tile
   uint64_t h = 1469598103934665603ull;
   auto mix = [&h] (uint64_t v) {
     for (int k = 0; k < 8; k++) {
@@ -159,13 +161,20 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     mix ((uint64_t) tx);
     mix ((uint64_t) tiles_y[j]);
     mix ((uint64_t) first);
+    if (row) {                  // (what the tiles' records are made of)
+      const ObmcJob & g = jobs[j];
+      mix ((uint64_t) g.w | ((uint64_t) g.h << 20) | ((uint64_t) row_uv << 40) | (1ull << 41));
+      mix ((uint64_t) g.xbsep | ((uint64_t) g.ybsep << 8) | ((uint64_t) g.xblen << 16) | ((uint64_t) g.yblen << 24) | ((uint64_t) g.xoff << 32)
+          | ((uint64_t) g.yoff << 40));
+      mix ((uint64_t) g.nbx | ((uint64_t) g.nby << 20));
+    }
   }
   constexpr int per_queue = SchroHipContext::kOrderSlots / SchroHipContext::kQueues;
   const int k0 = ctx->cur * per_queue;
   SchroHipContext::OrderSlot * slot = nullptr, *lru = &ctx->order_slots[k0];
   for (int k = k0; k < k0 + per_queue; k++) {
     SchroHipContext::OrderSlot & o = ctx->order_slots[k];
-    if (o.d && o.hash == h && o.count == (size_t) total)
+    if (o.d && o.hash == h && o.count == (size_t) total * words)
       slot = &o;
     if (o.last_use < lru->last_use)
       lru = &o;
@@ -246,7 +255,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
       SCHRO_HIP_CHECK (hipEventSynchronize (slot->copied));
       slot->copy_pending = false;
     }
-    if (slot->cap < keys.size ()) {
+    if (slot->cap < keys.size () * words) {
       // grow-only; hipFree waits for the work that may still read the old table
       if (slot->d)
         SCHRO_HIP_CHECK (hipFree (slot->d));
@@ -255,21 +264,27 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
       slot->d = nullptr;
       slot->h = nullptr;
       slot->cap = 0;
-      const size_t cap = keys.size () + keys.size () / 4;
+      const size_t cap = (keys.size () + keys.size () / 4) * words;
       SCHRO_HIP_CHECK (hipMalloc ((void **) &slot->d, cap * sizeof (uint32_t)));
       SCHRO_HIP_CHECK (hipHostMalloc ((void **) &slot->h, cap * sizeof (uint32_t), hipHostMallocDefault));
       slot->cap = cap;
     }
     if (!slot->copied)
       SCHRO_HIP_CHECK (hipEventCreateWithFlags (&slot->copied, hipEventDisableTiming));
-    for (size_t k = 0; k < keys.size (); k++)
-      slot->h[k] = keys[k].entry;
-    SCHRO_HIP_CHECK (hipMemcpyAsync (slot->d, slot->h, keys.size () * sizeof (uint32_t), hipMemcpyHostToDevice,
+    for (size_t k = 0; k < keys.size (); k++) {
+      slot->h[k * words] = keys[k].entry;
+      if (row) {
+        const ObmcJob & g = jobs[keys[k].entry >> 16];
+        const int t = (int) (keys[k].entry & 0xffffu);
+        obmc_row_tile_record (g, row_uv != 0, t % g.tiles_x, t / g.tiles_x, &slot->h[k * words + 1]);
+      }
+    }
+    SCHRO_HIP_CHECK (hipMemcpyAsync (slot->d, slot->h, keys.size () * words * sizeof (uint32_t), hipMemcpyHostToDevice,
             ctx->stream));
     SCHRO_HIP_CHECK (hipEventRecord (slot->copied, ctx->stream));
     slot->copy_pending = true;
     slot->hash = h;
-    slot->count = keys.size ();
+    slot->count = keys.size () * words;
   }
   slot->last_use = ++ctx->arg_clock;
   *d_order = slot->d;
@@ -504,19 +519,45 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         return rs;
       continue;
     }
+    // r05: a row launch's weight tables, one per block geometry among its jobs (nearly always one), made here instead of
+    // by every tile; the jobs name theirs in `ipw` (a field of the item kernels, which these launches do not use)
+    void *d_wtabs = nullptr;
+    if (row) {
+      const size_t words = (size_t) obmc_row_weight_words (nd);
+      std::vector < uint32_t > tabs, one (words);
+      for (ObmcJob & j : jobs) {
+        obmc_row_weight_table (j, nd, uv, one.data ());
+        size_t k = 0;
+        while (k * words < tabs.size () && memcmp (&tabs[k * words], one.data (), words * 4))
+          k++;
+        if (k * words == tabs.size ()) {
+          if ((k + 1) * words * 4 > SchroHipContext::kArgSlotBytes)
+            return set_error (SCHRO_HIP_EINVAL, "obmc_batch: more than %zu block geometries in one launch", k);
+          tabs.insert (tabs.end (), one.begin (), one.end ());
+        }
+        j.ipw = (int) k;
+      }
+      int rw = push_args (ctx, tabs.data (), tabs.size () * 4, &d_wtabs);
+      if (rw)
+        return rw;
+    }
     void *d_jobs;
     int r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
     if (r)
       return r;
     const uint32_t *d_order;
-    r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order);
+    r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order, row ? (uv ? 1 : 0) : -1);
     if (r)
       return r;
+#ifndef SCHRO_HIP_EXPERIMENTS
+    if (row && !d_order)        // (the product's row kernels take their tiles from the table only)
+      return set_error (SCHRO_HIP_EINVAL, "obmc_batch: no tile table for a row launch of %zu jobs", jobs.size ());
+#endif
     if (g_stamps)               // scratch runs: the dump describes the last launch only
       (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
     {
       ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow)
+      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
           : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
     }
     if (r)

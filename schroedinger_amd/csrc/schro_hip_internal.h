@@ -476,7 +476,12 @@ int launch_obmc_strip (hipStream_t stream, const ObmcJob * d_jobs, int njobs, in
 int obmc_row_tile_width (bool uv);
 int obmc_row_tile_height ();
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
-    int max_planes, const uint32_t * d_order, uint32_t * overflow);
+    int max_planes, const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs);
+// the weight table of a job's block geometry as the row kernels copy it into LDS (ObmcJob::ipw: its index in d_wtabs)
+// words 1 .. 3 of tile (tx, ty)'s record in a row launch's order table (word 0: job << 16 | tile)
+void obmc_row_tile_record (const ObmcJob & job, bool uv, int tx, int ty, uint32_t * rec);
+int obmc_row_weight_words (int nd);
+void obmc_row_weight_table (const ObmcJob & job, int nd, bool uv, uint32_t * out);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
