@@ -142,8 +142,6 @@ blk_dc (const B & hb, int pl)
 }
 
 
-// obmc_weight_1d (obmc_common.h; schromotion.c:40-69) with get_ramp's division by
-// 2 * offset - 1 done as a multiplication (m = ceil (2^32 / (2 * offset - 1)), from the host)
 // what differs between the planes of a job; kept in LDS (one copy per workgroup) so that the
 // pointers of the plane not being worked on cost no scalar registers -- with both planes'
 // pointers live beside the block geometry the kernel spilled 119 SGPRs
@@ -153,22 +151,6 @@ struct __attribute__ ((aligned (8))) PlaneIO {
   uint8_t *out;
   int residual_stride, out_stride;
 };
-
-__device__ __forceinline__ int
-weight_1d (int i, int blen, int offset, uint32_t m)
-{
-  if (offset == 0)
-    return 8;
-  int x = i;
-  if (i >= 2 * offset) {
-    if (blen - 1 - i >= 2 * offset)
-      return 8;
-    x = blen - 1 - i;
-  }
-  if (offset == 1)
-    return x == 0 ? 3 : 5;
-  return 1 + mdiv (6 * x + offset - 1, 2 * offset - 1, m);
-}
 
 __device__ __forceinline__ uint32_t
 lerp1 (uint32_t a, uint32_t b)
