@@ -154,9 +154,12 @@ def test_references_move_to_the_dependents_device():
     picture's device before its function runs, once per device, and handed out by number."""
     s = sa.Scheduler(2, virtual=True)
     seen = {}
+    gate = threading.Event()        # (holds the first anchor until the second has been placed: "least loaded" then sees its device busy)
 
-    def ref(token):
+    def ref(token, wait=False):
         def g(ctx, index):
+            if wait:
+                gate.wait(5)
             s.publish_reference(index, token)
             return 0
         return g
@@ -166,8 +169,9 @@ def test_references_move_to_the_dependents_device():
             seen[name] = (index, [s.reference_frame(index, n) for n in numbers])
             return 0
         return g
-    d0, _ = s.submit(0, [], True, ref(0x1000))
+    d0, _ = s.submit(0, [], True, ref(0x1000, wait=True))
     d1, _ = s.submit(10, [], True, ref(0x2000))
+    gate.set()
     assert d0 != d1
     dev, foreign = s.submit(11, [10, 0], False, dep("B11", [10, 0]))
     assert (dev, foreign) == (d1, 0)
