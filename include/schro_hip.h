@@ -923,7 +923,7 @@ void schro_hip_obmc_stamps_dump (void);
  * device-affinity rule the reference's scheduler lacks (schro_decoder_async_schedule,
  * schrodecoder.c:1546-1682; schro_picture_new :332-400): a picture runs on the device that
  * holds its first reference, so a reference chain (closed GOP) never leaves its device; a
- * picture without references starts a chain on the least loaded device.  A device runs its
+ * picture without references starts a chain on the least loaded device (ties: the device holding the fewest live references).  A device runs its
  * pictures in submission (= coded) order, which puts references before their dependents.
  * `func` is the picture's pixel path -- the stage calls of this header on `ctx` -- and runs on
  * that device's thread; no collective, no peer traffic unless a picture predicts across two

@@ -14,7 +14,7 @@
 //     are allocated in) becomes schro_hip_scheduler_submit: a picture that predicts goes to
 //     the device of its first reference, so a reference chain (a closed GOP) stays on one
 //     device and no reference ever crosses xGMI; a picture without references (an intra
-//     picture, every VC-2 low-delay picture) starts a chain on the least loaded device;
+//     picture, every VC-2 low-delay picture) starts a chain on the least loaded device (ties: the one with the fewest live references);
 //   * a device runs its pictures in submission order -- coded order, in which references
 //     precede the pictures that use them -- so the wavelet-before-render and
 //     reference-before-dependent orderings of schrodecoder.c:1589-1660 hold by construction;
@@ -509,13 +509,20 @@ schro_hip_scheduler_submit (SchroHipScheduler * s, int picture_number, const int
     t.refs.push_back (it->second);
   }
   if (dev < 0) {
-    // a new chain: the device with the least work outstanding, ties to the lowest index
-    long best = -1;
+    // a new chain: the device with the least work outstanding; ties to the device that holds the fewest live references
+    // (their dependents are still to come: with fast workers two anchors in a row would both see idle devices), then to
+    // the lowest index
+    std::vector < long >live (s->devs.size (), 0);
+    for (const auto & o : s->owner)
+      if (!o.second->retired)
+        live[(size_t) o.second->device]++;
+    long best = -1, best_live = -1;
     for (int k = 0; k < (int) s->devs.size (); k++) {
       const long load = s->devs[k].submitted - s->devs[k].finished;
-      if (dev < 0 || load < best) {
+      if (dev < 0 || load < best || (load == best && live[(size_t) k] < best_live)) {
         dev = k;
         best = load;
+        best_live = live[(size_t) k];
       }
     }
   }

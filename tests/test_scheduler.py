@@ -282,3 +282,19 @@ def test_both_references_the_same_foreign_picture():
     s.retire(50)
     s.wait()
     s.close()
+
+
+def test_a_new_chain_goes_to_the_device_with_fewer_live_references():
+    """r05: two anchors in a row with workers fast enough that both devices are idle at every submit -- the second
+    chain still goes to the other device (its dependents are still to come), and a retired reference does not count."""
+    s = sa.Scheduler(2, virtual=True)
+    d0, _ = s.submit(0, [], True, lambda c, i: 0)
+    assert s.wait() == 0                                     # nothing outstanding anywhere
+    d1, _ = s.submit(10, [], True, lambda c, i: 0)
+    assert s.wait() == 0
+    assert d0 != d1
+    s.retire(0)
+    d2, _ = s.submit(20, [], True, lambda c, i: 0)           # device d0 holds no live reference any more
+    assert s.wait() == 0
+    assert d2 == d0
+    s.close()
