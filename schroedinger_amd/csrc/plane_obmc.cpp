@@ -520,45 +520,64 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       continue;
     }
     // r05: a row launch's weight tables, one per block geometry among its jobs (nearly always one), made here instead of
-    // by every tile; the jobs name theirs in `ipw` (a field of the item kernels, which these launches do not use)
-    void *d_wtabs = nullptr;
-    if (row) {
-      const size_t words = (size_t) obmc_row_weight_words (nd);
-      std::vector < uint32_t > tabs, one (words);
-      for (ObmcJob & j : jobs) {
-        obmc_row_weight_table (j, nd, uv, one.data ());
-        size_t k = 0;
-        while (k * words < tabs.size () && memcmp (&tabs[k * words], one.data (), words * 4))
-          k++;
-        if (k * words == tabs.size ()) {
-          if ((k + 1) * words * 4 > SchroHipContext::kArgSlotBytes)
-            return set_error (SCHRO_HIP_EINVAL, "obmc_batch: more than %zu block geometries in one launch", k);
-          tabs.insert (tabs.end (), one.begin (), one.end ());
+    // by every tile; the jobs name theirs in `ipw` (a field of the item kernels, which these launches do not use).  A
+    // group with more geometries than a table slot holds (35 .. 48) goes out in several launches.
+    std::vector < ObmcJob > all_jobs;
+    all_jobs.swap (jobs);
+    const int all_tiles = tile_base;
+    int r = 0;
+    for (size_t first_job = 0; first_job < all_jobs.size () && !r;) {
+      void *d_wtabs = nullptr;
+      size_t end_job = all_jobs.size ();
+      std::vector < uint32_t > tabs;
+      if (row) {
+        const size_t words = (size_t) obmc_row_weight_words (nd);
+        std::vector < uint32_t > one (words);
+        for (size_t n = first_job; n < end_job; n++) {
+          ObmcJob & j = all_jobs[n];
+          obmc_row_weight_table (j, nd, uv, one.data ());
+          size_t k = 0;
+          while (k * words < tabs.size () && memcmp (&tabs[k * words], one.data (), words * 4))
+            k++;
+          if (k * words == tabs.size ()) {
+            if ((k + 1) * words * 4 > SchroHipContext::kArgSlotBytes) {
+              end_job = n;      // (this job starts the next launch)
+              break;
+            }
+            tabs.insert (tabs.end (), one.begin (), one.end ());
+          }
+          j.ipw = (int) k;
         }
-        j.ipw = (int) k;
+        r = push_args (ctx, tabs.data (), tabs.size () * 4, &d_wtabs);
+        if (r)
+          return r;
       }
-      int rw = push_args (ctx, tabs.data (), tabs.size () * 4, &d_wtabs);
-      if (rw)
-        return rw;
-    }
-    void *d_jobs;
-    int r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
-    if (r)
-      return r;
-    const uint32_t *d_order;
-    r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order, row ? (uv ? 1 : 0) : -1);
-    if (r)
-      return r;
+      // this launch's jobs, their tiles counted from its first one
+      jobs.assign (all_jobs.begin () + (long) first_job, all_jobs.begin () + (long) end_job);
+      const int base = jobs.front ().tile_base;
+      tile_base = (end_job < all_jobs.size () ? all_jobs[end_job].tile_base : all_tiles) - base;
+      for (ObmcJob & j : jobs)
+        j.tile_base -= base;
+      first_job = end_job;
+      void *d_jobs;
+      r = push_args (ctx, jobs.data (), sizeof (ObmcJob) * jobs.size (), &d_jobs);
+      if (r)
+        return r;
+      const uint32_t *d_order;
+      r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order, row ? (uv ? 1 : 0) : -1);
+      if (r)
+        return r;
 #ifndef SCHRO_HIP_EXPERIMENTS
-    if (row && !d_order)        // (the product's row kernels take their tiles from the table only)
-      return set_error (SCHRO_HIP_EINVAL, "obmc_batch: no tile table for a row launch of %zu jobs", jobs.size ());
+      if (row && !d_order)      // (the product's row kernels take their tiles from the table only)
+        return set_error (SCHRO_HIP_EINVAL, "obmc_batch: no tile table for a row launch of %zu jobs", jobs.size ());
 #endif
-    if (g_stamps)               // scratch runs: the dump describes the last launch only
-      (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
-    {
-      ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-      r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
-          : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
+      if (g_stamps)             // scratch runs: the dump describes the last launch only
+        (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
+      {
+        ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
+        r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
+            : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
+      }
     }
     if (r)
       return r;

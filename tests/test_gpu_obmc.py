@@ -289,3 +289,38 @@ def test_more_than_1024_blocks_meet_a_tile(ctx):
         run_case(ctx, 244, 150, 8, 4, prec, (1, 1, 1), (1, 1), 20 << prec, 47753)
         run_case(ctx, 260, 136, 8, 4, prec, (1, 1, 1), (1, 0), 20 << prec, 11, pair=prec > 0)
     run_case(ctx, 250, 140, 4, 4, 0, (1, 1, 1), (1, 1), 16, 3)
+
+
+def test_more_block_geometries_in_a_call_than_a_table_slot_holds(ctx):
+    """r05: the row kernels copy their weight table in from a table the host makes per block geometry (one slot of 64 KB per
+    launch: 35 tables of 16-pixel rows).  48 luma planes of 48 different geometries in ONE call go out in two launches."""
+    w, h, prec = 72, 56, 2
+    geos = [(16, xbsep, yblen, ybsep) for xbsep in (8, 12, 16) for ybsep in (4, 8, 12, 16, 20, 24, 28, 32)
+            for yblen in range(ybsep, min(2 * ybsep, 32) + 1, 4)][:48]
+    assert len(set(geos)) == 48
+    r1, r2 = synth.picture_u8(h, w, seed=3), synth.picture_u8(h, w, seed=4)
+    u1, u2 = O.UpComp(r1, upsample=True), O.UpComp(r2, upsample=True)
+    p1, p2 = ctx.upload(r1), ctx.upload(r2)
+    g1, g2 = ctx.hp_plane(h, w), ctx.hp_plane(h, w)
+    ctx.upsample_batch([(p1, g1), (p2, g2)])
+    jobs, want, keep = [], [], [p1, p2, g1, g2]
+    for n, (xblen, xbsep, yblen, ybsep) in enumerate(geos):
+        P = synth.motion_params(w, h, xblen, xbsep, prec, (1, 1, 1), (1, 1), yblen=yblen, ybsep=ybsep)
+        mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24, 100 + n)
+        res = synth.image_s(h, w, np.int16, seed=200 + n)
+        d_mv, d_res, out = ctx.upload_bytes(mv), ctx.upload(res), ctx.plane(h, w, np.uint8).fill(0x44)
+        jobs.append(sa.obmc_plane(d_mv, P, 0, g1, g2, d_res, out))
+        want.append((O.motion_render(mv, O.MotionParams(**P), 0, u1, u2, res, w, h), out, (xblen, yblen, ybsep)))
+        keep += [d_mv, d_res, out]
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    ctx.obmc_batch(jobs)
+    ctx.synchronize()
+    launches = ctx.profile_read()["obmc"][1]
+    ctx.profile_enable(False)
+    # (38 of the geometries take the 16-pixel row kernel -- 35 + 3 --, the ten with the most rows per tile the item kernel)
+    assert launches >= 3, launches
+    for ref, out, geo in want:
+        assert np.array_equal(out.download(), ref), geo
+    for p in keep:
+        p.free()
