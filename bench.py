@@ -325,13 +325,14 @@ def cpu_baseline(wl, cores, reps=10, check=True):
 
 
 def coherent_motion_field(nbx, nby, seed):
-    """A smooth field -- a pan plus a slow zoom, different for the two references -- with +-2 quarter-pels of
-    noise per block and the headline's mode mix: what a real encoder's vectors look like to the gather, next to
-    the headline's independent-per-block worst case."""
+    """A smooth field -- a pan plus a slow zoom, different for the two references -- with -2 .. +1 quarter-pels of
+    noise per block (every quarter-pel phase equally often: the headline's 2.25 taps per window, so that the figure
+    differs from the headline by the windows' locality alone) and the headline's mode mix: what a real encoder's
+    vectors look like to the gather, next to the headline's independent-per-block worst case."""
     mv = synth.motion_field(nbx, nby, 64, seed=seed)
     mode = mv["flags"] & 3
     yy, xx = np.divmod(np.arange(nbx * nby), nbx)
-    n = synth.lcg(4 * nbx * nby, 77 + seed).reshape(4, -1) % 5 - 2
+    n = synth.lcg(4 * nbx * nby, 77 + seed).reshape(4, -1) % 4 - 2
     vec = np.stack([5 + xx // 64 + n[0], -7 + xx // 48 + n[1], 3 + yy // 64 + n[2], 9 - yy // 48 + n[3]], 1).astype(np.int16)
     mv["v"] = np.where((mode == 0)[:, None], mv["v"], vec)
     return mv
@@ -383,7 +384,7 @@ def coherent_motion(wl, steps=24):
         d.free()
     return {"ms_per_step": round(dt * 1e3, 4), "Mpix_per_s": round(wl.frames * W * H / dt / 1e6, 1),
             "obmc_ms_per_step": round(prof["obmc"][0] / 3, 4),
-            "vectors": "a pan + a slow zoom per reference, +-2 quarter-pels of noise per block, the headline's mode mix",
+            "vectors": "a pan + a slow zoom per reference, -2 .. +1 quarter-pels of noise per block (all phases equally often), the headline's mode mix",
             "note": "secondary figure, outside the timed region: the headline's vectors are independent per block "
                     "(uniform in +-16 pel), the worst case for the gather"}
 

@@ -111,3 +111,7 @@ def test_coherent_motion_field_keeps_the_mode_mix():
     # neighbours differ by the noise (+-2 quarter-pels) and the zoom's step, not by +-64
     d = np.abs(np.diff(b["v"].astype(int).reshape(nby, nbx, 4)[:, :, 0], axis=1))[~dc.reshape(nby, nbx)[:, 1:] & ~dc.reshape(nby, nbx)[:, :-1]]
     assert d.max() <= 5 and abs(v).max() < 64
+    # every quarter-pel phase equally often (the headline's tap mix)
+    for c in range(4):
+        share = np.bincount(v[:, c] & 3, minlength=4) / len(v)
+        assert share.min() > 0.2 and share.max() < 0.3, (c, share)
