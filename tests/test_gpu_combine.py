@@ -289,3 +289,46 @@ def test_depth_one_call_with_an_unaligned_ll_plane_takes_the_scratch_route(ctx):
         out.free()
     for p in (d_co, ll_al, wide):
         p.free()
+
+
+def test_predictions_alone_over_random_geometries(ctx):
+    """r05: the prediction-only row kernels store (sum + 32) >> 6 without a clamp where no DC value is wide -- the weights
+    over a pixel add up to 64 wherever it lies, folded rims included.  Random sizes, block sets, precisions and chroma
+    formats; the u8 prediction itself against the oracle's render of a zero residual."""
+    rng = np.random.default_rng(77)
+    blocks = [(8, 4), (12, 8), (16, 8), (16, 12), (8, 8), (4, 4)]
+    for n in range(24):
+        w, h = int(rng.integers(3, 40)) * 8 + int(rng.integers(0, 8)), int(rng.integers(3, 30)) * 4 + int(rng.integers(0, 4))
+        xblen, xbsep = blocks[int(rng.integers(0, len(blocks)))]
+        prec = int(rng.integers(1, 3))
+        chroma = [(1, 1), (1, 0), (0, 0)][int(rng.integers(0, 3))]
+        P = synth.motion_params(w, h, xblen, xbsep, prec, (1, 1, 1), chroma)
+        mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, 300 + n)
+        d_mv = ctx.upload_bytes(mv)
+        dims = [(h, w)] + [(-(-h // (1 << chroma[1])), -(-w // (1 << chroma[0])))] * 2
+        refs_np = [[synth.picture_u8(ph, pw, seed=400 + 10 * r + k + n) for k, (ph, pw) in enumerate(dims)] for r in range(2)]
+        pair = chroma[0] == 1
+        hp, keep = [], [d_mv]
+        for r in range(2):
+            g0 = ctx.hp_plane(*dims[0])
+            ctx.upsample_batch([(ctx.upload(refs_np[r][0]), g0)])
+            if pair:
+                gp = ctx.hp_plane(*dims[1], pair=True)
+                ctx.upsample_batch([((ctx.upload(refs_np[r][1]), ctx.upload(refs_np[r][2])), gp)])
+                hp.append([g0, gp, gp])
+                keep += [g0, gp]
+            else:
+                g1, g2 = ctx.hp_plane(*dims[1]), ctx.hp_plane(*dims[2])
+                ctx.upsample_batch([(ctx.upload(refs_np[r][1]), g1), (ctx.upload(refs_np[r][2]), g2)])
+                hp.append([g0, g1, g2])
+                keep += [g0, g1, g2]
+        preds = [ctx.plane(ph, pw, np.uint8).fill(0xa1) for (ph, pw) in dims]
+        ctx.obmc_batch([sa.obmc_plane(d_mv, P, k, hp[0][k], hp[1][k], None, preds[k], prediction_only=True) for k in range(3)])
+        ctx.synchronize()
+        for k, (ph, pw) in enumerate(dims):
+            want = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=True),
+                                   O.UpComp(refs_np[1][k], upsample=True), np.zeros((ph, pw), np.int16), pw, ph)
+            got = preds[k].download()
+            assert np.array_equal(got, want), (n, w, h, xblen, xbsep, prec, chroma, k, int((got != want).sum()))
+        for p in keep + preds:
+            p.free()
