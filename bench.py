@@ -61,7 +61,12 @@ class BatchSet:
         # SCHRO_BENCH_PAIR=0: an image per chroma plane, the r03 form)
         pair = os.environ.get("SCHRO_BENCH_PAIR", "1") != "0"
         (ch, cw) = dims[1]
-        if pair:
+        if wl.prec == 0:
+            # full pel (r06): the references are the plain planes themselves -- no half-pel images, no upsample stage
+            # (schrodecoder.c:1596-1601)
+            self.hp = [[list(wl.ref[g][r]) for r in range(2)] for g in range(wl.groups)]
+            self.up_luma, self.up_chroma = [], []
+        elif pair:
             self.hp = [[[ctx.hp_plane(*dims[0])] + [ctx.hp_plane(ch, cw, pair=True)] * 2 for _ in range(2)] for _ in range(wl.groups)]
             self.up_luma = [(wl.ref[g][r][0], self.hp[g][r][0]) for g in range(wl.groups) for r in range(2)]
             self.up_chroma = [((wl.ref[g][r][1], wl.ref[g][r][2]), self.hp[g][r][1]) for g in range(wl.groups) for r in range(2)]
@@ -78,30 +83,35 @@ class BatchSet:
         self.iwt_combine, self.pred_jobs, self.iwt_coarse, self.iwt_ll = [], [], [], []
         self.coeff_np, self.mv_np, self.out, self.mv_dev = [], [], [], []
         nmv = 20 * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
-        self.co_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in dims] * wl.frames))
+        # (coefficient planes are padded to the transform's multiple of 2^depth: 1080p chroma 540 -> 544 rows)
+        pad = lambda n: -(-n // (1 << DEPTH)) * (1 << DEPTH)
+        cdims = [(pad(h), pad(w)) for (h, w) in dims]
+        self.co_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.int16) for d in cdims] * wl.frames))
         self.out_arena = sa.Arena(ctx, sa.Arena.size_of([(d, np.uint8) for d in dims] * wl.frames))
         self.mv_arena = sa.Arena(ctx, sa.Arena.size_of([((1, nmv), np.uint8)] * wl.frames))
         base = {}
         for f in range(wl.frames):
-            mv = synth.motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 64, seed=seed + 2 + f)
+            # (vectors uniform in +-16 pel, independently per block -- 64 quarter pels)
+            mv = synth.motion_field(wl.P["x_num_blocks"], wl.P["y_num_blocks"], 16 << wl.prec, seed=seed + 2 + f)
             d_mv = self.mv_arena.plane(1, nmv, np.uint8).upload(np.ascontiguousarray(mv).view(np.uint8).reshape(1, -1))
             self.mv_np.append(mv)
             self.mv_dev.append(d_mv)
             co_f, out_f = [], []
             for k, (h, w) in enumerate(dims):
                 key = (k, f % 4)        # 4 distinct coefficient sets, uploaded to distinct buffers
+                ih, iw = cdims[k]
                 if key not in base:
-                    base[key] = coeff_plane(h, w, seed + 7 * f + k)
+                    base[key] = coeff_plane(ih, iw, seed + 7 * f + k)
                 co = base[key]
-                d_co = self.co_arena.plane(h, w, np.int16).upload(co)
-                d_res = ctx.plane(h, w, np.int16)
+                d_co = self.co_arena.plane(ih, iw, np.int16).upload(co)
+                d_res = ctx.plane(ih, iw, np.int16)
                 out = self.out_arena.plane(h, w, np.uint8)
                 self.iwt_pairs.append((d_co, d_res))
                 if self.combine:
                     d_pred = ctx.plane(h, w, np.uint8)
                     self.iwt_combine.append((d_co, out, d_pred))
                     # the transform in two calls (SchroHipIwtPlane.ll): the levels above 0 into an LL plane ...
-                    d_ll = ctx.plane(h // 2, w // 2, np.int16)
+                    d_ll = ctx.plane(ih // 2, iw // 2, np.int16)
                     self.iwt_coarse.append((d_co.level_view(1), d_ll))
                     self.iwt_ll.append(d_ll)
                 g = min(f // REF_GROUP, wl.groups - 1)
@@ -126,11 +136,14 @@ class Workload:
     are the decoder's stage dependencies (OBMC after its wavelet; a batch's frames are rewritten
     only after the OBMC that read them)."""
 
-    def __init__(self, ctx, frames, seed, queues=2):
+    def __init__(self, ctx, frames, seed, queues=2, w=W, h=H, xblen=XBLEN, xbsep=XBSEP, prec=PREC):
+        """w .. prec (r06): the headline's configuration by default; the other pictures a decoder meets -- 1080p, the
+        reference encoder's default full-pel vectors, eighth pel, the 24 / 16 block set -- run the same step."""
         self.ctx, self.frames, self.queues = ctx, frames, queues
         self.combine = os.environ.get("SCHRO_BENCH_COMBINE", "1") != "0"
-        self.P = synth.motion_params(W, H, XBLEN, XBSEP, PREC, (1, 1, 1), (1, 1))
-        dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+        self.w, self.h, self.prec = w, h, prec
+        self.P = synth.motion_params(w, h, xblen, xbsep, prec, (1, 1, 1), (1, 1))
+        dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
         self.dims = dims
         # two references (planar u8) per group of REF_GROUP pictures, shared by the batches as between two
         # anchors of a GOP: the work per picture does not depend on the batch size (2 reference
@@ -198,9 +211,11 @@ class Workload:
                 c.iiwt_batch(b.iwt_coarse, DEPTH - 1, FILTER)
                 c.queue_mark(8 + s)
                 c.select_queue(s)
-            c.upsample_batch(b.up_luma)
+            if b.up_luma:
+                c.upsample_batch(b.up_luma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3 == 0])
-            c.upsample_batch(b.up_chroma)
+            if b.up_chroma:
+                c.upsample_batch(b.up_chroma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
             if split:
                 c.queue_wait_mark(8 + s)
@@ -387,6 +402,68 @@ def coherent_motion(wl, steps=24):
             "vectors": "a pan + a slow zoom per reference, -2 .. +1 quarter-pels of noise per block (all phases equally often), the headline's mode mix",
             "note": "secondary figure, outside the timed region: the headline's vectors are independent per block "
                     "(uniform in +-16 pel), the worst case for the gather"}
+
+
+def check_picture(wl, s=0, f=0):
+    """Picture f of batch set s as the device holds it against the oracle (checker only)."""
+    import oracle_lib as O
+    b = wl.sets[s]
+    g = min(f // REF_GROUP, wl.groups - 1)
+    for k, (h, w) in enumerate(wl.dims):
+        res = O.inverse_iwt(b.coeff_np[f][k], DEPTH, FILTER)
+        u = [O.UpComp(wl.ref_np_all[g][r][k], upsample=wl.prec > 0) for r in range(2)]
+        want = O.motion_render(b.mv_np[f], O.MotionParams(**wl.P), k, u[0], u[1], res, w, h)
+        if not np.array_equal(b.out[f][k].download(), want):
+            return False
+    return True
+
+
+def decode_variant(device, frames=8, steps=24, check=True, **geom):
+    """The headline's step on another kind of picture (outside the timed region, a context of its own): the whole pixel
+    path -- upsample where the precision has one, OBMC prediction, 3-level DD(9,7) transform with the add -- two batches in
+    flight, the classes' times from per-launch events of three steps that run alone, the OBMC class against ITS
+    algorithmic bytes (1 B written + 1 B per reference used per sample + 20 B per block), one picture against the oracle."""
+    import schroedinger_amd as sa
+    c = sa.Context(device)
+    try:
+        wl = Workload(c, frames, seed=4242, queues=2, **geom)
+        for _ in range(8):
+            wl.step()
+        c.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        c.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        c.profile_enable(True)
+        c.profile_reset()
+        for _ in range(3):
+            wl.step(alone=True)
+        c.synchronize()
+        prof = c.profile_read()
+        c.profile_enable(False)
+        w, h = wl.w, wl.h
+        samples = frames * (w * h * 3 // 2)
+        modes = np.concatenate([m["flags"] & 3 for m in wl.mv_np])
+        refs_per_px = float(((modes == 1) | (modes == 2)).mean() + 2 * (modes == 3).mean())
+        obmc_bytes = int((1 + refs_per_px) * samples) + 20 * frames * wl.P["x_num_blocks"] * wl.P["y_num_blocks"]
+        obmc_ms = prof["obmc"][0] / 3
+        out = {"ms_per_step": round(dt * 1e3, 4), "Mpix_per_s": round(frames * w * h / dt / 1e6, 1),
+               "pictures_per_step": frames, "width": w, "height": h,
+               "blocks": "%dx%d / %dx%d" % (wl.P["xblen_luma"], wl.P["yblen_luma"], wl.P["xbsep_luma"], wl.P["ybsep_luma"]),
+               "mv_precision": wl.prec,
+               "obmc_ms_per_step": round(obmc_ms, 4),
+               "obmc_alg_bytes_per_step": obmc_bytes,
+               "obmc_frac_of_8TBs": round(obmc_bytes / (obmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "classes_ms_per_step": {k: round(prof[k][0] / 3, 4) for k in ("obmc", "iiwt_finest", "iiwt_coarse", "upsample")
+                                       if prof[k][1]}}
+        if check:
+            wl.step()               # (the steps above left set 1's pictures last: both sets hold their outputs anyway)
+            c.synchronize()
+            out["parity"] = "bit-exact vs oracle (picture 0)" if check_picture(wl) else "MISMATCH vs oracle (picture 0)"
+        return out
+    finally:
+        c.close()
 
 
 def cpu_model():
@@ -1285,6 +1362,18 @@ def main():
         if world == 1 and not args.headline_only:
             wl.queues = args.queues
             out["coherent_motion"] = coherent_motion(wl)
+            # r06: the other pictures a decoder meets, each through the whole path: full-pel
+            # vectors on plain references (the reference encoder's default: no upsample stage), eighth pel, the 24 / 16
+            # block set, and 1080p with 8 and 32 pictures per step
+            dev = ctx.device
+            out["fullpel_2160p"] = decode_variant(dev, prec=0)
+            out["eighthpel_2160p"] = decode_variant(dev, prec=3)
+            out["blocks_24_16_2160p"] = decode_variant(dev, xblen=24, xbsep=16)
+            out["decode_1080p"] = decode_variant(dev, w=1920, h=1080)
+            out["decode_1080p"]["pictures_32_per_step"] = decode_variant(dev, frames=32, w=1920, h=1080, check=False)
+            if any(str(out[k].get("parity", "")).startswith("MISMATCH") for k in
+                   ("fullpel_2160p", "eighthpel_2160p", "blocks_24_16_2160p", "decode_1080p")):
+                out["parity_variants"] = "MISMATCH"
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share
             v, checked, equal, single = cpu_baseline(wl, cores)
@@ -1333,7 +1422,7 @@ def main():
                     "host_enqueue_ms_per_step": alt["host_enqueue_ms_per_step"]}
             out["lowdelay_8k"] = lowdelay_8k(ctx)
         print(json.dumps(out))
-        if out.get("parity", "").startswith("MISMATCH"):
+        if out.get("parity", "").startswith("MISMATCH") or out.get("parity_variants") == "MISMATCH":
             sys.exit(1)
     if dist is not None:
         dist.barrier()

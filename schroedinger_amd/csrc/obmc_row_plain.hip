@@ -1,0 +1,55 @@
+// obmc_row_plain.hip -- the row formulation of OBMC (obmc_row_body.h, RK 0) on PLAIN planar references: mv_precision 0,
+// the reference encoder's default (schroencoder.c:4488) and its own test stream's (testsuite/test_stream.drc).  No
+// upsample stage runs for such pictures (schrodecoder.c:1596-1601): the references are the decoder's pictures as
+// they are, one plane per component, and a window row is one dword-aligned run of one plane.
+//
+// References: schromotion8.c:303-335 (get_block), schroframe.c:2111-2122 (prec 0), :1940-1998 (the aprons the
+// reference's frames carry, here the edge class's clamps).
+
+#include "obmc_row_body.h"
+
+namespace schro {
+namespace {
+
+// (waves per SIMD: as obmc_row.hip's kernels of the same shape; one tap per window: fewer registers in flight)
+SCHRO_ROW_KERNEL (obmc_row_plain_2_1, 6, 2, 1, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_2_2, 6, 2, 2, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_3_1, 7, 3, 1, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_3_2, 5, 3, 2, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_4_1, 4, 4, 1, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_4_2, 4, 4, 2, false, kRTH, false, 0)
+// prediction_only launches (the combine form): the U and V planes of a picture are two plain planes, one job
+SCHRO_ROW_KERNEL (obmc_row_plain_p_2_1, 6, 2, 1, false, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_2_2, 6, 2, 2, false, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_3_1, 8, 3, 1, false, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_4_1, 4, 4, 1, false, kRTH, true, 0)
+// the 24 / 16 block set's luma rows: two segments of 12
+SCHRO_ROW_KERNEL (obmc_row_plain_h2_3_1, 6, 3, 1, false, kRTH, false, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_3_1, 7, 3, 1, false, kRTH, true, 0, 2)
+
+}                               // namespace
+
+RowKernel
+obmc_row_kernel_plain (int nd, int np, int ns, bool nores)
+{
+  if (ns == 2)
+    return nd == 3 && np == 1 ? (nores ? obmc_row_plain_p_h2_3_1 : obmc_row_plain_h2_3_1) : nullptr;
+  if (nores)
+    switch (nd * 10 + np) {
+      case 21: return obmc_row_plain_p_2_1;
+      case 22: return obmc_row_plain_p_2_2;
+      case 31: return obmc_row_plain_p_3_1;
+      case 41: return obmc_row_plain_p_4_1;
+    }
+  switch (nd * 10 + np) {
+    case 21: return obmc_row_plain_2_1;
+    case 22: return obmc_row_plain_2_2;
+    case 31: return obmc_row_plain_3_1;
+    case 32: return obmc_row_plain_3_2;
+    case 41: return obmc_row_plain_4_1;
+    case 42: return obmc_row_plain_4_2;
+  }
+  return nullptr;
+}
+
+}                               // namespace schro

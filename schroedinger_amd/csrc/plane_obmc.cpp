@@ -131,7 +131,7 @@ schro_hip_obmc_stamps_dump (void)
 
 static int
 obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int variant, int total,
-    const uint32_t ** d_order, int row_uv = -1)  // row_uv >= 0: a row launch (1: of (U, V) pairs) -- FOUR words per tile, obmc_row_tile_record
+    const uint32_t ** d_order, int row_uv = -1, int row_ns = 1)     // row_uv >= 0: a row launch (1: of (U, V) pairs; row_ns: segments per block row) -- FOUR words per tile, obmc_row_tile_record
 {
   *d_order = nullptr;
   static const bool enabled = !SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER") || atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_ORDER")) != 0;
@@ -163,7 +163,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
     mix ((uint64_t) first);
     if (row) {                  // (what the tiles' records are made of)
       const ObmcJob & g = jobs[j];
-      mix ((uint64_t) g.w | ((uint64_t) g.h << 20) | ((uint64_t) row_uv << 40) | (1ull << 41));
+      mix ((uint64_t) g.w | ((uint64_t) g.h << 20) | ((uint64_t) row_uv << 40) | (1ull << 41) | ((uint64_t) row_ns << 42));
       mix ((uint64_t) g.xbsep | ((uint64_t) g.ybsep << 8) | ((uint64_t) g.xblen << 16) | ((uint64_t) g.yblen << 24) | ((uint64_t) g.xoff << 32)
           | ((uint64_t) g.yoff << 40));
       mix ((uint64_t) g.nbx | ((uint64_t) g.nby << 20));
@@ -276,7 +276,7 @@ obmc_tile_order (SchroHipContext * ctx, const std::vector < ObmcJob > &jobs, int
       if (row) {
         const ObmcJob & g = jobs[keys[k].entry >> 16];
         const int t = (int) (keys[k].entry & 0xffffu);
-        obmc_row_tile_record (g, row_uv != 0, t % g.tiles_x, t / g.tiles_x, &slot->h[k * words + 1]);
+        obmc_row_tile_record (g, row_uv != 0, row_ns, t % g.tiles_x, t / g.tiles_x, &slot->h[k * words + 1]);
       }
     }
     SCHRO_HIP_CHECK (hipMemcpyAsync (slot->d, slot->h, keys.size () * words * sizeof (uint32_t), hipMemcpyHostToDevice,
@@ -302,12 +302,12 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   auto variant_of = [](const SchroHipObmcPlane & pl) {
     return (pl.picture_weight_1 == 1 && pl.picture_weight_2 == 1 && pl.picture_weight_bits == 1) ? 1 : 0;
   };
-  // default weights, half- / quarter-pel references and blocks up to 16 wide: the row kernel
-  // (obmc_row.hip); SCHRO_HIP_OBMC_KERNEL=item sends them to obmc.hip's item kernel (A/B runs: the
-  // second formulation the parity tests compare)
+  // default weights and blocks up to 16 wide (r06: or 24, as two segments), references of any precision (r06: plain
+  // planes at full pel, eighth pel): the row kernels (obmc_row*.hip); SCHRO_HIP_OBMC_KERNEL=item sends them to obmc.hip's
+  // item kernel (A/B runs: the second formulation the parity tests compare)
   static const bool use_row = !SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL") || strcmp (SCHRO_ENV ("SCHRO_HIP_OBMC_KERNEL"), "row") == 0;
   std::vector < ObmcJob > all (nplanes);
-  std::vector < int >key (nplanes), row_nd (nplanes);
+  std::vector < int >key (nplanes), row_nd (nplanes), row_ns (nplanes, 1);
   uint32_t pred_epoch = 0;      // (r05: this call's number among the context's prediction_only calls, once it has one)
   for (int p = 0; p < nplanes; p++) {
     const SchroHipObmcPlane & pl = planes[p];
@@ -384,9 +384,10 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
             "obmc_batch: plane %d: reference %d is not a half-pel image of this component (128-byte aligned, stride from "
             "schro_hip_upsampled_bytes / _pair_bytes)", p, r + 1);
     const int variant = variant_of (pl);
-    const int nd_row = (variant == 1 && use_row) ? obmc_row_nd (j, false) : 0;
+    const int nd_row = (variant == 1 && use_row) ? obmc_row_form (j, false, &row_ns[p]) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
-    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only ? 1 << 19 : 0);
+    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only ? 1 << 19 : 0)
+        | (nd_row ? row_ns[p] << 20 : 0);
     row_nd[p] = nd_row;
   }
   // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
@@ -413,15 +414,18 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // its component out of the pair images in obmc.hip
     if (a.ref_ps && b.ref_ps && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
         && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1] && !planes[p].prediction_only == !planes[p + 1].prediction_only) {
-      const int nd = obmc_row_nd (a, true);
+      int ns;
+      const int nd = obmc_row_form (a, true, &ns);
       if (nd) {
         row_nd[p] = row_nd[p + 1] = nd;
-        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only ? 1 << 19 : 0);
+        row_ns[p] = row_ns[p + 1] = ns;
+        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only ? 1 << 19 : 0) | (ns << 20);
         p++;
       }
       continue;
     }
-    if (pairs_pay && row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && same_blocks (a, b)) {
+    if (pairs_pay && row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && same_blocks (a, b)
+        && obmc_row_has_kernel (a.prec, row_nd[p], 2, row_ns[p])) {
       key[p] |= 1 << 17;
       key[p + 1] |= 1 << 17;
       p++;
@@ -440,6 +444,10 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         if (!done[p] && key[p] == key[first])
           nd = std::max (nd, row_nd[p]);
     const bool paired = (key[first] >> 17) & 1, uv = (key[first] >> 18) & 1, pred_only = (key[first] >> 19) & 1;
+    const int ns = row ? std::max (1, (key[first] >> 20) & 3) : 1;
+    // (two planes per job: every row length of the group needs the kernel)
+    SCHRO_HIP_REQUIRE (!row || obmc_row_has_kernel (prec, nd, uv ? 3 : paired ? 2 : 1, ns),
+        "obmc_batch: no row kernel for precision %d, %d dwords x %d segments per row, %s", prec, nd, ns, uv ? "(U, V) pairs" : paired ? "two planes per job" : "one plane per job");
     uint32_t *overflow = nullptr;
     if (pred_only) {
       if (!ctx->dc_gave_up) {
@@ -531,11 +539,11 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       size_t end_job = all_jobs.size ();
       std::vector < uint32_t > tabs;
       if (row) {
-        const size_t words = (size_t) obmc_row_weight_words (nd);
+        const size_t words = (size_t) obmc_row_weight_words (nd, ns);
         std::vector < uint32_t > one (words);
         for (size_t n = first_job; n < end_job; n++) {
           ObmcJob & j = all_jobs[n];
-          obmc_row_weight_table (j, nd, uv, one.data ());
+          obmc_row_weight_table (j, nd, ns, uv, one.data ());
           size_t k = 0;
           while (k * words < tabs.size () && memcmp (&tabs[k * words], one.data (), words * 4))
             k++;
@@ -564,7 +572,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       if (r)
         return r;
       const uint32_t *d_order;
-      r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order, row ? (uv ? 1 : 0) : -1);
+      r = obmc_tile_order (ctx, jobs, variant, tile_base, &d_order, row ? (uv ? 1 : 0) : -1, ns);
       if (r)
         return r;
 #ifndef SCHRO_HIP_EXPERIMENTS
@@ -575,7 +583,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
       {
         ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-        r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, nd, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
+        r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, nd, ns, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
             : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
       }
     }

@@ -466,8 +466,11 @@ void dequant_tables (int quant_index, int is_intra, uint32_t * factor, uint32_t 
 // overflow: NULL, or (prediction_only launches) the word a prediction that does not fit 8 bits is reported in
 int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
     int total_tiles, int prec, int variant, const uint32_t * d_order, uint32_t * overflow);
-// row kernel (obmc_row.hip): prediction dwords per block row, 0 = not its case
-int obmc_row_nd (const ObmcJob & job, bool uv);
+// row kernels (obmc_row*.hip): prediction dwords per block row and segment, *ns = segments per block row (1, 2);
+// 0 = not their case
+int obmc_row_form (const ObmcJob & job, bool uv, int *ns);
+// is there a kernel of `np` planes per job (1, 2; 3: (U, V) pairs from pair images) for this precision and form?
+bool obmc_row_has_kernel (int prec, int nd, int np, int ns);
 // obmc_strip.hip (r05): the register-accumulator form for the 12 / 8 block set
 bool obmc_strip_ok (const ObmcJob & j);
 void obmc_strip_tiles (const ObmcJob & j, int seg_rows, int *strips, int *segs);
@@ -475,13 +478,13 @@ int launch_obmc_strip (hipStream_t stream, const ObmcJob * d_jobs, int njobs, in
     int cus);
 int obmc_row_tile_width (bool uv);
 int obmc_row_tile_height ();
-int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int nd,
-    int max_planes, const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs);
+int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec, int nd, int ns,
+    int planes_per_job, const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs);
 // the weight table of a job's block geometry as the row kernels copy it into LDS (ObmcJob::ipw: its index in d_wtabs)
 // words 1 .. 3 of tile (tx, ty)'s record in a row launch's order table (word 0: job << 16 | tile)
-void obmc_row_tile_record (const ObmcJob & job, bool uv, int tx, int ty, uint32_t * rec);
-int obmc_row_weight_words (int nd);
-void obmc_row_weight_table (const ObmcJob & job, int nd, bool uv, uint32_t * out);
+void obmc_row_tile_record (const ObmcJob & job, bool uv, int ns, int tx, int ty, uint32_t * rec);
+int obmc_row_weight_words (int nd, int ns);
+void obmc_row_weight_table (const ObmcJob & job, int nd, int ns, bool uv, uint32_t * out);
 // fills the item-kernel geometry fields of a job (obmc.hip)
 void obmc_item_geometry (ObmcJob * job);
 void obmc_tiles (int variant, int w, int h, int xoff, int *tiles_x, int *tiles_y);
