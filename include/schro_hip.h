@@ -261,6 +261,12 @@ typedef struct {
 int schro_hip_convert_u8_batch (SchroHipContext * ctx,
     const SchroHipConvertPlane * planes, int nplanes, int bpp);
 
+/* r06 -- dst (int16) += src (int16 when src_bytes_per_sample is 2, uint8 zero-extended when 1), 16-bit wrapping add
+ * over width x height: schro_frame_add's two cases on planes (schroframe.c:1082-1135: orc_add_s16_2d,
+ * orc_add_s16_u8_2d) = schro_gpuframe_add's (schrogpuframe.c:257-306).  `dst` of the plane is the int16 plane. */
+int schro_hip_add_batch (SchroHipContext * ctx, const SchroHipConvertPlane * planes, int nplanes,
+    int src_bytes_per_sample);
+
 /* Copy-out of a decoded u8 picture into a packed output frame; replaces the
  * packed-destination case of schro_frame_convert (&output_picture, ref_output_frame)
  * in x_combine (schrodecoder.c:2011, 2052 -> schroframe.c:869-979): chroma
@@ -514,7 +520,11 @@ typedef struct {
                                  * required (else an error at the call), and a DC value outside [-128, 127] makes the
                                  * launch raise a flag: the next synchronising call of the context answers
                                  * SCHRO_HIP_ENEEDS_RESIDUAL and names the batch (such pictures need the
-                                 * residual form, which follows the reference's 16-bit wrap-around). */
+                                 * residual form, which follows the reference's 16-bit wrap-around).
+                                 * r06, 2: residual NULL, `out` is an int16 plane that receives (acc - 8160) >> 6 =
+                                 * the prediction - 128 in the reference's 16-bit arithmetic (orc_rrshift6_s16_ip_2d,
+                                 * schroorc.orc:676-682: what schro_motion_render (add = FALSE) leaves in its dest and
+                                 * schro_motion_render_cuda's contract): any weights, any DC values. */
 } SchroHipObmcPlane;
 
 int schro_hip_obmc_batch (SchroHipContext * ctx,
@@ -901,9 +911,20 @@ int schro_upsampled_hipframe_upsample_inplace (SchroHipFrame * frame);
  * nothing is read: schrodecoder.c:1904-1906); output_frame: device u8.  motion->motion_vectors: the
  * host array, or a device copy of it.  Global motion is not
  * supported (the reference routes it to a different renderer, schromotion.c:113-118)
- * -> SCHRO_HIP_EUNSUPPORTED. */
+ * -> SCHRO_HIP_EUNSUPPORTED.
+ * r06 -- add FALSE with an S16 device frame as `dest`: the literal contract of schro_motion_render_cuda (motion,
+ * mc_tmp_frame) (schrocuda.h:13; schrodecoder.c:1742-1760, where mc_tmp_frame is an S16 frame of the transform's padded
+ * size): dest receives the prediction - 128 in the reference's 16-bit arithmetic ((acc - 8160) >> 6,
+ * orc_rrshift6_s16_ip_2d / _sub_s16_2d's d2) over the area the references cover; any weights, any DC values, never
+ * SCHRO_HIP_ENEEDS_RESIDUAL.  schro_hipframe_add (picture->frame, mc_tmp_frame) and schro_hipframe_convert (output,
+ * picture->frame) then finish the picture exactly as the HAVE_CUDA branch does (:1908-1910, :2011). */
 int schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest,
     SchroHipFrame * addframe, int add, SchroHipFrame * output_frame);
+
+/* schro_gpuframe_add (dest, src) (schrogpuframe.h:18; call site schrodecoder.c:1908-1910) = schro_frame_add
+ * (schroframe.c:1000-1029) on device frames: dest (S16) += src (S16, or U8 zero-extended) of the same chroma format,
+ * 16-bit wrapping add over the components' common size.  Other depth pairs: SCHRO_HIP_EINVAL (the reference asserts). */
+int schro_hipframe_add (SchroHipFrame * dest, SchroHipFrame * src);
 
 /* schro_gpuframe_convert (schrogpuframe.h:20) replacement for the conversions the decode path
  * performs: s16/s32 -> u8 (+128, clamp, crop), u8 -> u8 copy, planar -> packed (YUYV, UYVY,

@@ -507,6 +507,16 @@ class Context:
             arr[k] = _lib.ConvertPlane(s.ptr, s.stride, d.ptr, d.stride, d.width, d.height)
         check(self.lib.schro_hip_convert_u8_batch(self.h, arr, n, bpp))
 
+    def add_batch(self, pairs):
+        """pairs: [(dst s16 DevicePlane, src s16 | u8 DevicePlane)]: dst += src over their common size
+        (schro_frame_add / schro_gpuframe_add on planes)."""
+        n = len(pairs)
+        arr = (_lib.ConvertPlane * n)()
+        for k, (d, s) in enumerate(pairs):
+            assert d.dtype == np.int16 and s.dtype.itemsize == pairs[0][1].dtype.itemsize
+            arr[k] = _lib.ConvertPlane(s.ptr, s.stride, d.ptr, d.stride, min(d.width, s.width), min(d.height, s.height))
+        check(self.lib.schro_hip_add_batch(self.h, arr, n, pairs[0][1].dtype.itemsize))
+
     def upsample_batch(self, pairs):
         """pairs: [(src u8 plane h x w, dst HpPlane)] or [((src U, src V), dst pair HpPlane)]."""
         n = len(pairs)
@@ -548,7 +558,8 @@ def obmc_plane(mvs, params, component, ref1, ref2, residual, out, prediction_onl
         p.residual_bpp = residual.dtype.itemsize
     p.out, p.out_stride = out.ptr, out.stride
     p.width, p.height = out.width, out.height
-    p.prediction_only = 1 if prediction_only else 0
+    # (prediction_only 2, r06: `out` is an s16 plane that receives the prediction - 128)
+    p.prediction_only = int(prediction_only)
     p.ref_pair = 1 if getattr(ref1, "pair", False) else 0      # (U, V) pair images (HpPlane (pair=True))
     assert ref2 is None or bool(getattr(ref2, "pair", False)) == bool(p.ref_pair)
     return p

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_upsampled_bytes", "schro_hip_upsampled_download", "schro_hip_upsampled_pair_bytes",
     "schro_hip_upsampled_pair_download", "schro_hip_pack_u8_batch",
     "schro_hip_pack_v210_batch", "schro_hip_iiwt_pack_v210_batch", "schro_hip_pack_wide_batch", "schro_hip_shift_right_batch",
-    "schro_hipframe_shift_right",
+    "schro_hipframe_shift_right", "schro_hip_add_batch", "schro_hipframe_add",
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
     "schro_hip_decode_lowdelay_transform_data", "schro_hipframe_dequantise",
@@ -362,6 +362,10 @@ def load():
     L.schro_hip_pack_wide_batch.restype = i
     L.schro_hipframe_shift_right.argtypes = [C.POINTER(Frame), i]
     L.schro_hipframe_shift_right.restype = i
+    L.schro_hip_add_batch.argtypes = [vp, C.POINTER(ConvertPlane), i, i]
+    L.schro_hip_add_batch.restype = i
+    L.schro_hipframe_add.argtypes = [C.POINTER(Frame), C.POINTER(Frame)]
+    L.schro_hipframe_add.restype = i
     L.schro_hip_dequant_batch.argtypes = [vp, C.POINTER(DequantPlane), i, i, i]
     L.schro_hip_dequant_batch.restype = i
     L.schro_hip_upsampled_bytes.argtypes = [i, i, C.POINTER(C.c_int)]

@@ -620,10 +620,16 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
   // add == FALSE (r04): the prediction alone into `dest`, a u8 device frame -- schro_motion_render_cuda (motion,
   // mc_tmp_frame) (schrodecoder.c:1759) --, for schro_frame_inverse_iwt_transform_combine_hip to add.  Else `dest`
   // is the CPU path's s16 scratch frame and not used: the accumulator lives in LDS here.
+  // r06: ... or an S16 device frame, which receives the prediction - 128 -- the literal contract of
+  // schro_motion_render_cuda (motion, mc_tmp_frame) (schrocuda.h:13, schrodecoder.c:1742-1760) and of the CPU call's
+  // add = FALSE (orc_rrshift6_sub_s16_2d's d2, schromotion8.c:896-899): schro_hipframe_add (frame, mc_tmp_frame) and
+  // schro_hipframe_convert then finish the picture as schrodecoder.c:1908-1910, 2011 do.  Any weights, any DC values.
+  bool s16_dest = false;
   if (!add) {
-    SCHRO_HIP_REQUIRE (dest && frame_ctx (dest) && format_bpp (dest->format) == 1 && !addframe,
-        "motion_render: add = FALSE renders the prediction into `dest`, a u8 device frame (addframe NULL)");
+    SCHRO_HIP_REQUIRE (dest && frame_ctx (dest) && (format_bpp (dest->format) == 1 || format_bpp (dest->format) == 2) && !addframe,
+        "motion_render: add = FALSE renders the prediction into `dest`, a u8 or s16 device frame (addframe NULL)");
     output_frame = dest;
+    s16_dest = format_bpp (dest->format) == 2;
   }
   // addframe NULL: nothing to add -- a zero_residual picture has no frame (schrodecoder.c:1800, :1861,
   // :1904-1906: the GPU paths take mc_tmp_frame as the combined frame); the prediction alone is clamped
@@ -655,7 +661,7 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
   // and wraps) is answered BEFORE anything is launched: SCHRO_HIP_ENEEDS_RESIDUAL, and the caller runs the picture in
   // the residual order (schrodecoder.c:1742-1760's stages the other way round: INTEGRATION 3).  Vectors that are already
   // on the device cannot be looked at here; the launch flags them (schro_hip_obmc_batch, prediction_only).
-  if (!add && (p->picture_weight_1 < 0 || p->picture_weight_2 < 0
+  if (!add && !s16_dest && (p->picture_weight_1 < 0 || p->picture_weight_2 < 0
           || p->picture_weight_1 + p->picture_weight_2 > (1 << p->picture_weight_bits)))
     return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "motion_render (add = FALSE): picture weights %d, %d / 2^%d can predict beyond 8 bits: "
         "this picture takes the residual order", p->picture_weight_1, p->picture_weight_2, p->picture_weight_bits);
@@ -665,7 +671,7 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
       d_mvs = motion->motion_vectors;
     } else {
       (void) hipGetLastError ();        // (an ordinary host pointer is "invalid value" to the query)
-      if (!add) {
+      if (!add && !s16_dest) {
         // SchroMotionVector (schromotion.h:53-75): pred_mode in the two low bits of the first word, the DC
         // values as three int16 at byte 12.  (Blocks on the picture's rim store their DC as a uint8_t and would
         // fit; they are refused with the rest -- the residual order is exact for every picture.)
@@ -721,8 +727,13 @@ schro_motion_render_hip (SchroHipMotion * motion, SchroHipFrame * dest, SchroHip
     pl.out_stride = output_frame->components[k].stride;
     pl.width = output_frame->components[k].width;
     pl.height = output_frame->components[k].height;
+    if (s16_dest) {
+      // (the reference hands over a frame of the transform's padded size; the picture is what the references cover)
+      pl.width = std::min (pl.width, motion->src1->components[k].width);
+      pl.height = std::min (pl.height, motion->src1->components[k].height);
+    }
     pl.ref_pair = k && motion->src1->is_upsampled == 2;
-    pl.prediction_only = add ? 0 : 1;
+    pl.prediction_only = add ? 0 : s16_dest ? 2 : 1;
   }
   return stage_done (ctx, schro_hip_obmc_batch (ctx, planes, 3));
 }
@@ -783,6 +794,30 @@ schro_hipframe_convert (SchroHipFrame * dest, SchroHipFrame * src)
   }
   return set_error (SCHRO_HIP_EUNSUPPORTED, "hipframe_convert: depth %d -> %d is not on the decode path",
       sb, db);
+}
+
+// schro_gpuframe_add (dest, src) (schrogpuframe.h:18, call site schrodecoder.c:1908-1910) = schro_frame_add
+// (schroframe.c:1000-1029): dest (s16) += src (s16 | u8) over the components' common size
+int
+schro_hipframe_add (SchroHipFrame * dest, SchroHipFrame * src)
+{
+  SCHRO_HIP_REQUIRE (dest && src && frame_ctx (dest) && src->domain == dest->domain,
+      "hipframe_add: both frames must live in the same device domain");
+  SCHRO_HIP_REQUIRE (!(dest->format & 0x100) && !(src->format & 0x100) && format_bpp (dest->format) == 2
+      && (format_bpp (src->format) == 1 || format_bpp (src->format) == 2)
+      && SCHRO_HIP_FORMAT_H_SHIFT (dest->format) == SCHRO_HIP_FORMAT_H_SHIFT (src->format)
+      && SCHRO_HIP_FORMAT_V_SHIFT (dest->format) == SCHRO_HIP_FORMAT_V_SHIFT (src->format),
+      "hipframe_add: s16 += s16 | u8 of the same chroma format (add function unimplemented, schroframe.c:1027)");
+  SchroHipConvertPlane planes[3];
+  for (int k = 0; k < 3; k++) {
+    planes[k].src = src->components[k].data;
+    planes[k].src_stride = src->components[k].stride;
+    planes[k].dst = (uint8_t *) dest->components[k].data;
+    planes[k].dst_stride = dest->components[k].stride;
+    planes[k].width = std::min (dest->components[k].width, src->components[k].width);
+    planes[k].height = std::min (dest->components[k].height, src->components[k].height);
+  }
+  return stage_done (frame_ctx (dest), schro_hip_add_batch (frame_ctx (dest), planes, 3, format_bpp (src->format)));
 }
 
 int

@@ -664,6 +664,50 @@ void shift_right_kernel (const ConvertJob * __restrict__ jobs, int njobs, int sh
   }
 }
 
+// schro_frame_add (schroframe.c:1000-1029, 1082-1135; schro_gpuframe_add, schrogpuframe.c:257-306): dst (s16) += src
+// (s16, or u8 zero-extended), 16-bit wrapping add -- orc_add_s16_2d / orc_add_s16_u8_2d (addw; convubw, addw).  8 samples
+// per lane; ConvertJob: src, dst the planes, w x h the common size.
+template < typename S >
+__global__ __launch_bounds__ (kThreads)
+void add_kernel (const ConvertJob * __restrict__ jobs, int njobs)
+{
+  typedef short s16x2 __attribute__ ((ext_vector_type (2)));
+  const int bid = blockIdx.x;
+  const ConvertJob job = jobs[find_job (jobs, njobs, bid)];
+  const int t = bid - job.tile_base;
+  const int ty = fdiv (t, job.tiles_x), tx = t - ty * job.tiles_x;
+  const int x = tx * kCvtTW + (threadIdx.x % 64) * 8;
+  const int y = ty * kCvtTH + threadIdx.x / 64;
+  if (y >= job.h || x >= job.w)
+    return;
+  int16_t *drow = (int16_t *) (job.dst + (size_t) y * job.dst_stride) + x;
+  const S *srow = (const S *) ((const char *) job.src + (size_t) y * job.src_stride) + x;
+  if (x + 8 <= job.w && (((uintptr_t) drow) & 15) == 0 && (((uintptr_t) srow) & (8 * sizeof (S) - 1)) == 0) {
+    const u32x4 d = gload < u32x4 > (drow);
+    uint32_t dv[4] = { d.x, d.y, d.z, d.w }, av[4];
+    if constexpr (sizeof (S) == 2) {
+      const u32x4 a = gload < u32x4 > (srow);
+      av[0] = a.x;
+      av[1] = a.y;
+      av[2] = a.z;
+      av[3] = a.w;
+    } else {
+      const u32x2 b = gload < u32x2 > (srow);
+      av[0] = __builtin_amdgcn_perm (0u, b.x, 0x0c010c00u);
+      av[1] = __builtin_amdgcn_perm (0u, b.x, 0x0c030c02u);
+      av[2] = __builtin_amdgcn_perm (0u, b.y, 0x0c010c00u);
+      av[3] = __builtin_amdgcn_perm (0u, b.y, 0x0c030c02u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      dv[k] = __builtin_bit_cast (uint32_t, (s16x2) (__builtin_bit_cast (s16x2, dv[k]) + __builtin_bit_cast (s16x2, av[k])));
+    gstore < u32x4 > (drow, (u32x4) { dv[0], dv[1], dv[2], dv[3] });
+    return;
+  }
+  for (int e = 0; e < 8 && x + e < job.w; e++)
+    gstore < int16_t > (drow + e, (int16_t) (gload < int16_t > (drow + e) + (int16_t) gload < S > (srow + e)));
+}
+
 }                               // namespace
 
 int
@@ -678,6 +722,19 @@ launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, in
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)
     return set_error (SCHRO_HIP_EDEVICE, "shift_right launch: %s", hipGetErrorString (e));
+  return 0;
+}
+
+int
+launch_add (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int src_bpp)
+{
+  if (src_bpp == 2)
+    SCHRO_LAUNCH ((add_kernel < int16_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs, njobs);
+  else
+    SCHRO_LAUNCH ((add_kernel < uint8_t >), dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs, njobs);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return set_error (SCHRO_HIP_EDEVICE, "add launch: %s", hipGetErrorString (e));
   return 0;
 }
 

@@ -185,6 +185,12 @@ void obmc_kernel (const ObmcJob * __restrict__ jobs, int njobs, uint32_t * __res
     }
   }
 
+  if (job.out_s16) {
+    // orc_rrshift6_s16_ip_2d (schroorc.orc:676-682; schromotion8.c:896-899 with add = FALSE): subw 8160, shrsw 6
+    const int16_t t = (int16_t) ((int16_t) ((int16_t) acc - 8160) >> 6);
+    gstore < int16_t > ((int16_t *) (job.out + (size_t) py * job.out_stride) + px, t);
+    return;
+  }
   // orc_rrshift6_add_s16_2d / _s32_2d
   int16_t t1 = (int16_t) ((int16_t) acc + 32);
   t1 = (int16_t) (t1 >> 6);
@@ -367,6 +373,18 @@ obmc_finish (const ObmcJob & job, const int *acc, int tid, int x_lo, int y_lo, i
   typedef short s16x2 __attribute__ ((ext_vector_type (2)));
   // whole-width tile, s16 residual, aligned rows: 8 pixels per lane with packed 16-bit
   // arithmetic (the reference's adds wrap at 16 bits: v_pk_add_u16 does exactly that)
+  if (job.out_s16) {
+    // the prediction - 128 as s16 (orc_rrshift6_s16_ip_2d: subw 8160, shrsw 6), a pixel per lane and step
+    for (int it = tid; it < kFTH * kFTW; it += kThreads) {
+      const int xx = it % kFTW, yy = it / kFTW;
+      const int x = x_lo + xx, y = y_lo + yy;
+      if (y >= y_hi || x >= x_hi)
+        continue;
+      const int a = acc[(yy & (kFTH / 2 - 1)) * kAccStride + kAccMargin + xx] >> (yy & (kFTH / 2));
+      gstore < int16_t > ((int16_t *) (job.out + (size_t) y * job.out_stride) + x, (int16_t) ((int16_t) ((int16_t) a - 8160) >> 6));
+    }
+    return;
+  }
   const bool fast = job.res_bpp == 2 && x_hi - x_lo == kFTW
       && ((((uintptr_t) job.residual) | (uintptr_t) job.residual_stride) & 15) == 0
       && ((((uintptr_t) job.out) | (uintptr_t) job.out_stride) & 7) == 0;

@@ -362,7 +362,7 @@ bool
 obmc_strip_ok (const ObmcJob & j)
 {
   return j.xblen == 12 && j.yblen == 12 && j.xbsep == 8 && j.ybsep == 8 && j.xoff == 2 && j.yoff == 2 && j.ref_ps == 0
-      && (j.prec == 1 || j.prec == 2) && (!j.residual || j.res_bpp == 2) && j.nbx >= 2 && j.nby >= 2;
+      && (j.prec == 1 || j.prec == 2) && (!j.residual || j.res_bpp == 2) && j.nbx >= 2 && j.nby >= 2 && !j.out_s16;
 }
 
 // waves of one plane: strips of 15 block columns x segments of seg_rows block rows

@@ -47,6 +47,43 @@ schro_hip_convert_u8_batch (SchroHipContext * ctx, const SchroHipConvertPlane * 
   return launch_convert (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, bpp);
 }
 
+// dst (s16) += src (s16 | u8): schro_frame_add / schro_gpuframe_add on planes (schroframe.c:1082-1135,
+// schrogpuframe.c:257-306); width x height = the planes' common size
+int
+schro_hip_add_batch (SchroHipContext * ctx, const SchroHipConvertPlane * planes, int nplanes, int src_bytes_per_sample)
+{
+  SCHRO_HIP_REQUIRE (ctx && planes && nplanes > 0 && nplanes <= kMaxJobs, "add_batch: bad arguments");
+  SCHRO_HIP_REQUIRE (src_bytes_per_sample == 1 || src_bytes_per_sample == 2, "add_batch: the source is u8 or s16");
+  (void) hipSetDevice (ctx->device);
+  int tw, th;
+  convert_tile_geometry (&tw, &th);
+  std::vector < ConvertJob > jobs (nplanes);
+  int tile_base = 0;
+  for (int p = 0; p < nplanes; p++) {
+    const SchroHipConvertPlane & pl = planes[p];
+    SCHRO_HIP_REQUIRE (pl.src && pl.dst && pl.width > 0 && pl.height > 0 && pl.dst_stride >= 2 * pl.width
+        && pl.src_stride >= src_bytes_per_sample * pl.width && ((uintptr_t) pl.dst | (uintptr_t) pl.dst_stride) % 2 == 0
+        && ((uintptr_t) pl.src | (uintptr_t) pl.src_stride) % src_bytes_per_sample == 0, "add_batch: plane %d invalid", p);
+    ConvertJob & j = jobs[p];
+    memset (&j, 0, sizeof (j));
+    j.src = pl.src;
+    j.dst = pl.dst;
+    j.src_stride = pl.src_stride;
+    j.dst_stride = pl.dst_stride;
+    j.w = pl.width;
+    j.h = pl.height;
+    j.tiles_x = div_up (pl.width, tw);
+    j.tile_base = tile_base;
+    tile_base += j.tiles_x * div_up (pl.height, th);
+  }
+  void *d_jobs;
+  int r = push_args (ctx, jobs.data (), sizeof (ConvertJob) * nplanes, &d_jobs);
+  if (r)
+    return r;
+  ProfileScope ps (ctx, SCHRO_HIP_KERNEL_CONVERT);
+  return launch_add (ctx->stream, (const ConvertJob *) d_jobs, nplanes, tile_base, src_bytes_per_sample);
+}
+
 }                               // extern "C"
 
 namespace schro {

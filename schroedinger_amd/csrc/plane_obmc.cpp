@@ -318,7 +318,12 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     SCHRO_HIP_REQUIRE (pl.component >= 0 && pl.component <= 2, "obmc_batch: bad component");
     SCHRO_HIP_REQUIRE (!pl.residual || pl.residual_bpp == 2 || pl.residual_bpp == 4, "obmc_batch: residual bpp");
     // r04: the prediction alone, for the wavelet's combine form: it must fit the u8 plane it is written to
-    SCHRO_HIP_REQUIRE (!pl.prediction_only || (!pl.residual && pl.picture_weight_1 >= 0 && pl.picture_weight_2 >= 0
+    SCHRO_HIP_REQUIRE (pl.prediction_only >= 0 && pl.prediction_only <= 2, "obmc_batch: plane %d: prediction_only is 0, 1 or 2", p);
+    // r06, prediction_only 2: the prediction - 128 into an s16 plane (schro_motion_render's add = FALSE / schro_motion_render_cuda's
+    // dest): 16-bit arithmetic carries whatever the weights and DC values give
+    SCHRO_HIP_REQUIRE (pl.prediction_only != 2 || (!pl.residual && ((uintptr_t) pl.out | (uintptr_t) pl.out_stride) % 2 == 0),
+        "obmc_batch: plane %d: prediction_only 2 needs residual NULL and an s16 plane in `out`", p);
+    SCHRO_HIP_REQUIRE (pl.prediction_only != 1 || (!pl.residual && pl.picture_weight_1 >= 0 && pl.picture_weight_2 >= 0
             && pl.picture_weight_1 + pl.picture_weight_2 <= (1 << pl.picture_weight_bits)),
         "obmc_batch: plane %d: prediction_only needs residual NULL and picture weights >= 0 that sum to at most 1 << bits "
         "(a prediction of 8 bits); other pictures take the residual form", p);
@@ -383,11 +388,12 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
             && ((uintptr_t) j.ref[r] & 127) == 0,
             "obmc_batch: plane %d: reference %d is not a half-pel image of this component (128-byte aligned, stride from "
             "schro_hip_upsampled_bytes / _pair_bytes)", p, r + 1);
+    j.out_s16 = pl.prediction_only == 2;
     const int variant = variant_of (pl);
-    const int nd_row = (variant == 1 && use_row) ? obmc_row_form (j, false, &row_ns[p]) : 0;
+    const int nd_row = (variant == 1 && use_row && !j.out_s16) ? obmc_row_form (j, false, &row_ns[p]) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
-    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only ? 1 << 19 : 0)
-        | (nd_row ? row_ns[p] << 20 : 0);
+    key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only == 1 ? 1 << 19 : 0)
+        | (nd_row ? row_ns[p] << 20 : 0) | (j.out_s16 ? 1 << 22 : 0);
     row_nd[p] = nd_row;
   }
   // row kernel: the U and V planes of a picture (same vectors, blocks and sample windows) become
@@ -413,13 +419,13 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // (obmc_row.hip, UV form); what it does not take (eighth pel, other weights, long rows) reads
     // its component out of the pair images in obmc.hip
     if (a.ref_ps && b.ref_ps && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
-        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1] && !planes[p].prediction_only == !planes[p + 1].prediction_only) {
+        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1] && planes[p].prediction_only == planes[p + 1].prediction_only && !a.out_s16) {
       int ns;
       const int nd = obmc_row_form (a, true, &ns);
       if (nd) {
         row_nd[p] = row_nd[p + 1] = nd;
         row_ns[p] = row_ns[p + 1] = ns;
-        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only ? 1 << 19 : 0) | (ns << 20);
+        key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only == 1 ? 1 << 19 : 0) | (ns << 20);
         p++;
       }
       continue;

@@ -172,6 +172,9 @@ struct ObmcJob {
   int nseg, ref_ps, lpi, ref_cb, ipw, chunk_cap;
   uint32_t m_tiles_x, m_xbsep, m_ybsep, m_nseg, m_lpi;
   uint32_t m_xramp, m_yramp;    // ceil (2^32 / (2 * offset - 1)): get_ramp's division (schromotion.c:40-49)
+  int out_s16;                  // r06: `out` is an s16 plane that receives (acc - 8160) >> 6 = the prediction - 128
+                                // (orc_rrshift6_s16_ip_2d: schro_motion_render's add = FALSE, schro_motion_render_cuda's dest);
+                                // no residual.  obmc.hip's kernels only
   unsigned long long *stamps;   // scratch runs only (SCHRO_HIP_OBMC_STAMPS): per-workgroup phase stamps
   // row kernel: the second plane of a job.  The U and V planes of a picture have the same
   // blocks, vectors and sample windows, so one workgroup decodes a tile's blocks once and
@@ -432,6 +435,7 @@ int launch_convert (hipStream_t stream, const ConvertJob * d_jobs, int njobs,
 void convert_tile_geometry (int *tw, int *th);
 int launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int total_tiles);
 int launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp, int shift);
+int launch_add (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int src_bpp);
 void pack_tile_geometry (int *groups_x, int *rows);
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
     int njobs, int total_tiles);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 kernel stats of bench.py's decode variants (GPU box): gpurun_out/var_<name>/
+set -e
+repo=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+run () {
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/var_$name -o run -- python3 $repo/scripts/variant_run.py "$@" > $repo/gpurun_out/var_$name.log 2>&1
+  f=$(find $repo/gpurun_out/var_$name -name '*kernel_stats.csv' | head -1)
+  echo "== $name"; cat $repo/gpurun_out/var_$name.log | tail -1 | cut -c1-300
+  python3 - "$f" <<PY
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    print("%-70s calls %5s avg %9.1f ns" % (r["Name"][:70], r["Calls"], float(r["AverageNs"])))
+PY
+}
+run fullpel prec=0 check=0
+run eighth prec=3 check=0
+run b2416 xblen=24 xbsep=16 check=0
+run p1080 w=1920 h=1080 check=0
+run headline check=0

@@ -281,8 +281,9 @@ class MotionParams(C.Structure):
         "chroma_h_shift", "chroma_v_shift")]
 
 
-def motion_render(mvs, params, k, ref1, ref2, residual, width, height):
-    """schro_motion_render_u8 (add=TRUE) for component k -> u8 (height, width)."""
+def motion_render(mvs, params, k, ref1, ref2, residual, width, height, return_acc=False):
+    """schro_motion_render_u8 (add=TRUE) for component k -> u8 (height, width); return_acc: (out, the s16
+    accumulator the blocks were scattered into -- what orc_rrshift6_*'s read)."""
     mvs = np.ascontiguousarray(mvs)
     assert mvs.dtype == MV_DTYPE
     residual = np.ascontiguousarray(residual)
@@ -293,7 +294,44 @@ def motion_render(mvs, params, k, ref1, ref2, residual, width, height):
         _ptr(residual), residual.strides[0], _bpp(residual),
         _ptr(acc), acc.strides[0], _ptr(out), out.strides[0], width, height)
     assert r == 0
-    return out
+    return (out, acc) if return_acc else out
+
+
+def rrshift6_s16(acc):
+    """orc_rrshift6_s16_ip_2d (schroorc.orc:676-682: subw 8160, shrsw 6): the s16 frame schro_motion_render (add = FALSE)
+    leaves in its dest (schromotion8.c:896-899) -- the prediction - 128.  The reference's own compiled kernel where
+    oracle/_ref is there, else its restatement (tests/test_oracle_motion.py compares the two)."""
+    acc = np.ascontiguousarray(acc, np.int16)
+    if ref_available():
+        d = acc.copy()
+        reforc().orc_rrshift6_s16_ip_2d(_ptr(d), C.c_int(d.strides[0]), C.c_int(d.shape[1]), C.c_int(d.shape[0]))
+        return d
+    return rrshift6_s16_restated(acc)
+
+
+def rrshift6_s16_restated(acc):
+    return ((acc.astype(np.int32) - 8160).astype(np.int16) >> 6).astype(np.int16)
+
+
+def frame_add(dst, src):
+    """schro_frame_add's two cases (schroframe.c:1082-1135): dst (s16) += src (s16 | u8) over the common size,
+    16-bit wrap -- orc_add_s16_2d / orc_add_s16_u8_2d compiled from the reference where oracle/_ref is there."""
+    d = np.ascontiguousarray(dst, np.int16).copy()
+    s = np.ascontiguousarray(src)
+    h, w = min(d.shape[0], s.shape[0]), min(d.shape[1], s.shape[1])
+    if ref_available():
+        f = reforc().orc_add_s16_2d if s.dtype == np.int16 else reforc().orc_add_s16_u8_2d
+        assert s.dtype in (np.int16, np.uint8)
+        f(_ptr(d), C.c_int(d.strides[0]), _ptr(s), C.c_int(s.strides[0]), C.c_int(w), C.c_int(h))
+        return d
+    return frame_add_restated(dst, src)
+
+
+def frame_add_restated(dst, src):
+    d = np.ascontiguousarray(dst, np.int16).copy()
+    h, w = min(d.shape[0], src.shape[0]), min(d.shape[1], src.shape[1])
+    d[:h, :w] = (d[:h, :w].astype(np.int32) + src[:h, :w].astype(np.int32)).astype(np.int16)
+    return d
 
 
 # ---- VC-2 low-delay transform data ----------------------------------------------

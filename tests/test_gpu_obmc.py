@@ -324,3 +324,61 @@ def test_more_block_geometries_in_a_call_than_a_table_slot_holds(ctx):
         assert np.array_equal(out.download(), ref), geo
     for p in keep:
         p.free()
+
+
+@pytest.mark.parametrize("prec", [0, 2, 3])
+@pytest.mark.parametrize("weights", [(1, 1, 1), (3, -1, 1), (5, 3, 2)])
+def test_prediction_into_an_s16_plane(ctx, prec, weights):
+    """r06, prediction_only = 2 -- schro_motion_render (add = FALSE) / schro_motion_render_cuda's dest: the s16 plane
+    receives (acc - 8160) >> 6 (orc_rrshift6_s16_ip_2d: the prediction - 128) for ANY weights and DC values, the
+    reference's 16-bit wrap included; checked against the oracle's accumulator through the reference's own compiled
+    kernel (oracle_lib.rrshift6_s16)."""
+    w, h, chroma = 136, 72, (1, 1)
+    P = synth.motion_params(w, h, 12, 8, prec, weights, chroma)
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, 31, (0.2, 0.3, 0.2, 0.3))
+    dc_blocks = np.flatnonzero((mv["flags"] & 3) == 0)
+    mv["v"][dc_blocks[::3], :3] = np.array([300, -400, 32767], np.int16)      # DC values outside 8 bits wrap as the reference's
+    d_mv = ctx.upload_bytes(mv)
+    jobs, want, keep = [], [], [d_mv]
+    for k in range(3):
+        cw, ch = comp_size(w, h, k, chroma)
+        r1, r2 = (synth.picture_u8(ch, cw, seed=50 + 10 * r + k) for r in range(2))
+        _, acc = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(r1, upsample=prec > 0), O.UpComp(r2, upsample=prec > 0),
+                                 np.zeros((ch, cw), np.int16), cw, ch, return_acc=True)
+        want.append(O.rrshift6_s16(acc))
+        if prec == 0:
+            g1, g2 = ctx.upload(r1), ctx.upload(r2)
+        else:
+            p1, p2 = ctx.upload(r1), ctx.upload(r2)
+            g1, g2 = ctx.hp_plane(ch, cw), ctx.hp_plane(ch, cw)
+            ctx.upsample_batch([(p1, g1), (p2, g2)])
+            keep += [p1, p2]
+        out = ctx.plane(ch + 3, cw + 5, np.int16).fill(0x11)      # (a larger plane: the rest stays as it was)
+        out.width, out.height = cw, ch
+        jobs.append(sa.obmc_plane(d_mv, P, k, g1, g2, None, out, prediction_only=2))
+        keep += [g1, g2, out]
+    ctx.obmc_batch(jobs)
+    outs = [x for x in keep if isinstance(x, sa.DevicePlane) and x.dtype == np.int16]
+    for k, out in enumerate(outs):
+        cw, ch = comp_size(w, h, k, chroma)
+        out.width, out.height = cw + 5, ch + 3
+        got = out.download()
+        assert np.array_equal(got[:ch, :cw], want[k]), k
+        assert (got[ch:, :] == 0x1111).all() and (got[:, cw:] == 0x1111).all()
+    for p in keep:
+        p.free()
+
+
+def test_add_batch(ctx):
+    """r06: dst (s16) += src (s16 | u8), schro_frame_add's two cases, 16-bit wrap, ragged sizes and unaligned rows."""
+    rng = np.random.default_rng(11)
+    for (h, w) in ((48, 64), (37, 53), (5, 7), (270, 1920)):
+        for sdt in (np.int16, np.uint8):
+            d = rng.integers(-32768, 32768, (h, w)).astype(np.int16)
+            s = (rng.integers(-32768, 32768, (h + 2, w + 3)).astype(np.int16) if sdt == np.int16
+                 else rng.integers(0, 256, (h + 2, w + 3)).astype(np.uint8))
+            gd, gs = ctx.upload(d), ctx.upload(s)
+            ctx.add_batch([(gd, gs)])
+            assert np.array_equal(gd.download(), O.frame_add(d, s)), (h, w, sdt)
+            gd.free()
+            gs.free()

@@ -273,3 +273,74 @@ def test_zero_residual_picture_has_no_frame_to_add(ctx, hs, vs, prec):
     ctx.obmc_batch(jobs)
     for k in range(3):
         assert np.array_equal(outs[k].download(), wants[k]), k
+
+
+@pytest.mark.parametrize("hs,vs,prec,weights", [(1, 1, 2, (1, 1, 1)), (1, 0, 0, (1, 1, 1)), (1, 1, 3, (3, -1, 1))])
+def test_the_have_cuda_branch_renamed(ctx, hs, vs, prec, weights):
+    """r06: the reference's HAVE_CUDA branches with `cuda` spelt `hip`, call for call --
+    x_render_motion: mc_tmp_frame = S16 frame of the transform's padded size; schro_motion_render_cuda (motion,
+    mc_tmp_frame) (schrodecoder.c:1742-1760); x_combine: schro_gpuframe_add (picture->frame, mc_tmp_frame)
+    (:1908-1910), schro_gpuframe_convert (planar_output_frame, combined_frame) (:2011).  The picture equals the CPU
+    call's fused form (the oracle) wherever the 16-bit sums do not wrap -- they cannot for legal weights --, and the
+    s16 frames equal the reference's own Orc kernels on the oracle's accumulator for any weights."""
+    w, h, depth, filt = 200, 120, 3, 0
+    lib = ctx.lib
+    pd = dims(w, h, hs, vs)
+    # (schrodecoder.c:1749-1754: the luma size rounded up to the transform depth + the chroma shift)
+    il = (round_up(h, depth + vs), round_up(w, depth + hs))
+    iw = [il, (il[0] >> vs, il[1] >> hs), (il[0] >> vs, il[1] >> hs)]
+    P = synth.motion_params(w, h, 12, 8, prec, weights, (hs, vs))
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 24 << prec, seed=9)
+    params = frames.make_params(
+        wavelet_filter_index=filt, transform_depth=depth, iwt_luma_width=iw[0][1], iwt_luma_height=iw[0][0],
+        iwt_chroma_width=iw[1][1], iwt_chroma_height=iw[1][0], num_refs=2, xblen_luma=12, yblen_luma=12,
+        xbsep_luma=8, ybsep_luma=8, mv_precision=prec, picture_weight_bits=weights[2], picture_weight_1=weights[0],
+        picture_weight_2=weights[1], x_num_blocks=P["x_num_blocks"], y_num_blocks=P["y_num_blocks"])
+    resid = [synth.image_s(ih, iwd, np.int16, seed=60 + k) for k, (ih, iwd) in enumerate(iw)]
+    coeffs = [O.forward_iwt(r, depth, filt) for r in resid]
+    fmt16, fmt8 = frames.frame_format(np.int16, hs, vs), frames.frame_format(np.uint8, hs, vs)
+    frame = frames.DeviceFrame(ctx, fmt16, iw[0][1], iw[0][0])
+    sa.check(lib.schro_frame_inverse_iwt_transform_hip(frame.ptr(), frames.HostFrame(coeffs, hs, vs).ptr(), C.byref(params)))
+    res_np = frame.download()
+    refs_np = [[synth.picture_u8(ph, pw, seed=70 + 10 * r + k) for k, (ph, pw) in enumerate(pd)] for r in range(2)]
+    refs = []
+    for r in range(2):
+        d = frames.DeviceFrame(ctx, fmt8, w, h).upload(frames.HostFrame(refs_np[r], hs, vs))
+        if prec > 0:
+            u = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+            sa.check(lib.schro_upsampled_hipframe_upsample(u.ptr(), d.ptr()))
+            refs.append(u)
+        else:
+            refs.append(d)
+    # x_render_motion, the HAVE_CUDA branch: an S16 mc_tmp_frame of the padded size
+    mc_tmp = frames.DeviceFrame(ctx, fmt16, iw[0][1], iw[0][0])
+    motion = _lib.Motion(refs[0].ptr(), refs[1].ptr(), mv.ctypes.data, C.pointer(params))
+    sa.check(lib.schro_motion_render_hip(C.byref(motion), mc_tmp.ptr(), None, 0, None))
+    got_pred = mc_tmp.download()
+    accs = []
+    for k, (ph, pw) in enumerate(pd):
+        _, acc = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                                 O.UpComp(refs_np[1][k], upsample=prec > 0), np.zeros((ph, pw), np.int16), pw, ph, return_acc=True)
+        accs.append(acc)
+        assert np.array_equal(got_pred[k][:ph, :pw], O.rrshift6_s16(acc)), k
+    # x_combine: schro_gpuframe_add (picture->frame, mc_tmp_frame); schro_gpuframe_convert (output, picture->frame)
+    sa.check(lib.schro_hipframe_add(frame.ptr(), mc_tmp.ptr()))
+    got_sum = frame.download()
+    out = frames.DeviceFrame(ctx, fmt8, w, h)
+    sa.check(lib.schro_hipframe_convert(out.ptr(), frame.ptr()))
+    got = out.download()
+    for k, (ph, pw) in enumerate(pd):
+        want_sum = O.frame_add(res_np[k][:ph, :pw], O.rrshift6_s16(accs[k]))
+        assert np.array_equal(got_sum[k][:ph, :pw], want_sum), k
+        assert np.array_equal(got[k], O.convert_u8(want_sum, pw, ph)), k
+        if weights == (1, 1, 1):        # ... which is the CPU call's fused picture
+            fused = O.motion_render(mv, O.MotionParams(**P), k, O.UpComp(refs_np[0][k], upsample=prec > 0),
+                                    O.UpComp(refs_np[1][k], upsample=prec > 0), res_np[k], pw, ph)
+            assert np.array_equal(got[k], fused), k
+    # a u8 source: schro_gpuframe_add's other case (schrogpuframe.c:272-283)
+    sa.check(lib.schro_hipframe_add(frame.ptr(), refs[0].ptr() if prec == 0 else out.ptr()))
+    src8 = refs_np[0] if prec == 0 else got
+    for k, (ph, pw) in enumerate(pd):
+        assert np.array_equal(frame.download()[k][:ph, :pw], O.frame_add(got_sum[k][:ph, :pw], src8[k])), k
+    for f in (frame, out, mc_tmp) + tuple(refs):
+        f.unref()

@@ -164,3 +164,21 @@ def test_block_arithmetic_matches_reference_kernels():
     t = ((acc.astype(np.int64) + 32).astype(np.int16).astype(np.int64)) >> 6
     t = (res32.astype(np.int16).astype(np.int64) + t).astype(np.int16)      # convlw truncates
     assert np.array_equal(out, np.clip(t, 0, 255).astype(np.uint8))
+
+
+def test_rrshift6_s16_and_frame_add_against_the_reference_kernels():
+    """r06: the two restatements the S16-destination render and schro_hipframe_add are checked with are the reference's
+    own compiled kernels where oracle/_ref exists (orc_rrshift6_s16_ip_2d, orc_add_s16_2d, orc_add_s16_u8_2d); the
+    numpy forms (what a box without _ref falls back to) give the same bytes, full range included."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    acc = rng.integers(-32768, 32768, (37, 53)).astype(np.int16)
+    acc[0, :8] = [-32768, 32767, 8159, 8160, 8161, -24609, -24608, 0]
+    assert np.array_equal(O.rrshift6_s16(acc), O.rrshift6_s16_restated(acc))
+    # legal sums: (acc + 32) >> 6 - 128
+    legal = rng.integers(0, 255 * 64 + 1, (16, 24)).astype(np.int16)
+    assert np.array_equal(O.rrshift6_s16(legal), ((legal.astype(np.int32) + 32) >> 6) - 128)
+    d = rng.integers(-32768, 32768, (40, 64)).astype(np.int16)
+    for src in (rng.integers(-32768, 32768, (33, 70)).astype(np.int16), rng.integers(0, 256, (44, 60)).astype(np.uint8)):
+        assert np.array_equal(O.frame_add(d, src), O.frame_add_restated(d, src))
