@@ -53,9 +53,11 @@ extern "C" {
  * the picture takes the residual order instead (inverse transform into the residual frame, then
  * schro_motion_render_hip (..., add = TRUE, ...): INTEGRATION 3).  schro_motion_render_hip (add = FALSE) answers
  * BEFORE it launches anything when the vectors are in host memory (it scans them); with device-resident vectors the
- * launch raises a flag that the next synchronising call of the context reports with this code, naming the
- * prediction_only batch (schro_hip_obmc_prediction_epoch).  schro_hip_set_abort_on_error (1) never turns this
- * code into an abort. */
+ * launch raises a flag that the next SYNCHRONISING call of the context (a stage call with stage completion on,
+ * schro_hip_synchronize, schro_hip_queue_synchronize) reports once with this code, naming the prediction_only
+ * batches (schro_hip_obmc_prediction_epoch numbers them); r06: a call that only enqueues is never refused for it, and
+ * schro_hip_obmc_overflowed returns every such batch's number, so a host that pipelines pictures knows exactly
+ * which ones to repeat.  schro_hip_set_abort_on_error (1) never turns this code into an abort. */
 #define SCHRO_HIP_ENEEDS_RESIDUAL (-6)
 
 /* schroedinger/schrodomain.h:30-36 -- ids for the new domain */
@@ -317,7 +319,7 @@ int schro_hip_pack_v210_batch (SchroHipContext * ctx,
  * x_wavelet_transform, schrodecoder.c:1855-1886, then schro_frame_convert (output_picture, frame) in x_combine, :2011-2052 ->
  * schrovirtframe.c:1438-1537, :943-991).  dst receives exactly the bytes of schro_hip_iiwt_batch into a pixel frame followed by
  * schro_hip_pack_v210_batch from it.  Where the transform is the three-level s32 Haar (filters 3, 4) of a 4:2:2 picture whose
- * size is a multiple of 48 x 8 (BASELINE config 5: 7680 x 4320) the copy-out is the transform kernel's epilogue and the pixel
+ * size is a multiple of 192 x 8 (v210 groups of 6 pixels x whole strips of the kernel; BASELINE config 5: 7680 x 4320) the copy-out is the transform kernel's epilogue and the pixel
  * frame never exists (per 8K picture 353 MB of memory traffic instead of 883 MB); every other case runs the two passes. */
 typedef struct {
   const void *src[3];           /* the coefficient planes Y, U, V (device, s16 or s32), in-place sub-band layout */
@@ -532,6 +534,13 @@ int schro_hip_obmc_batch (SchroHipContext * ctx,
 /* r05: prediction_only calls of schro_hip_obmc_batch are numbered per context (1, 2, ...); this is the number of
  * the latest one (0: none yet) -- what a later SCHRO_HIP_ENEEDS_RESIDUAL names. */
 unsigned int schro_hip_obmc_prediction_epoch (SchroHipContext * ctx);
+/* r06: the numbers of the FINISHED prediction_only batches whose predictions did not fit 8 bits and that this call has
+ * not returned before, oldest first: up to `max` of them into epochs[], the count as the result (0: none; < 0: an
+ * error).  Nothing is lost between calls: a batch's flag is read once its launches have completed and kept until it
+ * has been returned here; a synchronising call names the same batches once in its SCHRO_HIP_ENEEDS_RESIDUAL status
+ * (batches already returned here are not named again).  A host may run any number of prediction_only batches ahead:
+ * the thirteenth unfinished one waits for the first. */
+int schro_hip_obmc_overflowed (SchroHipContext * ctx, unsigned int *epochs, int max);
 
 /* ---- core-syntax coefficients: dequantisation on the device ----------------
  *

@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "schro_hip_lowdelay_arith", "schro_hip_lowdelay_batch", "schro_hip_dc_predict_batch",
     "schro_hip_dequant_batch",
     "schro_hip_decode_lowdelay_transform_data", "schro_hipframe_dequantise",
-    "schro_hip_obmc_batch", "schro_hip_obmc_prediction_epoch",
+    "schro_hip_obmc_batch", "schro_hip_obmc_prediction_epoch", "schro_hip_obmc_overflowed",
     "schro_hip_frame_new_and_alloc", "schro_hip_frame_ref", "schro_hip_frame_unref",
     "schro_frame_to_hip", "schro_hipframe_to_cpu",
     "schro_frame_inverse_iwt_transform_hip", "schro_frame_inverse_iwt_transform_combine_hip", "schro_frame_inverse_iwt_transform_convert_hip", "schro_upsampled_hipframe_upsample",
@@ -380,6 +380,8 @@ def load():
     L.schro_hip_obmc_batch.restype = i
     L.schro_hip_obmc_prediction_epoch.argtypes = [vp]
     L.schro_hip_obmc_prediction_epoch.restype = C.c_uint
+    L.schro_hip_obmc_overflowed.argtypes = [vp, C.POINTER(C.c_uint), i]
+    L.schro_hip_obmc_overflowed.restype = i
     L.schro_hip_frame_new_and_alloc.argtypes = [vp, i, i, i, i]
     L.schro_hip_frame_new_and_alloc.restype = C.POINTER(Frame)
     L.schro_hip_frame_ref.argtypes = [C.POINTER(Frame)]

@@ -186,26 +186,80 @@ dc_gave_up (SchroHipContext * ctx)
     return set_error (SCHRO_HIP_EDEVICE, "inverse wavelet launch %u: a tile gave up waiting for the level above it (its picture is incomplete)",
         epoch);
   }
-  // r05: predictions that did not fit 8 bits (prediction_only OBMC batches, numbered).  Not an error of the
-  // stream -- the reference decodes such a picture (16-bit wrap, schromotion8.c:542-657) -- but an answer the
-  // caller routes on: the picture of that batch is wrong and takes the residual order.  Never aborts.
-  if (ctx->dc_gave_up) {
-    volatile uint32_t *ring = (volatile uint32_t *) ctx->dc_gave_up + 4;
-    uint32_t first = 0;
-    int n = 0;
-    for (int k = 0; k < SchroHipContext::kOvfRing; k++)
-      if (ring[k]) {
-        ring[k] = 0;
-        if (!first || ctx->ovf_epoch[k] < first)
-          first = ctx->ovf_epoch[k];
-        n++;
-      }
-    if (n)
-      return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "prediction_only OBMC batch %u%s met a DC value outside [-128, 127]: its prediction "
-          "does not fit 8 bits and the combined picture differs from the reference's; such pictures take the residual order "
-          "(schro_hip_obmc_prediction_epoch names a batch)", first, n > 1 ? " (and later ones)" : "");
-  }
   return 0;
+}
+
+// r06 -- predictions that did not fit 8 bits (prediction_only OBMC batches, numbered).  Not an error of the
+// stream -- the reference decodes such a picture (16-bit wrap, schromotion8.c:542-657) -- but an answer the caller
+// routes on: the picture of that batch is wrong and takes the residual order.  Never aborts.  Ring word k belongs to ONE
+// batch at a time (ovf_epoch[k]) and is looked at only when that batch's event has fired, so a flag is never
+// attributed to another batch; what is found goes into two lists and stays there until it has been named by a
+// synchronising call (once) and fetched by schro_hip_obmc_overflowed.
+static void
+pred_overflow_collect (SchroHipContext * ctx, int k, bool wait)
+{
+  if (!ctx->dc_gave_up || !ctx->ovf_epoch[k] || !ctx->ovf_ev[k])
+    return;
+  if (wait)
+    (void) hipEventSynchronize (ctx->ovf_ev[k]);
+  else if (hipEventQuery (ctx->ovf_ev[k]) != hipSuccess) {
+    (void) hipGetLastError ();  // (hipErrorNotReady is not an error of ours)
+    return;
+  }
+  volatile uint32_t *ring = (volatile uint32_t *) ctx->dc_gave_up + 4;
+  if (ring[k]) {
+    ring[k] = 0;
+    ctx->ovf_unannounced.push_back (ctx->ovf_epoch[k]);
+    ctx->ovf_unfetched.push_back (ctx->ovf_epoch[k]);
+  }
+  ctx->ovf_epoch[k] = 0;
+}
+
+int
+pred_overflow_claim (SchroHipContext * ctx, uint32_t epoch)
+{
+  const int k = (int) (epoch % SchroHipContext::kOvfRing);
+  // (the host is kOvfRing prediction_only batches ahead of the device only if nobody synchronises: then it waits here)
+  pred_overflow_collect (ctx, k, true);
+  if (!ctx->ovf_ev[k])
+    SCHRO_HIP_CHECK (hipEventCreateWithFlags (&ctx->ovf_ev[k], hipEventDisableTiming));
+  ctx->ovf_epoch[k] = epoch;
+  return 0;
+}
+
+int
+pred_overflow_poll (SchroHipContext * ctx)
+{
+  for (int k = 0; k < SchroHipContext::kOvfRing; k++)
+    pred_overflow_collect (ctx, k, false);
+  if (ctx->ovf_unannounced.empty ())
+    return 0;
+  char list[160];
+  size_t n = 0;
+  for (size_t i = 0; i < ctx->ovf_unannounced.size () && n + 16 < sizeof (list); i++)
+    n += (size_t) snprintf (list + n, sizeof (list) - n, i ? ", %u" : "%u", ctx->ovf_unannounced[i]);
+  ctx->ovf_unannounced.clear ();
+  return set_status (SCHRO_HIP_ENEEDS_RESIDUAL, "prediction_only OBMC batch(es) %s met a DC value outside [-128, 127]: the prediction "
+      "does not fit 8 bits and the combined picture differs from the reference's; such pictures take the residual order "
+      "(schro_hip_obmc_overflowed returns the batches' numbers)", list);
+}
+
+extern "C" int
+schro_hip_obmc_overflowed (SchroHipContext * ctx, unsigned int *epochs, int max)
+{
+  SCHRO_HIP_REQUIRE (ctx && (epochs || max == 0) && max >= 0, "obmc_overflowed: bad arguments");
+  for (int k = 0; k < SchroHipContext::kOvfRing; k++)
+    pred_overflow_collect (ctx, k, false);
+  const int n = (int) std::min ((size_t) max, ctx->ovf_unfetched.size ());
+  for (int i = 0; i < n; i++) {
+    epochs[i] = ctx->ovf_unfetched[(size_t) i];
+    // (what the caller has been handed need not interrupt a later synchronising call)
+    auto it = std::find (ctx->ovf_unannounced.begin (), ctx->ovf_unannounced.end (), epochs[i]);
+    if (it != ctx->ovf_unannounced.end ())
+      ctx->ovf_unannounced.erase (it);
+  }
+  ctx->ovf_unfetched.erase (ctx->ovf_unfetched.begin (), ctx->ovf_unfetched.begin () + n);
+  return n;
 }
 
 int
@@ -508,7 +562,10 @@ context_new_unbound (int device)
     ctx->frame_dq_plan = nullptr;
     ctx->dq_stage_q[q] = nullptr;
     ctx->dq_stage_size_q[q] = 0;
+    ctx->pack_tmp_q[q] = nullptr;
+    ctx->pack_tmp_size_q[q] = 0;
     memset (ctx->ovf_epoch, 0, sizeof (ctx->ovf_epoch));
+    memset (ctx->ovf_ev, 0, sizeof (ctx->ovf_ev));
     ctx->streams[q] = nullptr;
     ctx->queue_ev[q] = nullptr;
   }
@@ -635,9 +692,14 @@ schro_hip_context_free (SchroHipContext * ctx)
     (void) hipFree (s.ptr);
   if (ctx->dc_gave_up)
     (void) hipHostFree (ctx->dc_gave_up);
+  for (int k = 0; k < SchroHipContext::kOvfRing; k++)
+    if (ctx->ovf_ev[k])
+      (void) hipEventDestroy (ctx->ovf_ev[k]);
   for (int q = 0; q < SchroHipContext::kQueues; q++) {
     if (ctx->dq_stage_q[q])
       (void) hipFree (ctx->dq_stage_q[q]);
+    if (ctx->pack_tmp_q[q])
+      (void) hipFree (ctx->pack_tmp_q[q]);
     if (ctx->scratch_q[q])
       (void) hipFree (ctx->scratch_q[q]);
     if (ctx->dc_edge_q[q])
@@ -811,7 +873,8 @@ schro_hip_queue_synchronize (SchroHipContext * ctx, int queue)
 {
   SCHRO_HIP_REQUIRE (ctx && queue >= 0 && queue < SchroHipContext::kQueues, "queue_synchronize: queue %d out of range", queue);
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[queue]));
-  return 0;
+  const int r = dc_gave_up (ctx);
+  return r ? r : pred_overflow_poll (ctx);
 }
 
 int
@@ -844,7 +907,8 @@ schro_hip_synchronize (SchroHipContext * ctx)
   SCHRO_HIP_REQUIRE (ctx, "synchronize: no context");
   for (int q = 0; q < SchroHipContext::kQueues; q++)
     SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->streams[q]));
-  return dc_gave_up (ctx);
+  const int r = dc_gave_up (ctx);
+  return r ? r : pred_overflow_poll (ctx);
 }
 
 // Queues.  The reference's scheduler runs the stages of different pictures on several worker

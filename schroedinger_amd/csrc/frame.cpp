@@ -35,7 +35,8 @@ stage_done (SchroHipContext * ctx, int r)
   if (r || !ctx->stage_complete)
     return r;
   SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
-  return dc_gave_up (ctx);
+  r = dc_gave_up (ctx);
+  return r ? r : pred_overflow_poll (ctx);
 }
 
 int
@@ -509,6 +510,27 @@ schro_hipframe_dequantise (SchroHipFrame * transform_frame, const SchroHipQuanti
     SCHRO_HIP_REQUIRE (q->codeblocks[k] && q->ncodeblocks[k] > 0 && (q->values[k] || q->values_bytes[k] == 0),
         "hipframe_dequantise: component %d has no codeblock records (or values_bytes without values)", k);
     stage_bytes += (q->values_bytes[k] + 255) & ~(size_t) 255;
+    // r06: the records come, in the end, from the bitstream -- every codeblock lies inside its component
+    // and its values inside the blob, or nothing is launched (two cheap loops over records the plan compare reads anyway)
+    const SchroHipFrameData & comp = transform_frame->components[k];
+    const long long comp_bytes = comp.length > 0 ? (long long) comp.length : (long long) comp.stride * comp.height;
+    for (int n = 0; n < q->ncodeblocks[k]; n++) {
+      const SchroHipCodeblock & cb = q->codeblocks[k][n];
+      const long long row = (long long) cb.width * bpp;
+      SCHRO_HIP_REQUIRE (cb.width >= 0 && cb.height >= 0, "hipframe_dequantise: component %d, codeblock %d has a negative size", k, n);
+      if (cb.width == 0 || cb.height == 0)      // (an empty codeblock of a tiny sub-band: nothing is read or written)
+        continue;
+      SCHRO_HIP_REQUIRE (cb.dst_offset >= 0 && cb.dst_stride >= comp.stride && comp.stride > 0
+          && cb.dst_stride % comp.stride == 0 && cb.dst_offset % bpp == 0
+          && (long long) (cb.dst_offset % comp.stride) + row <= (long long) comp.stride
+          && (long long) cb.dst_offset + (long long) (cb.height - 1) * cb.dst_stride + row <= comp_bytes,
+          "hipframe_dequantise: component %d, codeblock %d (%d x %d at byte %d, pitch %d) does not lie inside the transform frame's "
+          "component (%d x %d, stride %d)", k, n, cb.width, cb.height, cb.dst_offset, cb.dst_stride, comp.width, comp.height, comp.stride);
+      SCHRO_HIP_REQUIRE (cb.src_offset < 0 || ((cb.src_bytes == 1 || cb.src_bytes == 2 || cb.src_bytes == 4)
+              && (unsigned long long) cb.src_offset + (unsigned long long) cb.width * cb.height * cb.src_bytes <= (unsigned long long) q->values_bytes[k]),
+          "hipframe_dequantise: component %d, codeblock %d: its values (%d bytes each, from byte %d) do not lie inside the %zu bytes of values",
+          k, n, (int) cb.src_bytes, cb.src_offset, (size_t) q->values_bytes[k]);
+    }
   }
   // host-side values: staged in a buffer of the selected queue (the queue's order keeps a later call's copy behind this
   // call's kernel); a host that pipelines uploads the picture's blob itself, on the copy queue, and passes device pointers

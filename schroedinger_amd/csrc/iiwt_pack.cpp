@@ -56,25 +56,39 @@ schro_hip_iiwt_pack_v210_batch (SchroHipContext * ctx, const SchroHipIwtPackPict
     ProfileScope ps (ctx, SCHRO_HIP_KERNEL_IIWT_FINEST);
     return launch_iiwt_haar3_v210 (ctx->stream, (const HaarPackJob *) d_jobs, npictures, tile_base, filter);
   }
-  // the two passes: the pixel frame in planes of the domain for the length of the call (this is the general form, not
-  // the fast one: the stream is drained before the planes go back)
+  // the two passes (the general form): transform into pixel planes, then the pack
   std::vector < SchroHipIwtPlane > planes ((size_t) 3 * npictures);
   std::vector < SchroHipPackPlane > packs ((size_t) npictures);
-  std::vector < void *>temps;
-  int r = 0;
-  for (int p = 0; p < npictures && !r; p++) {
+  // r06: the pixel planes live in the queue's own grow-only block -- nothing is allocated, freed or waited
+  // for per call; a block that must grow waits for the queue once
+  size_t need = 0;
+  for (int p = 0; p < npictures; p++)
+    for (int c = 0; c < 3; c++) {
+      const SchroHipIwtPackPicture & pic = pictures[p];
+      const int w = c ? pic.width >> pic.h_shift : pic.width, h = c ? pic.height >> pic.v_shift : pic.height;
+      need += round_up (round_up ((size_t) w * bytes_per_sample, 64) * (size_t) h, 256);
+    }
+  const int q = ctx->cur;
+  if (ctx->pack_tmp_size_q[q] < need) {
+    if (ctx->pack_tmp_q[q]) {
+      SCHRO_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+      SCHRO_HIP_CHECK (hipFree (ctx->pack_tmp_q[q]));
+      ctx->pack_tmp_q[q] = nullptr;
+      ctx->pack_tmp_size_q[q] = 0;
+    }
+    SCHRO_HIP_CHECK (hipMalloc (&ctx->pack_tmp_q[q], need));
+    ctx->pack_tmp_size_q[q] = need;
+  }
+  size_t at = 0;
+  for (int p = 0; p < npictures; p++) {
     const SchroHipIwtPackPicture & pic = pictures[p];
     SchroHipPackPlane & pk = packs[(size_t) p];
     memset (&pk, 0, sizeof (pk));
     for (int c = 0; c < 3; c++) {
       const int w = c ? pic.width >> pic.h_shift : pic.width, h = c ? pic.height >> pic.v_shift : pic.height;
       const int stride = (int) round_up ((size_t) w * bytes_per_sample, 64);
-      void *t = schro_hip_domain_alloc (ctx, (size_t) stride * h);
-      if (!t) {
-        r = SCHRO_HIP_ENOMEM;
-        break;
-      }
-      temps.push_back (t);
+      void *t = (char *) ctx->pack_tmp_q[q] + at;
+      at += round_up ((size_t) stride * (size_t) h, 256);
       SchroHipIwtPlane & pl = planes[(size_t) 3 * p + c];
       memset (&pl, 0, sizeof (pl));
       pl.src = pic.src[c];
@@ -96,13 +110,8 @@ schro_hip_iiwt_pack_v210_batch (SchroHipContext * ctx, const SchroHipIwtPackPict
     pk.height = pic.out_height;
     pk.format = SCHRO_HIP_FORMAT_v210;
   }
-  if (!r)
-    r = schro_hip_iiwt_batch (ctx, planes.data (), 3 * npictures, depth, filter, bytes_per_sample);
+  int r = schro_hip_iiwt_batch (ctx, planes.data (), 3 * npictures, depth, filter, bytes_per_sample);
   if (!r)
     r = schro_hip_pack_v210_batch (ctx, packs.data (), npictures, bytes_per_sample);
-  if (hipStreamSynchronize (ctx->stream) != hipSuccess && !r)
-    r = set_error (SCHRO_HIP_EDEVICE, "iiwt_pack_v210_batch: the queue failed");
-  for (void *t:temps)
-    schro_hip_domain_free (ctx, t);
   return r;
 }

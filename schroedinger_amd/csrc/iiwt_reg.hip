@@ -333,11 +333,7 @@ finish_row (P (&row)[4], bool is_first, bool is_last, bool store_lane, char *dst
       b.x = __builtin_amdgcn_perm (v[1], v[0], 0x06040200u);
       b.y = __builtin_amdgcn_perm (v[3], v[2], 0x06040200u);
       if (cmb.full) {
-#ifdef SCHRO_IWT_OUT_NT
-        __builtin_nontemporal_store (b, (SCHRO_GLOBAL u32x2 *) dst);
-#else
-        gstore < u32x2 > (dst, b);
-#endif
+        gstore < u32x2 > (dst, b);       // (streaming stores here: a wash, HISTORY 8)
       }
       if (cmb.any_ragged) {
 #pragma unroll
@@ -445,16 +441,7 @@ reg_tile (const IwtJob & job, int r0, int c0, int nr, int nc, int lane, WAIT wai
     // registers without a spill for DD(9,7) (measured, 8 x 2160p finest level: AHEAD 1 / 2 / 3 / 4 = 0.0835 / 0.0787 /
     // 0.0768 / 0.0762 ms; 8 with 13 spilled dwords 0.0838 = r04's kernel, which also branched per lane, see finish_row).
     constexpr int NPAIR = RP - 2 * H;
-#ifdef SCHRO_IWT_PRED_AHEAD
-    constexpr int AHEAD = cmin (NPAIR, SCHRO_IWT_PRED_AHEAD);
-#else
-    constexpr int AHEAD = cmin (NPAIR, 4);
-#endif
-#ifdef SCHRO_IWT_PRED_RAMP
-    constexpr int RAMP = SCHRO_IWT_PRED_RAMP;
-#else
-    constexpr int RAMP = 2;
-#endif
+    constexpr int AHEAD = cmin (NPAIR, 4), RAMP = 2;
     u32x2 pr[NPAIR][2];
     __builtin_amdgcn_sched_barrier (0);
 #pragma unroll

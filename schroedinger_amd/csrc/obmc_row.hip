@@ -162,6 +162,10 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
     return 0;
   // the blocks (segments) that can meet a tile and their rows inside it fit the kernel's tables
   const int tw = uv ? RowGeo < 3, true >::kTW : RowGeo < 3, false >::kTW;
+  // (a launch's order table names a tile in 16 bits -- plane_obmc.cpp: obmc_tile_order --: larger planes go to obmc.hip
+  // instead of failing there)
+  if ((long long) ((j.w + tw - 1) / tw) * ((j.h + kRTH - 1) / kRTH) > 0xffff)
+    return 0;
   const int nbi = ((tw - 1 + j.xblen - 1) / j.xbsep + 1) * *ns, nbj = (kRTH - 1 + j.yblen - 1) / j.ybsep + 1;
   int blk_cap, item_cap;
   if (*ns == 2) {

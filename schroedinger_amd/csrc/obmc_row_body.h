@@ -57,10 +57,7 @@ namespace schro {
 namespace {
 
 constexpr int kRThreads = 256;
-#ifndef SCHRO_ROW_TH
-#define SCHRO_ROW_TH 32
-#endif
-constexpr int kRTH = SCHRO_ROW_TH;      // output tile height: obmc_tiles (variants 3, 4); the kernels take it as TH
+constexpr int kRTH = 32;                // output tile height: obmc_tiles (variants 3, 4); the kernels take it as TH (48 / 64: measured slower, HISTORY 8)
 // What depends on the row length (ND dwords of prediction per block row) and on the form of the job:
 //   UV = false: one plane (or the U and the V plane one after the other, NP == 2); a prediction byte is a pixel,
 //     an accumulator word holds two pixels; the tile is 128 pixels wide;

@@ -152,9 +152,7 @@ strip_finish (const StripTaps & t, uint32_t * out)
   }
 }
 
-#ifndef SCHRO_STRIP_WAVES
 #define SCHRO_STRIP_WAVES 6
-#endif
 // Work is handed out statically: the launch has at most as many waves as the device holds at once, wave w takes items w,
 // w + waves, ... (an item = a strip of a segment of a plane) -- every wave the same number of them, give or take one: a
 // launch of 1.1 "rounds" of one item per wave took twice a wave's life.

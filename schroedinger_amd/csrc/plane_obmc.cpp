@@ -309,6 +309,13 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
   std::vector < ObmcJob > all (nplanes);
   std::vector < int >key (nplanes), row_nd (nplanes), row_ns (nplanes, 1);
   uint32_t pred_epoch = 0;      // (r05: this call's number among the context's prediction_only calls, once it has one)
+  // r06: however the call ends, its ring word's event goes onto the queue behind whatever it has launched
+  struct OvfDone {
+    SchroHipContext *c = nullptr;
+    int k = 0;
+    void arm (SchroHipContext * ctx_, int k_) { c = ctx_; k = k_; }
+    ~OvfDone () { if (c && c->ovf_ev[k]) (void) hipEventRecord (c->ovf_ev[k], c->stream); }
+  } ovf_done;
   for (int p = 0; p < nplanes; p++) {
     const SchroHipObmcPlane & pl = planes[p];
     // (residual NULL: nothing to add -- the prediction alone, clamped)
@@ -460,13 +467,16 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         SCHRO_HIP_CHECK (hipHostMalloc ((void **) &ctx->dc_gave_up, 64, hipHostMallocDefault));
         memset (ctx->dc_gave_up, 0, 64);
       }
-      // (one number and one ring word per prediction_only CALL: all its launches share them)
+      // (one number and one ring word per prediction_only CALL: all its launches share them; r06: the word is this
+      // batch's alone until the event behind its launches -- OvfDone below -- has fired and the word has been read)
       if (!pred_epoch) {
         pred_epoch = ++ctx->pred_epoch;
-        const int slot = (int) (pred_epoch % SchroHipContext::kOvfRing);
-        // a word still raised by a batch nobody has asked about keeps naming THAT batch
-        if (!((volatile uint32_t *) ctx->dc_gave_up)[4 + slot])
-          ctx->ovf_epoch[slot] = pred_epoch;
+        if (pred_epoch == 0)      // (0 means "none")
+          pred_epoch = ++ctx->pred_epoch;
+        const int rc = pred_overflow_claim (ctx, pred_epoch);
+        if (rc)
+          return rc;
+        ovf_done.arm (ctx, (int) (pred_epoch % SchroHipContext::kOvfRing));
       }
       overflow = ctx->dc_gave_up + 4 + pred_epoch % SchroHipContext::kOvfRing;
     }
@@ -503,18 +513,13 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // r05, experiments build only (SCHRO_HIP_OBMC_STRIP=1): the 12 / 8 block set on one-byte planes by the strip kernel,
     // accumulator in registers (obmc_strip.hip: bit-exact, 2.5 x slower -- the gather's lines from L2 are the bound, not the
     // LDS tile); its waves take strips of 15 block columns x segments of 8 block rows
-#ifndef SCHRO_OBMC_STRIP
-#define SCHRO_OBMC_STRIP 0
-#endif
-#ifndef SCHRO_OBMC_STRIP_SEG
-#define SCHRO_OBMC_STRIP_SEG 8
-#endif
-    static const bool use_strip = SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP") ? atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP")) != 0 : SCHRO_OBMC_STRIP != 0;
-    bool strip = use_strip && row && !paired && !uv && nd == 3;
+#ifdef SCHRO_HIP_EXPERIMENTS
+    static const bool use_strip = SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP") && atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_STRIP")) != 0;
+    bool strip = use_strip && row && !paired && !uv && nd == 3 && ns == 1;
     for (size_t k = 0; strip && k < jobs.size (); k++)
       strip = obmc_strip_ok (jobs[k]);
     if (strip) {
-      const int seg_rows = SCHRO_OBMC_STRIP_SEG;
+      const int seg_rows = 8;
       int wave_base = 0;
       for (ObmcJob & j : jobs) {
         int strips, segs;
@@ -533,6 +538,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         return rs;
       continue;
     }
+#endif
     // r05: a row launch's weight tables, one per block geometry among its jobs (nearly always one), made here instead of
     // by every tile; the jobs name theirs in `ipw` (a field of the item kernels, which these launches do not use).  A
     // group with more geometries than a table slot holds (35 .. 48) goes out in several launches.
@@ -582,8 +588,10 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
       if (r)
         return r;
 #ifndef SCHRO_HIP_EXPERIMENTS
-      if (row && !d_order)      // (the product's row kernels take their tiles from the table only)
-        return set_error (SCHRO_HIP_EINVAL, "obmc_batch: no tile table for a row launch of %zu jobs", jobs.size ());
+      // (the product's row kernels take their tiles from the table only; obmc_row_form admits no plane that would not
+      // get one -- more than 65535 tiles --, so this is an internal inconsistency, not a property of the caller's planes)
+      if (row && !d_order)
+        return set_error (SCHRO_HIP_EINVAL, "obmc_batch: internal: no tile table for a row launch of %zu jobs", jobs.size ());
 #endif
       if (g_stamps)             // scratch runs: the dump describes the last launch only
         (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);

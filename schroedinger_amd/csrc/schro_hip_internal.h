@@ -9,6 +9,12 @@
 
 #include "schro_hip.h"
 
+// The device-free build of the host code for the sanitizers (schro_hip_dry.h: test infrastructure, never shipped): the
+// HIP runtime's entry points become host stand-ins and launches are dropped.
+#ifdef SCHRO_HIP_DRY
+#include "schro_hip_dry.h"
+#endif
+
 // Switches that force one of the library's kernels where another would be chosen (the tests' second
 // formulations, A/B runs) and the measured-slower forms they select live in the EXPERIMENTS build only
 // (libschro_hip_exp.so: make exp, -DSCHRO_HIP_EXPERIMENTS; tests/test_gpu_experiments.py runs it in child
@@ -58,6 +64,14 @@ round_up (size_t a, size_t b)
 // launch with two hipEventRecord: 8 us of barrier packets per launch, 0.12 ms per profiled bench step.)
 bool profile_launch_events (hipEvent_t * start, hipEvent_t * stop);
 
+#ifdef SCHRO_HIP_DRY
+// (the grid and the block are still evaluated: a launch geometry computed from a bad table shows up in UBSAN)
+#define SCHRO_LAUNCH(kernel, grid, block, shmem, stream, ...)                                      \
+  do {                                                                                             \
+    const dim3 g_ = (grid), b_ = (block);                                                          \
+    (void) g_; (void) b_; (void) (shmem); (void) (stream);                                         \
+  } while (0)
+#else
 #define SCHRO_LAUNCH(kernel, grid, block, shmem, stream, ...)                                      \
   do {                                                                                             \
     hipEvent_t pa_, pb_;                                                                           \
@@ -66,6 +80,7 @@ bool profile_launch_events (hipEvent_t * start, hipEvent_t * stop);
     else                                                                                           \
       hipLaunchKernelGGL (kernel, grid, block, shmem, stream, __VA_ARGS__);                        \
   } while (0)
+#endif
 
 // ---- job tables handed to the kernels (device memory, one per launch) ------
 
@@ -450,8 +465,15 @@ int launch_dc_predict (hipStream_t stream, const DcJob * d_jobs, int njobs, int 
 // the hand-over buffer of the selected queue for a launch of njobs bands of at most max_rows x max_w
 int dc_edge_for (SchroHipContext * ctx, int njobs, int max_rows, int max_w, unsigned long long **edge,
     int *edge_pitch, uint32_t * epoch);
-// non-zero (the launch's epoch) once a dc_skew_kernel strip has given up waiting: reported by the next call
+// non-zero (the launch's epoch) once a dc_skew_kernel strip or a chain-wavelet tile has given up waiting (a device fault
+// of the launch): reported by the next call that looks, enqueueing or synchronising
 int dc_gave_up (SchroHipContext * ctx);
+// r06: the prediction_only OBMC batches whose predictions did not fit 8 bits -- a per-picture ROUTING answer
+// (SCHRO_HIP_ENEEDS_RESIDUAL), looked for by the synchronising calls only (stage completion, schro_hip_synchronize,
+// schro_hip_queue_synchronize) and by schro_hip_obmc_overflowed: an unrelated enqueue is never refused for it
+int pred_overflow_poll (SchroHipContext * ctx);
+// before batch `epoch` is given ring word epoch % kOvfRing: the word's previous owner has finished and its answer is kept
+int pred_overflow_claim (SchroHipContext * ctx, uint32_t epoch);
 }
 // (plane_lowdelay.cpp, beside the plan's other entry points; not part of the public header)
 extern "C" bool schro_hip_dequant_plan_matches (const SchroHipDequantPlan * plan, const SchroHipDequantPlane * planes, int nplanes, int bpp, int arith);
@@ -615,9 +637,17 @@ struct SchroHipContext {
   struct SchroHipDequantPlan *frame_dq_plan;
   void *dq_stage_q[kQueues];    // staging of host-side quantised values, one per queue (in-order reuse)
   size_t dq_stage_size_q[kQueues];
+  // r06: the pixel planes of schro_hip_iiwt_pack_v210_batch's two-pass route, one grow-only block per queue (in-order
+  // reuse: the next call's transform writes them behind this call's pack on the same queue) -- no allocation, no wait per call
+  void *pack_tmp_q[kQueues];
+  size_t pack_tmp_size_q[kQueues];
   static constexpr int kOvfRing = 12;
   uint32_t pred_epoch;
-  uint32_t ovf_epoch[kOvfRing];
+  uint32_t ovf_epoch[kOvfRing];         // the batch that owns ring word k (0: nobody)
+  hipEvent_t ovf_ev[kOvfRing];          // ... recorded behind its launches (r06): the word is read and handed on only once it has fired
+  // r06: batches found raised, oldest first -- not yet named by a synchronising call's status / not yet fetched by
+  // schro_hip_obmc_overflowed (nothing is dropped: a word is cleared only into these lists)
+  std::vector < uint32_t > ovf_unannounced, ovf_unfetched;
   int cus;                      // compute units of the device (launch shaping)
 };
 

@@ -89,3 +89,19 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'#include\s*["<][^">]*oracle|import\s+oracle|from\s+oracle|libschro_oracle|dlopen', t):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_no_compile_time_knobs_outside_the_experiments_guard():
+    """VERDICT r05 hygiene: the product sources carry no scratch switches -- every preprocessor conditional of
+    schroedinger_amd/csrc is the experiments guard (SCHRO_HIP_EXPERIMENTS), the include guard / __HIPCC__ split of
+    the shared header, or C++ feature plumbing; an A/B form lives under the guard or is deleted."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schroedinger_amd", "csrc")
+    allowed = re.compile(r"^\s*#\s*(ifdef|ifndef|if)\s+(defined\s*\(?\s*)?(SCHRO_HIP_EXPERIMENTS|__HIPCC__|__cplusplus)\b")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.h"))):
+        for n, line in enumerate(open(path), 1):
+            if re.match(r"^\s*#\s*(ifdef|ifndef|if)\b", line) and not allowed.match(line):
+                bad.append("%s:%d: %s" % (os.path.basename(path), n, line.strip()))
+    assert not bad, bad

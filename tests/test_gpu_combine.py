@@ -132,8 +132,12 @@ def test_predictions_outside_8_bits_are_refused(ctx):
         run_case(ctx, 320, 240, 3, 0, edit_mv=widen)
     assert ei.value.code == _lib.ENEEDS_RESIDUAL
     epoch = ctx.lib.schro_hip_obmc_prediction_epoch(ctx.h)
-    assert epoch == before + 1 and ("batch %d " % epoch) in str(ei.value)
+    assert epoch == before + 1 and ("batch(es) %d " % epoch) in str(ei.value)
     ctx.synchronize()           # (reported once)
+    # r06: ... and the batch's number stays fetchable until it has been fetched
+    got = (C.c_uint * 4)()
+    assert ctx.lib.schro_hip_obmc_overflowed(ctx.h, got, 4) == 1 and got[0] == epoch
+    assert ctx.lib.schro_hip_obmc_overflowed(ctx.h, got, 4) == 0
     # ... and weights whose prediction can leave 8 bits are refused at the call
     P = synth.motion_params(96, 64, 12, 8, 2, (2, 3, 1), (1, 1))
     d_mv = ctx.upload_bytes(synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 8, 1))
@@ -332,3 +336,47 @@ def test_predictions_alone_over_random_geometries(ctx):
             assert np.array_equal(got, want), (n, w, h, xblen, xbsep, prec, chroma, k, int((got != want).sum()))
         for p in keep + preds:
             p.free()
+
+
+def test_a_pipelining_host_learns_every_batch_that_overflowed(ctx):
+    """r06: twenty prediction_only batches enqueued without a synchronisation in between -- more than the
+    ring of flag words holds --, every third one with a DC value outside 8 bits; calls that only enqueue (more OBMC
+    batches, a DC prediction, a transform) are never refused for another picture's routing answer; the synchronisation
+    at the end names the batches once and schro_hip_obmc_overflowed returns exactly the overflowed ones."""
+    w, h = 96, 64
+    P = synth.motion_params(w, h, 12, 8, 2, (1, 1, 1), (1, 1))
+    g, out = ctx.hp_plane(h, w), ctx.plane(h, w, np.uint8)
+    ctx.upsample_batch([(ctx.upload(synth.picture_u8(h, w, seed=3)), g)])
+    ctx.synchronize()
+    ctx.lib.schro_hip_context_set_stage_completion(ctx.h, 0)
+    try:
+        base = ctx.lib.schro_hip_obmc_prediction_epoch(ctx.h)
+        want, keep = [], []
+        band = ctx.upload(synth.image_s(16, 24, np.int16, seed=1))
+        for n in range(20):
+            mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 8, seed=40 + n, modes=(0.3, 0.3, 0.1, 0.3))
+            if n % 3 == 1:
+                dc = np.flatnonzero((mv["flags"] & 3) == 0)
+                mv["v"][dc[::2], :3] = -700            # (blocks on the rim store their DC as a uint8_t: take many)
+                want.append(base + n + 1)
+            d_mv = ctx.upload_bytes(mv)
+            keep.append(d_mv)
+            ctx.obmc_batch([sa.obmc_plane(d_mv, P, 0, g, g, None, out, prediction_only=True)])
+            ctx.dc_predict_batch([band])                # an unrelated enqueue: not refused
+        with pytest.raises(sa.SchroHipError, match="residual order") as ei:
+            ctx.synchronize()
+        assert ei.value.code == _lib.ENEEDS_RESIDUAL
+        for e in want[:8]:
+            assert (" %d" % e) in str(ei.value) or ("%d," % e) in str(ei.value), (e, str(ei.value))
+        ctx.synchronize()                               # named once
+        got = (C.c_uint * 32)()
+        n = ctx.lib.schro_hip_obmc_overflowed(ctx.h, got, 3)
+        assert n == 3
+        rest = (C.c_uint * 32)()
+        m = ctx.lib.schro_hip_obmc_overflowed(ctx.h, rest, 32)
+        assert sorted(list(got[:n]) + list(rest[:m])) == want
+        assert ctx.lib.schro_hip_obmc_overflowed(ctx.h, rest, 32) == 0
+        for p in keep:
+            p.free()
+    finally:
+        ctx.lib.schro_hip_context_set_stage_completion(ctx.h, 1)
