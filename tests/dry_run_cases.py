@@ -183,19 +183,18 @@ def test_dequant_and_lowdelay_geometries(ctx):
         hc = [int(rng.integers(1, 5)) for _ in range(depth + 1)]
         vc = [int(rng.integers(1, 4)) for _ in range(depth + 1)]
         cbs = ctx.codeblock_layout(w, h, depth, hc, vc, plane.stride, plane.dtype.itemsize)
-        vals = []
         off = 0
         for cb in cbs:
-            n = cb["width"] * cb["height"]
+            n = cb.width * cb.height
             if rng.integers(0, 3) == 0 or n == 0:
-                cb["src_offset"] = -1
+                cb.src_offset = -1
             else:
-                cb["src_bytes"] = 2
-                cb["src_offset"] = off
+                cb.src_bytes = 2
+                cb.src_offset = off
                 off += 2 * n
-            cb["quant_index"] = int(rng.integers(0, 61))
+            cb.quant_index = int(rng.integers(0, 61))
         blob = ctx.upload_bytes(np.zeros(max(off, 2), np.uint8))
-        jobs = [(plane, cbs, blob, bool(rnd & 2))]
+        jobs = [(plane, blob, cbs, bool(rnd & 2))]
         ctx.dequant_batch(jobs, arith=0)
         plan = ctx.dequant_plan(jobs, arith=0)
         plan.run(jobs)
@@ -269,3 +268,71 @@ def test_contexts_on_several_threads(ctx):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not errs, errs
+
+
+def test_scheduler_with_contexts_and_moving_references():
+    """The scheduler on three (dry) devices with REAL contexts: reference pictures allocate and publish an upsampled
+    frame, dependents of other chains fetch it (a peer copy behind the owner's event), pictures retire while others
+    run: the records' lifetimes and the per-device threads under ThreadSanitizer / AddressSanitizer."""
+    sched = sa.Scheduler(3)
+    assert sched.n_devices == 3 and all(c is not None for c in sched.contexts)
+    fmt8 = frames.frame_format(np.uint8, 1, 1)
+    w, h = 176, 144
+    P = synth.motion_params(w, h, 12, 8, 2, (1, 1, 1), (1, 1))
+    mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], 32, seed=3)
+    keep, lock = {}, threading.Lock()
+
+    def reference(number):
+        def run(ctx, dev):
+            plain = frames.DeviceFrame(ctx, fmt8, w, h)
+            up = frames.DeviceFrame(ctx, fmt8, w, h, upsampled=True)
+            sa.check(ctx.lib.schro_upsampled_hipframe_upsample(up.ptr(), plain.ptr()))
+            sched.publish_reference(dev, up.ptr())
+            with lock:
+                keep[number] = (plain, up)
+            return 0
+        return run
+
+    def dependent(number, refs):
+        def run(ctx, dev):
+            f = [C.cast(sched.reference_frame(dev, n), C.POINTER(_lib.Frame)) for n in refs]
+            assert all(f)
+            d_mv = ctx.upload_bytes(mv)
+            planes, outs = [], []
+            for k in range(3):
+                class V:
+                    pass
+                views = []
+                for fr in f:
+                    v = V()
+                    v.ptr, v.stride = fr.contents.components[k].data, fr.contents.components[k].stride
+                    v.pair = k > 0 and fr.contents.is_upsampled == 2
+                    views.append(v)
+                out = ctx.plane(h >> (k > 0), w >> (k > 0), np.uint8)
+                outs.append(out)
+                planes.append(sa.obmc_plane(d_mv, P, k, views[0], views[-1], None, out, prediction_only=1))
+            ctx.obmc_batch(planes)
+            ctx.synchronize()
+            for p in outs + [d_mv]:
+                p.free()
+            return 0
+        return run
+
+    # three chains of anchors; B pictures predict from anchors of two different chains (a foreign reference moves)
+    anchors = []
+    for n in range(9):
+        refs = [anchors[-3]] if len(anchors) >= 3 else []
+        sched.submit(n, refs, True, reference(n) if not refs else reference(n))
+        anchors.append(n)
+    for n in range(9, 27):
+        a, b = anchors[(n * 5) % 9], anchors[(n * 7 + 1) % 9]
+        sched.submit(n, [a, b], False, dependent(n, [a, b]))
+        if n % 4 == 0:
+            sched.retire(n)
+    assert sched.wait() == 0
+    assert sched.moves() > 0
+    for n in range(9):
+        sched.retire(n)
+    sched.close()
+    for plain, up in keep.values():
+        pass                                            # (the scheduler released the published frames; the plain ones go with their contexts)

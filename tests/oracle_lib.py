@@ -24,7 +24,8 @@ def build_oracle():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ORACLE_DIR, "libschro_oracle.so")
+        # (SCHRO_ORACLE_LIB: tests/test_sanitizers.py points the oracle's own tests at its sanitizer build)
+        path = os.environ.get("SCHRO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libschro_oracle.so")
         if not os.path.exists(path):
             build_oracle()
         L = C.CDLL(path)
