@@ -211,9 +211,27 @@ class Workload:
                 c.iiwt_batch(b.iwt_coarse, DEPTH - 1, FILTER)
                 c.queue_mark(8 + s)
                 c.select_queue(s)
+            # (A/B, SCHRO_BENCH_SPLIT_OBMC=1, r06: the chroma planes' upsample + OBMC on a queue of their own beside the luma
+            # launches -- does a longer run of OBMC workgroups, luma and chroma at once, fill the launches' tails?)
+            split_obmc = self.queues > 1 and not alone and os.environ.get("SCHRO_BENCH_SPLIT_OBMC", "0") == "1"
+            if split_obmc:
+                c.select_queue(2 + s)
+                c.queue_wait_mark(12 + s)       # the transform that last read this set's chroma predictions
+                if b.up_chroma:
+                    c.upsample_batch(b.up_chroma)
+                c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
+                c.queue_mark(8 + s)
+                c.select_queue(s)
             if b.up_luma:
                 c.upsample_batch(b.up_luma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3 == 0])
+            if split_obmc:
+                c.queue_wait_mark(8 + s)
+                c.iiwt_batch(b.iwt_combine, DEPTH, FILTER)
+                c.queue_mark(12 + s)
+                if self.queues > 1:
+                    c.select_queue(0)
+                return
             if b.up_chroma:
                 c.upsample_batch(b.up_chroma)
             c.obmc_batch([j for n, j in enumerate(b.pred_jobs) if n % 3])
@@ -418,7 +436,7 @@ def check_picture(wl, s=0, f=0):
     return True
 
 
-def decode_variant(device, frames=8, steps=24, check=True, **geom):
+def decode_variant(device, frames=8, steps=24, check=True, queues=2, **geom):
     """The headline's step on another kind of picture (outside the timed region, a context of its own): the whole pixel
     path -- upsample where the precision has one, OBMC prediction, 3-level DD(9,7) transform with the add -- two batches in
     flight, the classes' times from per-launch events of three steps that run alone, the OBMC class against ITS
@@ -426,7 +444,7 @@ def decode_variant(device, frames=8, steps=24, check=True, **geom):
     import schroedinger_amd as sa
     c = sa.Context(device)
     try:
-        wl = Workload(c, frames, seed=4242, queues=2, **geom)
+        wl = Workload(c, frames, seed=4242, queues=queues, **geom)
         for _ in range(8):
             wl.step()
         c.synchronize()
@@ -584,6 +602,39 @@ def iiwt_2160p(wl, reps=20):
             "wall_ms_two_batches_in_flight": round(wall2, 4), "wall_frac_of_8TBs_two_batches": frac(wall2),
             "note": "kernels_ms: the three launches' own durations (per-launch events); 4 B per sample (2 read + 2 written), "
                     "SURVEY 8(d); read_frac: the 2 B per sample read side alone"}
+
+
+def iiwt_s32_2160p(device, frames=8, reps=12):
+    """r06: the 3-level transform of s32 frames -- what pictures of more than 8 bits get in the core
+    syntax (schrodecoder.c:350-352), the 10-bit professional case -- for DD(9,7) and LeGall(5,3) on 8 x 2160p 4:2:0:
+    8 B per sample (4 read + 4 written).  A context of its own, outside the timed region."""
+    import schroedinger_amd as sa
+    c = sa.Context(device)
+    try:
+        dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+        samples = frames * (W * H * 3 // 2)
+        base = [coeff_plane(h, w, 31 + k).astype(np.int32) for k, (h, w) in enumerate(dims)]
+        pairs = [(c.upload(base[k]), c.plane(h, w, np.int32)) for _ in range(frames) for k, (h, w) in enumerate(dims)]
+        out = {}
+        for filt, name in ((0, "dd97"), (1, "legall53")):
+            for _ in range(3):
+                c.iiwt_batch(pairs, DEPTH, filt)
+            c.profile_enable(True)
+            c.profile_reset()
+            for _ in range(reps):
+                c.iiwt_batch(pairs, DEPTH, filt)
+            c.synchronize()
+            prof = c.profile_read()
+            c.profile_enable(False)
+            ms = (prof["iiwt_finest"][0] + prof["iiwt_coarse"][0]) / reps
+            out[name] = {"kernels_ms": round(ms, 4), "finest_ms": round(prof["iiwt_finest"][0] / reps, 4),
+                         "alg_GBs": round(8 * samples / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_8TBs": round(8 * samples / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "Mpix_per_s": round(frames * W * H / ms / 1e3, 1)}
+        out["workload"] = "3-level IIWT, %d x 3840x2160 4:2:0 s32 per launch set, 8 B per sample (4 read + 4 written)" % frames
+        return out
+    finally:
+        c.close()
 
 
 def quantised_handover(h, w, depth, stride, seed):
@@ -1337,6 +1388,7 @@ def main():
         if world == 1 and not args.headline_only:
             # not part of the timed region: the other sizes / views SURVEY 8(d) asks for
             out["iiwt_2160p"] = iiwt_2160p(wl)
+            out["iiwt_s32_2160p"] = iiwt_s32_2160p(ctx.device)
             out["iiwt_1080p"] = iiwt_1080p(ctx)
             # ... and with 1 and 32 pictures per launch set (one batch in flight / two): where latency ends
             out["iiwt_1080p"]["pictures_per_launch_set"] = {

@@ -105,6 +105,10 @@ obmc_row_has_kernel (int prec, int nd, int np, int ns)
 }
 
 // np: planes per job (1, 2); 3: (U, V) pairs from pair images
+// (r06, measured and not kept: PERSISTENT workgroups -- a grid of what the device holds at once, every workgroup looping
+// over the tiles blockIdx.x + k gridDim.x.  One tile per workgroup 0.167 ms of OBMC per 8 x 2160p step, eight persistent
+// workgroups per CU 0.192, seven 0.192: workgroups that all start together stay in step -- every CU decodes at once,
+// gathers at once, stores at once --, where the dispatcher's own refill staggers them.  HISTORY 9.)
 int
 launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec, int nd, int ns, int np,
     const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs)
@@ -131,7 +135,9 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
 {
   const int ps = uv ? 1 : 0;
   *ns = 1;
-  if (j.ref_ps != ps)
+  // (pair images go with (U, V) jobs and planes with plane jobs -- except at full pel, where a (U, V) job reads the
+  // two PLAIN planes of each reference, j.ref and j.ref_b, and interleaves their rows itself)
+  if (j.ref_ps != (j.prec == 0 ? 0 : ps))
     return 0;
   if (j.prec < 0 || j.prec > 3 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
     return 0;
@@ -148,8 +154,10 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
     return 0;
   if (j.prec == 0) {
     // plain planes: dword-aligned runs from a buffer of whole dwords
-    if (uv || ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1])) & 3) || ((j.ref_stride[0] | j.ref_stride[1]) & 3) || j.ref_stride[0] < j.w
+    if (((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1])) & 3) || ((j.ref_stride[0] | j.ref_stride[1]) & 3) || j.ref_stride[0] < j.w
         || j.ref_stride[1] < j.w || j.w < 4)
+      return 0;
+    if (uv && (!j.ref_b[0] || !j.ref_b[1] || ((((uintptr_t) j.ref_b[0]) | ((uintptr_t) j.ref_b[1])) & 3)))
       return 0;
   } else {
     if ((((uintptr_t) j.ref[0]) | ((uintptr_t) j.ref[1])) & 127)

@@ -227,7 +227,11 @@ issue_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, RawRun < ND > &r)
 {
   const uint32_t al = off & ~3u;
   r.sh = off & 3u;
-  if constexpr (ND == 2) {
+  if constexpr (ND == 1) {
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al, 0, 0);
+    r.c[0] = q.x;
+    r.c[1] = q.y;
+  } else if constexpr (ND == 2) {
     typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
     const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) al, 0, 0);
     r.c[0] = q.x;
@@ -415,13 +419,42 @@ predict_row_plain_abs (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t
   }
 }
 
-// one reference's prediction of a block row in the kernel's form; `ry`: edge class, RK 1: the window's rows lie at a
-// vertical quarter position
-template < int ND, int RK, bool ABS >
+// r06 -- (U, V) jobs at full pel: the references are two PLAIN planes per picture; a block row of n samples is n bytes
+// of each, fetched one after the other and interleaved into the (U, V) byte pairs the rest of the pass works on
+// (v_perm), so the accumulator, the weights and the finish are the pair images' (one decode and one tile for both planes)
+template < int ND >
 __device__ __forceinline__ void
-predict (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, const RowRef & rr, uint32_t ry, int row, uint32_t * out)
+interleave_uv (const uint32_t * u, const uint32_t * v, uint32_t * out)
 {
-  if constexpr (RK == 0) {
+#pragma unroll
+  for (int k = 0; k < ND; k++)
+    out[k] = __builtin_amdgcn_perm (v[k >> 1], u[k >> 1], (k & 1) ? 0x07030602u : 0x05010400u);
+}
+
+// one reference's prediction of a block row in the kernel's form; `ry`: edge class, RK 1: the window's rows lie at a
+// vertical quarter position.  ref_b: the V plane of a (U, V) job on plain planes
+template < int ND, int RK, bool ABS, bool UV >
+__device__ __forceinline__ void
+predict (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, __amdgpu_buffer_rsrc_t ref_b, uint32_t stride, const RowRef & rr, uint32_t ry, int row,
+    uint32_t * out)
+{
+  if constexpr (RK == 0 && UV) {
+    constexpr int NH = (ND + 1) / 2;    // dwords of each plane: ND dwords of (U, V) pairs are 2 ND samples
+    uint32_t u[NH], v[NH];
+    if constexpr (ABS) {
+      predict_row_plain_abs < NH > (job, ref, stride, rr, row, u);
+      predict_row_plain_abs < NH > (job, ref_b, stride, rr, row, v);
+    } else {
+      // (both loads out before either is touched)
+      RawRun < NH > qu, qv;
+      const uint32_t off = (uint32_t) rr.base + __umul24 ((rr.ydb & 0xffffu) + (uint32_t) row, stride);
+      issue_run < NH > (ref, off, qu);
+      issue_run < NH > (ref_b, off, qv);
+      align_run < NH > (qu, u);
+      align_run < NH > (qv, v);
+    }
+    interleave_uv < ND > (u, v, out);
+  } else if constexpr (RK == 0) {
     if constexpr (ABS)
       predict_row_plain_abs < ND > (job, ref, stride, rr, row, out);
     else
@@ -437,6 +470,7 @@ predict (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, const
 struct RowRefs {
   __amdgpu_buffer_rsrc_t rsrc[2];       // the plane's references as buffers: whole bands of 4 rows
   uint32_t stride[2];
+  __amdgpu_buffer_rsrc_t rsrc_b[2];     // r06, (U, V) jobs on plain planes (RK 0): the V planes (rsrc: the U planes), same strides
 };
 
 // the DC value(s) of a block as prediction bytes: a plane's byte four times, UV: (U, V) twice
@@ -468,9 +502,9 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   } else if constexpr (CLS == kREdge) {
     // any mode: both references are read (an unused one at offset 0) and the mode selects
     uint32_t p1[ND];
-    predict < ND, RK, true > (job, refs.rsrc[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
+    predict < ND, RK, true, UV > (job, refs.rsrc[0], refs.rsrc_b[0], refs.stride[0], hb.r[0], blk_ry (hb, 0), row, p);
     __builtin_amdgcn_sched_barrier (0);
-    predict < ND, RK, true > (job, refs.rsrc[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
+    predict < ND, RK, true, UV > (job, refs.rsrc[1], refs.rsrc_b[1], refs.stride[1], hb.r[1], blk_ry (hb, 1), row, p1);
     const uint32_t mode = blk_flags (hb) & 3u;
     const uint32_t dc = dc_bytes < UV > (hb, pl);       // (meaningful in mode 0 only)
     const uint32_t m0 = (mode & 1u) ? 0xffffffffu : 0u, m1 = (mode & 2u) ? 0xffffffffu : 0u;
@@ -481,15 +515,15 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     }
   } else if constexpr (CLS == kRBoth) {
     uint32_t p1[ND];
-    predict < ND, RK, false > (job, refs.rsrc[0], refs.stride[0], hb.r[0], 0u, row, p);
+    predict < ND, RK, false, UV > (job, refs.rsrc[0], refs.rsrc_b[0], refs.stride[0], hb.r[0], 0u, row, p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight (both at once: measured slower)
-    predict < ND, RK, false > (job, refs.rsrc[1], refs.stride[1], hb.r[1], 0u, row, p1);
+    predict < ND, RK, false, UV > (job, refs.rsrc[1], refs.rsrc_b[1], refs.stride[1], hb.r[1], 0u, row, p1);
 #pragma unroll
     for (int k = 0; k < ND; k++)
       p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
   } else {
     constexpr int r = CLS == kRRef1 ? 1 : 0;
-    predict < ND, RK, false > (job, refs.rsrc[r], refs.stride[r], hb.r[r], 0u, row, p);
+    predict < ND, RK, false, UV > (job, refs.rsrc[r], refs.rsrc_b[r], refs.stride[r], hb.r[r], 0u, row, p);
   }
   if (it >= hi)
     return;
@@ -804,7 +838,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 {
   typedef RowGeo < ND, UV, NS > G;
   static_assert (!UV || NP == 1, "a UV job is one virtual plane of (U, V) samples");
-  static_assert (!UV || RK != 0, "pair images are half-pel images: plain planes come one per component");
   static_assert (NS == 1 || (NS == 2 && ND == 3), "segments: halves of 12 bytes");
   constexpr int kRTW = G::kTW, ps = UV ? 1 : 0;
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * G::kAccW + 3];
@@ -857,7 +890,30 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   const int x_hi = min (x_lo + kRTW, job.w), y_hi = min (y_lo + TH, job.h);
   constexpr int nplanes = NP;   // (every job of a launch has NP planes: the host groups them so)
 
+  // scratch builds (experiments only; scripts/build_variant_one.sh ... -DSCHRO_HIP_EXPERIMENTS -DSCHRO_ROW_REP_SETUP=2): what
+  // a phase costs in LAUNCH time, as opposed to where a tile's lifetime goes -- everything in front of the passes (clear,
+  // tables, vectors, decode, sort, items) or the passes themselves done N times over (the pictures are then wrong)
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_REP_SETUP)
+  constexpr int kRepSetup = SCHRO_ROW_REP_SETUP;
+#else
+  constexpr int kRepSetup = 1;
+#endif
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_REP_PASSES)
+  constexpr int kRepPasses = SCHRO_ROW_REP_PASSES;
+#else
+  constexpr int kRepPasses = 1;
+#endif
+  const int xblen = job.xblen, yblen = job.yblen;
+  const int par = UV ? 0 : job.xoff & 1;        // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
+  const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
+  int ibase[kRRim + 1];         // first item of each class
+  bool exact = false;           // a DC value outside 0..255 in the tile: 16-bit sums may wrap
+  int nrim = 0;
   constexpr int kAccQuads = (TH * G::kAccW + 3) / 4;   // the accumulator tile is cleared 16 bytes at a time
+#pragma unroll
+  for (int rep_ = 0; rep_ < kRepSetup; rep_++) {
+  if (rep_)
+    __syncthreads ();
   for (int it = tid; it < kAccQuads; it += kRThreads)
     reinterpret_cast < u32x4 * >(acc)[it] = (u32x4) { 0u, 0u, 0u, 0u };
   // r05: the plane geometry's weights come ready-made from the host (the job's `ipw` names its table in `wtabs`,
@@ -882,9 +938,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     s_wide = 0;
   }
 
-  const int xblen = job.xblen, yblen = job.yblen;
-  const int par = UV ? 0 : job.xoff & 1;        // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
-  const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
   int nblk;
   {
     // ---- decode: every block whose footprint meets the tile, one per thread and round -----
@@ -1077,7 +1130,6 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     incl += __builtin_amdgcn_update_dpp (0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
     sbase = incl - cnt;
   }
-  int ibase[kRRim + 1];         // first item of each class
 #pragma unroll
   for (int c = 0; c <= kRRim; c++)
     ibase[c] = __builtin_amdgcn_readlane (sbase, row_slot_base (c));
@@ -1107,10 +1159,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     if (n & 1)
       ip[r] = (uint16_t) pair;
   }
-  const bool exact = __builtin_amdgcn_readfirstlane (s_wide) != 0;      // a DC value outside 0..255 in the tile: 16-bit sums may wrap
-  const int nrim = __builtin_amdgcn_readfirstlane (s_nrim);
+  exact = __builtin_amdgcn_readfirstlane (s_wide) != 0;
+  nrim = __builtin_amdgcn_readfirstlane (s_nrim);
   __syncthreads ();
   RSTAMP (3);
+  }                             // (kRepSetup)
 
   // ---- per plane of the job: accumulate, finish -----------------------------------------------
 #pragma unroll
@@ -1125,6 +1178,10 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
     // UV: the V plane's residual and picture (the references are the pair images in io)
     PlaneIO iov = io;
     if constexpr (UV) {
+      if constexpr (RK == 0) {  // plain planes: the V planes of the references (the rim path reads them by component)
+        iov.ref[0] = job.ref_b[0];
+        iov.ref[1] = job.ref_b[1];
+      }
       iov.residual = job.residual_b;
       iov.out = job.out_b;
       iov.residual_stride = job.residual_stride_b;
@@ -1160,14 +1217,20 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       const uint32_t bytes = RK == 0 ? (uint32_t) job.ref_stride[r] * (uint32_t) (job.h - 1) + (((uint32_t) job.w + 3u) & ~3u)
           : (uint32_t) job.ref_stride[r] * (uint32_t) ((job.h + 3) >> 2);
       refs.rsrc[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) io.ref[r], 0, (int) bytes, 0x00020000);
+      refs.rsrc_b[r] = refs.rsrc[r];
+      if constexpr (UV && RK == 0)
+        refs.rsrc_b[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) iov.ref[r], 0, (int) bytes, 0x00020000);
     }
 #define SCHRO_ROW_CLASS(C) row_class < ND, UV, C, RK, NS > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
     ibase[C], ibase[C + 1], exact, &turn)
-    SCHRO_ROW_CLASS (kRBoth);
-    SCHRO_ROW_CLASS (kRRef0);
-    SCHRO_ROW_CLASS (kRRef1);
-    SCHRO_ROW_CLASS (kRDc);
-    SCHRO_ROW_CLASS (kREdge);
+#pragma unroll
+    for (int rep_ = 0; rep_ < kRepPasses; rep_++) {
+      SCHRO_ROW_CLASS (kRBoth);
+      SCHRO_ROW_CLASS (kRRef0);
+      SCHRO_ROW_CLASS (kRRef1);
+      SCHRO_ROW_CLASS (kRDc);
+      SCHRO_ROW_CLASS (kREdge);
+    }
 #undef SCHRO_ROW_CLASS
     RSTAMP (4);
     // picture-rim blocks: exact clamp / fold path
@@ -1187,7 +1250,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #define SCHRO_ROW_SLOW(cb, dcpl) do { \
           const int md = (int) (blk_flags (hb) & 3u) | (blk_dc (hb, dcpl) << 8);       /* (the DC part is read in mode 0 only) */ \
           if constexpr (RK == 0) \
-            row_slow < 0, G, UV > (job, io, cb, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact); \
+            row_slow < 0, G, UV > (job, (UV && cb) ? iov : io, cb, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact); \
           else if (RK == 1 && job.prec == 1) \
             row_slow < 1, G, UV > (job, io, cb, bx, by, md, fx, fy, r2, s2, x_lo, y_lo, xfold_hi, yfold_hi, s_wx, s_wy, acc, par, exact); \
           else \
@@ -1239,11 +1302,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   }
   RSTAMP (9);
 #ifdef SCHRO_HIP_EXPERIMENTS
-  if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) {   // absolute start / end, where it ran
+  if (job.stamps && threadIdx.x == 0 && blockIdx.x < 16384) {  // absolute start / end, where it ran
     job.stamps[blockIdx.x * 16 + 12] = t_start;
     job.stamps[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime ();
-    job.stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg ((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
-    job.stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg ((20 << 0) | (0 << 6) | (31 << 11));     // XCC_ID
+    job.stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg ((4 << 0) | (0 << 6) | (31 << 11)); // HW_ID
+    job.stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg ((20 << 0) | (0 << 6) | (31 << 11));        // XCC_ID
   }
 #else
   (void) t_start;

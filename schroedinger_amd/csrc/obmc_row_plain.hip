@@ -23,6 +23,14 @@ SCHRO_ROW_KERNEL (obmc_row_plain_p_2_1, 6, 2, 1, false, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_2_2, 6, 2, 2, false, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_3_1, 8, 3, 1, false, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_4_1, 4, 4, 1, false, kRTH, true, 0)
+// r06: the U and V planes of a picture as ONE (U, V) job -- the two plain planes' rows interleaved in registers, then the
+// pair images' accumulator and finish (64-pixel tiles, one decode, one pass per item for both planes)
+SCHRO_ROW_KERNEL (obmc_row_plain_uv_2, 5, 2, 1, true, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_uv_3, 7, 3, 1, true, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_uv_4, 4, 4, 1, true, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_2, 5, 2, 1, true, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_3, 8, 3, 1, true, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_4, 4, 4, 1, true, kRTH, true, 0)
 // the 24 / 16 block set's luma rows: two segments of 12
 SCHRO_ROW_KERNEL (obmc_row_plain_h2_3_1, 6, 3, 1, false, kRTH, false, 0, 2)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_3_1, 7, 3, 1, false, kRTH, true, 0, 2)
@@ -36,12 +44,18 @@ obmc_row_kernel_plain (int nd, int np, int ns, bool nores)
     return nd == 3 && np == 1 ? (nores ? obmc_row_plain_p_h2_3_1 : obmc_row_plain_h2_3_1) : nullptr;
   if (nores)
     switch (nd * 10 + np) {
+      case 23: return obmc_row_plain_p_uv_2;
+      case 33: return obmc_row_plain_p_uv_3;
+      case 43: return obmc_row_plain_p_uv_4;
       case 21: return obmc_row_plain_p_2_1;
       case 22: return obmc_row_plain_p_2_2;
       case 31: return obmc_row_plain_p_3_1;
       case 41: return obmc_row_plain_p_4_1;
     }
   switch (nd * 10 + np) {
+    case 23: return obmc_row_plain_uv_2;
+    case 33: return obmc_row_plain_uv_3;
+    case 43: return obmc_row_plain_uv_4;
     case 21: return obmc_row_plain_2_1;
     case 22: return obmc_row_plain_2_2;
     case 31: return obmc_row_plain_3_1;

@@ -425,17 +425,26 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // r04: the U and V planes of a picture from PAIR images: one job, one fetch per tap for both
     // (obmc_row.hip, UV form); what it does not take (eighth pel, other weights, long rows) reads
     // its component out of the pair images in obmc.hip
-    if (a.ref_ps && b.ref_ps && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
-        && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1] && planes[p].prediction_only == planes[p + 1].prediction_only && !a.out_s16) {
+    // r06: ... and at full pel the U and V planes of a picture (plain planes: two per reference) the same way -- the job
+    // carries the V planes in ref_b and the kernel interleaves the rows
+    const bool uv_plain = a.prec == 0 && b.prec == 0 && !a.ref_ps && !b.ref_ps;
+    if (((a.ref_ps && b.ref_ps && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1]) || uv_plain)
+        && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
+        && planes[p].prediction_only == planes[p + 1].prediction_only && !a.out_s16 && !b.out_s16) {
       int ns;
-      const int nd = obmc_row_form (a, true, &ns);
+      ObmcJob au = a;
+      au.ref_b[0] = b.ref[0];
+      au.ref_b[1] = b.ref[1];
+      const int nd = obmc_row_form (au, true, &ns);
       if (nd) {
         row_nd[p] = row_nd[p + 1] = nd;
         row_ns[p] = row_ns[p + 1] = ns;
         key[p] = key[p + 1] = a.prec | (1 << 4) | (nd << 8) | (1 << 16) | (1 << 18) | (planes[p].prediction_only == 1 ? 1 << 19 : 0) | (ns << 20);
         p++;
+        continue;
       }
-      continue;
+      if (!uv_plain)            // (pair images outside the row kernels' case: obmc.hip reads the components out of them)
+        continue;
     }
     if (pairs_pay && row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && same_blocks (a, b)
         && obmc_row_has_kernel (a.prec, row_nd[p], 2, row_ns[p])) {

@@ -9,7 +9,8 @@ mkdir -p ../../build/v_$name
 x=""; case $file in *.cpp) x="-x hip";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. "$@" $x -c $file -o ../../build/v_$name/${file%.*}.o
 objs=""
-for f in context plane_iiwt plane_frameops plane_lowdelay plane_obmc iiwt_pack frame scheduler iiwt iiwt_reg iiwt_haar frameops obmc obmc_row obmc_strip lowdelay dequant; do
+for f in $(sed -n 's/^SRCS = //p' Makefile); do
+  f=${f%.*}
   if [ "$f" = "${file%.*}" ]; then objs="$objs ../../build/v_$name/$f.o"; else objs="$objs $f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/libschro_hip_$name.so $objs

@@ -14,8 +14,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     print("%-70s calls %5s avg %9.1f ns" % (r["Name"][:70], r["Calls"], float(r["AverageNs"])))
 PY
 }
-run fullpel prec=0 check=0
-run eighth prec=3 check=0
-run b2416 xblen=24 xbsep=16 check=0
-run p1080 w=1920 h=1080 check=0
-run headline check=0
+# (queues=1: one batch in flight, so a kernel's average duration is its own)
+run fullpel prec=0 check=0 queues=1
+run eighth prec=3 check=0 queues=1
+run b2416 xblen=24 xbsep=16 check=0 queues=1
+run p1080 w=1920 h=1080 check=0 queues=1
+run headline check=0 queues=1
