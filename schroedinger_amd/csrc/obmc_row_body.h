@@ -527,6 +527,18 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   }
   if (it >= hi)
     return;
+  // scratch builds (experiments only): the passes with their loads alone -- the prediction goes into ONE accumulator word
+  // and nothing else is done with it --, VERDICT r05 "what's weak" 2: is the gather by itself the launch?
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_PASS_LOADS_ONLY)
+  {
+    uint32_t x = 0;
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      x ^= p[k];
+    atomicAdd (acc + (it & 1023), x);
+    return;
+  }
+#endif
   int half;
   uint32_t *aw = acc_word < G, UV > (acc, par, hb.x, hb.y + row, &half);       // (block origins + par are even: half == 0)
   // the row's 2 * ND weight pairs (zero beyond the block: no tests in the loop), read in one go.  A word's two
