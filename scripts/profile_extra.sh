@@ -5,7 +5,7 @@
 set -e
 repo=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-for leg in "iiwt_1080p 8" "lowdelay_8k"; do
+for leg in "iiwt_1080p 8" "iiwt_2160p" "iiwt_s32_2160p" "lowdelay_8k"; do
   set -- $leg
   rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/x_$1 -o run -- python3 $repo/scripts/only.py $@ > $repo/gpurun_out/x_$1.log 2>&1
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "inst SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY"; do
@@ -14,7 +14,7 @@ for leg in "iiwt_1080p 8" "lowdelay_8k"; do
   done
 done
 cd $repo
-for leg in iiwt_1080p lowdelay_8k; do
+for leg in iiwt_1080p iiwt_2160p iiwt_s32_2160p lowdelay_8k; do
   echo "== $leg kernel stats (calls, total ns, average ns, min ns, max ns)"
   python3 -c "
 import csv, sys
