@@ -172,26 +172,26 @@ mas8_row4 (uint32_t d0, uint32_t d1, uint32_t d2, int *out)
 // byte-interleaved (schro_hip_internal.h: pair images).  Everything else is the one-plane kernel.
 constexpr int kUpMaxLD = 2 * (kUpTW / 8 + 8);   // LDS dwords per row of the pair form (48; one plane: 40)
 
+// the 16-byte source chunks of a tile a lane fetches (one plane: 23 rows x 10 chunks; a pair: x 12)
+template < bool PAIR > constexpr int kUpFetch = ((kUpTH + 7) * ((PAIR ? 2 : 1) * ((PAIR ? kUpTW / 2 : kUpTW) / 4 + 8) / 4) + kThreads - 1) / kThreads;
+
+// phase 1, first half: the tile's source chunks into registers -- picture coordinates clamped on the way in
 template < bool PAIR >
 __device__ __forceinline__ void
-upsample_body (const UpsampleJob & job, int t, uint32_t (*s0)[kUpMaxLD], uint32_t (*s2)[kUpMaxLD])
+upsample_fetch (const UpsampleJob & job, int t, u32x4 * q_out)
 {
-  // LDS rows, per plane: dword i holds pixels x0 - 16 + 4 i .. + 3, so that 16-byte source chunks
-  // land aligned; the filters use dwords 3 .. kTWp / 4 + 4 (pixels x0 - 4 .. x0 + kTWp + 3)
-  constexpr int kTWp = PAIR ? kUpTW / 2 : kUpTW;        // tile width in pixels of a plane
-  constexpr int kHalfLD = kTWp / 4 + 8;                 // LDS dwords per plane and row
+  constexpr int kTWp = PAIR ? kUpTW / 2 : kUpTW, kHalfLD = kTWp / 4 + 8;
   constexpr int kUpCh = (PAIR ? 2 : 1) * kHalfLD / 4, kHalfCh = kHalfLD / 4;
-  constexpr int kHalfDW = kTWp / 4 + 2, kVDW = (PAIR ? 2 : 1) * kHalfDW;
-  constexpr int ps = PAIR ? 1 : 0;
-  static_assert ((PAIR ? 2 : 1) * kHalfLD <= kUpMaxLD, "LDS row");
-
   const int tx = t % job.tiles_x, ty = t / job.tiles_x;
   const int x0 = tx * kTWp, y0 = ty * kUpTH;
   const int w = job.w, h = job.h;
   const int tid = threadIdx.x;
-
-  // one 16-byte chunk per lane: picture coordinates clamped on the way in
-  for (int it = tid; it < (kUpTH + 7) * kUpCh; it += kThreads) {
+#pragma unroll
+  for (int n = 0; n < kUpFetch < PAIR >; n++) {
+    const int it = tid + n * kThreads;
+    q_out[n] = (u32x4) { 0u, 0u, 0u, 0u };
+    if (it >= (kUpTH + 7) * kUpCh)
+      continue;
     const int ly = it / kUpCh, c = it - ly * kUpCh;
     const int half = PAIR ? c / kHalfCh : 0, cc = c - half * kHalfCh;
     const uint8_t *src = half ? job.src_b : job.src;
@@ -210,9 +210,42 @@ upsample_body (const UpsampleJob & job, int t, uint32_t (*s0)[kUpMaxLD], uint32_
         d[k >> 2] |= (uint32_t) gload < uint8_t > (row + clampi (gx + k, 0, w - 1)) << (8 * (k & 3));
       q = (u32x4) { d[0], d[1], d[2], d[3] };
     }
-    *reinterpret_cast < u32x4 * >(&s0[ly][4 * c]) = q;
+    q_out[n] = q;
   }
-  __syncthreads ();
+}
+
+// ... second half: into LDS.  LDS rows, per plane: dword i holds pixels x0 - 16 + 4 i .. + 3, so that 16-byte source chunks
+// land aligned; the filters use dwords 3 .. kTWp / 4 + 4 (pixels x0 - 4 .. x0 + kTWp + 3)
+template < bool PAIR >
+__device__ __forceinline__ void
+upsample_stage (const u32x4 * q, uint32_t (*s0)[kUpMaxLD])
+{
+  constexpr int kTWp = PAIR ? kUpTW / 2 : kUpTW, kHalfLD = kTWp / 4 + 8, kUpCh = (PAIR ? 2 : 1) * kHalfLD / 4;
+#pragma unroll
+  for (int n = 0; n < kUpFetch < PAIR >; n++) {
+    const int it = (int) threadIdx.x + n * kThreads;
+    if (it < (kUpTH + 7) * kUpCh) {
+      const int ly = it / kUpCh, c = it - ly * kUpCh;
+      *reinterpret_cast < u32x4 * >(&s0[ly][4 * c]) = q[n];
+    }
+  }
+}
+
+// phases 2 and 3 (s0 holds the tile's source rows): vertical filter, horizontal filters, the stores
+template < bool PAIR >
+__device__ __forceinline__ void
+upsample_filter_store (const UpsampleJob & job, int t, uint32_t (*s0)[kUpMaxLD], uint32_t (*s2)[kUpMaxLD])
+{
+  constexpr int kTWp = PAIR ? kUpTW / 2 : kUpTW;        // tile width in pixels of a plane
+  constexpr int kHalfLD = kTWp / 4 + 8;                 // LDS dwords per plane and row
+  constexpr int kHalfDW = kTWp / 4 + 2, kVDW = (PAIR ? 2 : 1) * kHalfDW;
+  constexpr int ps = PAIR ? 1 : 0;
+  static_assert ((PAIR ? 2 : 1) * kHalfLD <= kUpMaxLD, "LDS row");
+
+  const int tx = t % job.tiles_x, ty = t / job.tiles_x;
+  const int x0 = tx * kTWp, y0 = ty * kUpTH;
+  const int w = job.w, h = job.h;
+  const int tid = threadIdx.x;
 
   for (int it = tid; it < kUpTH * kVDW; it += kThreads) {
     const int gi = it % kVDW, ly = it / kVDW;
@@ -403,11 +436,69 @@ void upsample_kernel (const UpsampleJob * __restrict__ jobs, int njobs)
   __shared__ __attribute__ ((aligned (16))) uint32_t s2[kUpTH][kUpMaxLD];      // v-half
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   const UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
-  if (job.src_b)                // (uniform over the workgroup)
-    upsample_body < true > (job, bid - job.tile_base, s0, s2);
-  else
-    upsample_body < false > (job, bid - job.tile_base, s0, s2);
+  if (job.src_b) {              // (uniform over the workgroup)
+    u32x4 q[kUpFetch < true >];
+    upsample_fetch < true > (job, bid - job.tile_base, q);
+    upsample_stage < true > (q, s0);
+    __syncthreads ();
+    upsample_filter_store < true > (job, bid - job.tile_base, s0, s2);
+  } else {
+    u32x4 q[kUpFetch < false >];
+    upsample_fetch < false > (job, bid - job.tile_base, q);
+    upsample_stage < false > (q, s0);
+    __syncthreads ();
+    upsample_filter_store < false > (job, bid - job.tile_base, s0, s2);
+  }
 }
+
+#ifdef SCHRO_HIP_EXPERIMENTS
+// r06, VERDICT r05 item 3 (measured, HISTORY 9; experiments build, SCHRO_HIP_UPSAMPLE_PERSIST = workgroups per CU): a grid of
+// what the device holds at once, a workgroup takes tiles blockIdx.x, + gridDim.x, ... and asks for the NEXT tile's source
+// chunks -- registers -- right behind the barrier that follows staging the current one, so that they travel while the
+// current tile is filtered and stored.  All tiles of a launch are of one form (pair images or planes).
+template < bool PAIR >
+__device__ __forceinline__ void
+upsample_persist_body (const UpsampleJob * __restrict__ jobs, int njobs, int total, uint32_t (*s0)[kUpMaxLD], uint32_t (*s2)[kUpMaxLD])
+{
+  u32x4 q[kUpFetch < PAIR >];
+  int v = blockIdx.x;
+  if (v >= total)
+    return;
+  int bid = xcd_tile_id (v, total);
+  UpsampleJob job = jobs[find_job (jobs, njobs, bid)];
+  upsample_fetch < PAIR > (job, bid - job.tile_base, q);
+  for (;;) {
+    upsample_stage < PAIR > (q, s0);
+    __syncthreads ();
+    const int vn = v + (int) gridDim.x;
+    UpsampleJob jn = job;
+    int bn = bid;
+    if (vn < total) {
+      bn = xcd_tile_id (vn, total);
+      jn = jobs[find_job (jobs, njobs, bn)];
+      upsample_fetch < PAIR > (jn, bn - jn.tile_base, q);
+    }
+    upsample_filter_store < PAIR > (job, bid - job.tile_base, s0, s2);
+    if (vn >= total)
+      break;
+    __syncthreads ();           // (s0 / s2 are read until the tile's last store has been issued)
+    v = vn;
+    bid = bn;
+    job = jn;
+  }
+}
+
+__global__ __launch_bounds__ (kThreads)
+void upsample_persist_kernel (const UpsampleJob * __restrict__ jobs, int njobs, int total)
+{
+  __shared__ __attribute__ ((aligned (16))) uint32_t s0[kUpTH + 7][kUpMaxLD];
+  __shared__ __attribute__ ((aligned (16))) uint32_t s2[kUpTH][kUpMaxLD];
+  if (jobs[0].src_b)
+    upsample_persist_body < true > (jobs, njobs, total, s0, s2);
+  else
+    upsample_persist_body < false > (jobs, njobs, total, s0, s2);
+}
+#endif
 
 // ---- packed copy-out -----------------------------------------------------------
 // schro_frame_convert (packed dest, planar u8 src), schroframe.c:869-979, as one pass:
@@ -785,8 +876,13 @@ upsample_tile_geometry (int *tw, int *th)
 }
 
 int
-launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs, int njobs, int total_tiles)
+launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs, int njobs, int total_tiles, int persist_grid)
 {
+#ifdef SCHRO_HIP_EXPERIMENTS
+  if (persist_grid > 0 && persist_grid < total_tiles)
+    SCHRO_LAUNCH (upsample_persist_kernel, dim3 (persist_grid), dim3 (kThreads), 0, stream, d_jobs, njobs, total_tiles);
+  else
+#endif
   SCHRO_LAUNCH (upsample_kernel, dim3 (total_tiles), dim3 (kThreads), 0, stream, d_jobs,
       njobs);
   hipError_t e = hipGetLastError ();

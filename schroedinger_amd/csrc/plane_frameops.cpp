@@ -318,7 +318,17 @@ schro_hip_upsample_batch (SchroHipContext * ctx, const SchroHipUpsamplePlane * p
   if (r)
     return r;
   ProfileScope ps (ctx, SCHRO_HIP_KERNEL_UPSAMPLE);
-  return launch_upsample (ctx->stream, (const UpsampleJob *) d_jobs, nplanes, tile_base);
+  // scratch runs: SCHRO_HIP_UPSAMPLE_PERSIST = persistent workgroups per CU (launches whose planes are all of one form)
+  static const int persist = SCHRO_ENV ("SCHRO_HIP_UPSAMPLE_PERSIST") ? atoi (SCHRO_ENV ("SCHRO_HIP_UPSAMPLE_PERSIST")) : 0;
+  int grid = 0;
+  if (persist > 0) {
+    bool one_form = true;
+    for (int p = 1; p < nplanes; p++)
+      one_form = one_form && (!planes[p].src_v == !planes[0].src_v);
+    if (one_form)
+      grid = persist * ctx->cus / 8 * 8;
+  }
+  return launch_upsample (ctx->stream, (const UpsampleJob *) d_jobs, nplanes, tile_base, grid);
 }
 
 }                               // extern "C"

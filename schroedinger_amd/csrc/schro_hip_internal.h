@@ -452,8 +452,9 @@ int launch_pack (hipStream_t stream, const PackJob * d_jobs, int njobs, int tota
 int launch_shift_right (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int bpp, int shift);
 int launch_add (hipStream_t stream, const ConvertJob * d_jobs, int njobs, int total_tiles, int src_bpp);
 void pack_tile_geometry (int *groups_x, int *rows);
+// persist_grid > 0 (experiments build): that many persistent workgroups (all jobs of one form: pair images or planes)
 int launch_upsample (hipStream_t stream, const UpsampleJob * d_jobs,
-    int njobs, int total_tiles);
+    int njobs, int total_tiles, int persist_grid);
 void upsample_tile_geometry (int *tw, int *th);
 int launch_slices (hipStream_t stream, const SliceJob * d_jobs, int njobs, const SliceParams & P, int bpp, int arith,
     bool aligned16);

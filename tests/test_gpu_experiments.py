@@ -13,7 +13,8 @@ with the same oracle on the whole case matrix of its test file:
   * SCHRO_HIP_OBMC_MERGE=2: U + V planes of one-component images as one job (obmc_row_kernel_*_2) always;
   * SCHRO_HIP_IIWT_CHAIN=1: every level of the register wavelet in one launch (r04, iiwt_reg.hip);
   * SCHRO_HIP_OBMC_STRIP=1: the 12 / 8 block set's luma planes by the strip kernel (r05, obmc_strip.hip: accumulator in
-    registers, no LDS tile -- a third formulation of the same arithmetic; measured 2.5 x slower).
+    registers, no LDS tile -- a third formulation of the same arithmetic; measured 2.5 x slower);
+  * SCHRO_HIP_UPSAMPLE_PERSIST=n: the upsample as n persistent workgroups per CU that prefetch the next tile (r06).
 """
 import os
 import subprocess
@@ -59,4 +60,11 @@ def test_register_wavelet_chain_form():
 
 def test_strip_kernel_takes_the_12_8_luma_planes():
     out = run(["test_gpu_obmc.py", "test_gpu_combine.py", "test_gpu_stream.py", "test_gpu_fuzz.py"], env={"SCHRO_HIP_OBMC_STRIP": "1"})
+    assert "passed" in out
+
+
+def test_persistent_prefetching_upsample():
+    """r06 (measured, not the product's form): a grid of one workgroup per CU that loops over the
+    tiles and asks for the next tile's source before it filters and stores the current one -- the same planes."""
+    out = run(["test_gpu_frameops.py", "test_gpu_stream.py"], env={"SCHRO_HIP_UPSAMPLE_PERSIST": "1"})
     assert "passed" in out
