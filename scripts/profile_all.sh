@@ -11,4 +11,7 @@ scripts/pmc_obmc_mix.sh > gpurun_out/pmc_mix.log 2>&1
 repo=$(pwd)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/x_lowdelay_8k -o run -- python3 $repo/scripts/only.py lowdelay_8k > $repo/gpurun_out/x_lowdelay_8k.log 2>&1)
 scripts/pmc_lowdelay.sh > gpurun_out/pmc_lowdelay.log 2>&1
+# r06: the transforms by themselves (plain 2160p: north_star's own figure; 1080p; s32) and the decode variants' kernels
+scripts/profile_extra.sh > gpurun_out/profile_extra.log 2>&1
+scripts/profile_variants.sh > gpurun_out/variants.txt 2>&1
 echo done
