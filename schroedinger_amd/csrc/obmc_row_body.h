@@ -915,6 +915,11 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #else
   constexpr int kRepPasses = 1;
 #endif
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_REP_FINISH)
+  constexpr int kRepFinish = SCHRO_ROW_REP_FINISH;
+#else
+  constexpr int kRepFinish = 1;
+#endif
   const int xblen = job.xblen, yblen = job.yblen;
   const int par = UV ? 0 : job.xoff & 1;        // block origins xbsep * i - xoff are odd: shift the accumulator by a pixel
   const int xfold_hi = job.nbx * job.xbsep - job.xoff, yfold_hi = job.nby * job.ybsep - job.yoff;
@@ -1289,6 +1294,8 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 #undef SCHRO_ROW_PREFETCH
     __syncthreads ();
     RSTAMP (6);
+#pragma unroll
+    for (int rep_ = 0; rep_ < kRepFinish; rep_++)
     if constexpr (UV) {
       if (fast) {
         if (NORES && !exact)
