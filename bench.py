@@ -136,13 +136,13 @@ class Workload:
     are the decoder's stage dependencies (OBMC after its wavelet; a batch's frames are rewritten
     only after the OBMC that read them)."""
 
-    def __init__(self, ctx, frames, seed, queues=2, w=W, h=H, xblen=XBLEN, xbsep=XBSEP, prec=PREC):
+    def __init__(self, ctx, frames, seed, queues=2, w=W, h=H, xblen=XBLEN, xbsep=XBSEP, prec=PREC, weights=(1, 1, 1)):
         """w .. prec (r06): the headline's configuration by default; the other pictures a decoder meets -- 1080p, the
         reference encoder's default full-pel vectors, eighth pel, the 24 / 16 block set -- run the same step."""
         self.ctx, self.frames, self.queues = ctx, frames, queues
         self.combine = os.environ.get("SCHRO_BENCH_COMBINE", "1") != "0"
         self.w, self.h, self.prec = w, h, prec
-        self.P = synth.motion_params(w, h, xblen, xbsep, prec, (1, 1, 1), (1, 1))
+        self.P = synth.motion_params(w, h, xblen, xbsep, prec, tuple(weights), (1, 1))
         dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
         self.dims = dims
         # two references (planar u8) per group of REF_GROUP pictures, shared by the batches as between two
@@ -470,6 +470,7 @@ def decode_variant(device, frames=8, steps=24, check=True, queues=2, **geom):
                "pictures_per_step": frames, "width": w, "height": h,
                "blocks": "%dx%d / %dx%d" % (wl.P["xblen_luma"], wl.P["yblen_luma"], wl.P["xbsep_luma"], wl.P["ybsep_luma"]),
                "mv_precision": wl.prec,
+               "picture_weights": "%d, %d / 2^%d" % (wl.P["picture_weight_1"], wl.P["picture_weight_2"], wl.P["picture_weight_bits"]),
                "obmc_ms_per_step": round(obmc_ms, 4),
                "obmc_alg_bytes_per_step": obmc_bytes,
                "obmc_frac_of_8TBs": round(obmc_bytes / (obmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -1421,10 +1422,13 @@ def main():
             out["fullpel_2160p"] = decode_variant(dev, prec=0)
             out["eighthpel_2160p"] = decode_variant(dev, prec=3)
             out["blocks_24_16_2160p"] = decode_variant(dev, xblen=24, xbsep=16)
+            # (weighted prediction -- a fade: 3, 5 / 2^3; r06: the row kernels' weighted blend.  obmc.hip's general kernel, which
+            # such pictures ran until then and which pictures with a gain or a negative weight still run: 2.22 ms of OBMC per step)
+            out["weighted_2160p"] = decode_variant(dev, weights=(3, 5, 3))
             out["decode_1080p"] = decode_variant(dev, w=1920, h=1080)
             out["decode_1080p"]["pictures_32_per_step"] = decode_variant(dev, frames=32, w=1920, h=1080, check=False)
             if any(str(out[k].get("parity", "")).startswith("MISMATCH") for k in
-                   ("fullpel_2160p", "eighthpel_2160p", "blocks_24_16_2160p", "decode_1080p")):
+                   ("fullpel_2160p", "eighthpel_2160p", "blocks_24_16_2160p", "weighted_2160p", "decode_1080p")):
                 out["parity_variants"] = "MISMATCH"
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share

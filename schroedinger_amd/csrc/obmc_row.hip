@@ -44,13 +44,24 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_h2_uv_3, 6, 3, 1, true, kRTH, false, 1, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_3_1, 7, 3, 1, false, kRTH, true, 1, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_uv_3, 7, 3, 1, true, kRTH, true, 1, 2)
 
+// r06, picture weights other than 1, 1 / 2 (fades: non-negative, adding up to 1 << bits): the 12-pixel-row and (U, V) forms
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_3_1, 6, 3, 1, false, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_uv_3, 6, 3, 1, true, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_p_3_1, 7, 3, 1, false, kRTH, true, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_p_uv_3, 7, 3, 1, true, kRTH, true, 1, 1, true)
+
 }                               // namespace
 
 // the kernel of a form: nd dwords per row and segment, np planes per job (3: (U, V) pairs from pair images), ns segments
 // per block row; nores: a prediction_only launch.  NULL: the form has no kernel
 RowKernel
-obmc_row_kernel_half (int nd, int np, int ns, bool nores)
+obmc_row_kernel_half (int nd, int np, int ns, bool nores, bool weighted)
 {
+  if (weighted) {
+    if (ns != 1 || nd != 3)
+      return nullptr;
+    return np == 1 ? (nores ? obmc_row_kernel_w_p_3_1 : obmc_row_kernel_w_3_1) : np == 3 ? (nores ? obmc_row_kernel_w_p_uv_3 : obmc_row_kernel_w_uv_3) : nullptr;
+  }
   if (ns == 2) {
     if (nd == 3 && np == 1)
       return nores ? obmc_row_kernel_p_h2_3_1 : obmc_row_kernel_h2_3_1;
@@ -81,14 +92,14 @@ obmc_row_kernel_half (int nd, int np, int ns, bool nores)
   return nullptr;
 }
 
-RowKernel obmc_row_kernel_plain (int nd, int np, int ns, bool nores);        // obmc_row_plain.hip
-RowKernel obmc_row_kernel_eighth (int nd, int np, int ns, bool nores);       // obmc_row_eighth.hip
+RowKernel obmc_row_kernel_plain (int nd, int np, int ns, bool nores, bool weighted);         // obmc_row_plain.hip
+RowKernel obmc_row_kernel_eighth (int nd, int np, int ns, bool nores, bool weighted);        // obmc_row_eighth.hip
 
 static RowKernel
-row_kernel (int rk, int nd, int np, int ns, bool nores)
+row_kernel (int rk, int nd, int np, int ns, bool nores, bool weighted)
 {
-  return rk == 0 ? obmc_row_kernel_plain (nd, np, ns, nores) : rk == 3 ? obmc_row_kernel_eighth (nd, np, ns, nores)
-      : obmc_row_kernel_half (nd, np, ns, nores);
+  return rk == 0 ? obmc_row_kernel_plain (nd, np, ns, nores, weighted) : rk == 3 ? obmc_row_kernel_eighth (nd, np, ns, nores, weighted)
+      : obmc_row_kernel_half (nd, np, ns, nores, weighted);
 }
 
 // the reference kind of a precision: 0 plain planes, 1 half-pel images read at half / quarter pel, 3 at eighth pel
@@ -98,10 +109,11 @@ obmc_row_kind (int prec)
   return prec == 0 ? 0 : prec == 3 ? 3 : 1;
 }
 
+// weighted: picture weights other than 1, 1 / 2
 bool
-obmc_row_has_kernel (int prec, int nd, int np, int ns)
+obmc_row_has_kernel (int prec, int nd, int np, int ns, bool weighted)
 {
-  return row_kernel (obmc_row_kind (prec), nd, np, ns, false) != nullptr;
+  return row_kernel (obmc_row_kind (prec), nd, np, ns, false, weighted) != nullptr;
 }
 
 // np: planes per job (1, 2); 3: (U, V) pairs from pair images
@@ -111,10 +123,10 @@ obmc_row_has_kernel (int prec, int nd, int np, int ns)
 // gathers at once, stores at once --, where the dispatcher's own refill staggers them.  HISTORY 9.)
 int
 launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec, int nd, int ns, int np,
-    const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs)
+    const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs, bool weighted)
 {
   // a prediction_only launch (the caller passes its overflow word exactly then: every job's residual is NULL)
-  const RowKernel k = row_kernel (obmc_row_kind (prec), nd, np, ns, overflow != nullptr);
+  const RowKernel k = row_kernel (obmc_row_kind (prec), nd, np, ns, overflow != nullptr, weighted);
   if (!k)
     return set_error (SCHRO_HIP_EINVAL, "obmc (row): precision %d, %d dwords per row x %d segments x %d planes unsupported", prec, nd, ns, np);
   // scratch runs: SCHRO_HIP_OBMC_LDS_PAD = bytes of unused dynamic LDS per workgroup (fewer workgroups per CU)
@@ -141,6 +153,10 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
     return 0;
   if (j.prec < 0 || j.prec > 3 || (j.xblen & 1) || j.xblen < 2 || j.yblen > 32)
     return 0;
+  // picture weights: 1, 1 / 2, or (r06) any that are not negative and add up to 1 << bits -- the fades, for which the
+  // reference's interior and edge arithmetic agree (obmc_row_body.h: blend_weighted); a gain or a negative weight: obmc.hip
+  if (j.w1 < 0 || j.w2 < 0 || j.wbits < 0 || j.wbits > 6 || j.w1 + j.w2 != (1 << j.wbits))
+    return 0;
   // rows of up to 16 bytes are one run; the 24 / 16 block set's 24-byte rows two segments of 12
   int seg_bytes = j.xblen << ps;
   if (seg_bytes > 16) {
@@ -166,7 +182,7 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
       return 0;
   }
   const int need = (seg_bytes + 3) / 4, nd = need <= 2 ? 2 : need;      // 2, 3 or 4
-  if (!obmc_row_has_kernel (j.prec, nd, uv ? 3 : 1, *ns))
+  if (!obmc_row_has_kernel (j.prec, nd, uv ? 3 : 1, *ns, j.w1 != 1 || j.wbits != 1))
     return 0;
   // the blocks (segments) that can meet a tile and their rows inside it fit the kernel's tables
   const int tw = uv ? RowGeo < 3, true >::kTW : RowGeo < 3, false >::kTW;

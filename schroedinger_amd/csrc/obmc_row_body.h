@@ -466,6 +466,21 @@ predict (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, __amdgpu_buffer_rsrc_t
   }
 }
 
+// r06 -- the two references of a block blended with the PICTURE WEIGHTS, for weights that are not negative and add up to
+// 1 << bits (a fade): per byte (w1 a + w2 b + ((1 << bits) >> 1)) >> bits.  For such weights the reference's two block
+// arithmetics agree -- interior blocks: mullw by w << (6 - bits), addw, + 32, shrsw 6 (block_acc_biref, schromotion8.c:131-163);
+// edge blocks: orc_combine2_nxm_u8 (schroorc.orc:1737-1757), whose clamp never acts -- and a block of one reference is
+// its prediction unchanged (oneref_noscale, :391-397, :44-73); with 1, 1 / 2 it is avgub.  Everything else (a gain, a
+// negative weight) stays with obmc.hip, which keeps the two arithmetics apart.  Two 16-bit sums share a dword (< 2^15).
+__device__ __forceinline__ uint32_t
+blend_weighted (uint32_t a, uint32_t b, uint32_t w1, uint32_t w2, uint32_t round2, uint32_t bits)
+{
+  const uint32_t lo = __umul24 (__builtin_amdgcn_perm (0u, a, 0x0c010c00u), w1) + __umul24 (__builtin_amdgcn_perm (0u, b, 0x0c010c00u), w2) + round2;
+  const uint32_t hi = __umul24 (__builtin_amdgcn_perm (0u, a, 0x0c030c02u), w1) + __umul24 (__builtin_amdgcn_perm (0u, b, 0x0c030c02u), w2) + round2;
+  // (a shift of the dword: what a sum's low bits leave in its neighbour's top bits is not picked up)
+  return __builtin_amdgcn_perm (hi >> bits, lo >> bits, 0x06040200u);
+}
+
 // one pass: every lane predicts one (block, row) item and adds it into the accumulator tile
 struct RowRefs {
   __amdgpu_buffer_rsrc_t rsrc[2];       // the plane's references as buffers: whole bands of 4 rows
@@ -484,7 +499,7 @@ dc_bytes (const B & hb, int pl)
     return (uint32_t) (blk_dc (hb, pl) & 0xff) * 0x01010101u;
 }
 
-template < int ND, bool UV, int CLS, bool EXACT, int RK, int NS >
+template < int ND, bool UV, int CLS, bool EXACT, int RK, int NS, bool WP >
 __device__ __forceinline__ void
 row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlkT < RowGeo < ND, UV, NS >::kPadBlk > *s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int it, int hi)
@@ -493,6 +508,10 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
   const int e = s_item[min (it, hi - 1)];
   const auto & hb = s_hot[e & 0x1ff];
   const int row = e >> 9;
+  // WP: picture weights other than 1, 1 / 2 (obmc_row_form admits the non-negative ones that add up to 1 << bits) -- kernels of
+  // their own, so that the default weights' kernels do not carry the weights in their scalar registers
+  constexpr bool weighted = WP;
+  const uint32_t wround = WP ? (uint32_t) ((1 << job.wbits) >> 1) * 0x00010001u : 0u;
   uint32_t p[ND];
   if constexpr (CLS == kRDc) {
     // (DC values outside 0..255 are not in this class: rim)
@@ -511,16 +530,22 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
 #pragma unroll
     for (int k = 0; k < ND; k++) {
       const uint32_t a = (p[k] & m0) | (p1[k] & ~m0), b = (p1[k] & m1) | (p[k] & ~m1);  // one reference: average it with itself
-      p[k] = mode ? lerp1 (a, b) : dc;
+      p[k] = mode ? (weighted ? blend_weighted (a, b, (uint32_t) job.w1, (uint32_t) job.w2, wround, (uint32_t) job.wbits) : lerp1 (a, b)) : dc;
     }
   } else if constexpr (CLS == kRBoth) {
     uint32_t p1[ND];
     predict < ND, RK, false, UV > (job, refs.rsrc[0], refs.rsrc_b[0], refs.stride[0], hb.r[0], 0u, row, p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight (both at once: measured slower)
     predict < ND, RK, false, UV > (job, refs.rsrc[1], refs.rsrc_b[1], refs.stride[1], hb.r[1], 0u, row, p1);
+    if (weighted) {             // (a uniform branch: the job's weights)
 #pragma unroll
-    for (int k = 0; k < ND; k++)
-      p[k] = lerp1 (p[k], p1[k]);       // avgub of the two predictions, schromotion8.c:560-566 with the default weights
+      for (int k = 0; k < ND; k++)
+        p[k] = blend_weighted (p[k], p1[k], (uint32_t) job.w1, (uint32_t) job.w2, wround, (uint32_t) job.wbits);
+    } else {
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        p[k] = lerp1 (p[k], p1[k]);     // avgub of the two predictions, schromotion8.c:560-566 with the default weights
+    }
   } else {
     constexpr int r = CLS == kRRef1 ? 1 : 0;
     predict < ND, RK, false, UV > (job, refs.rsrc[r], refs.rsrc_b[r], refs.stride[r], hb.r[r], 0u, row, p);
@@ -581,7 +606,7 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
 // waves take the tile's passes in turn whatever the class sizes (with nine classes most have one
 // or two passes: "wave w takes the w-th pass of every class" left wave 0 with nine passes and
 // wave 3 with none)
-template < int ND, bool UV, int CLS, int RK, int NS >
+template < int ND, bool UV, int CLS, int RK, int NS, bool WP >
 __device__ __forceinline__ void
 row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_item, const RowBlkT < RowGeo < ND, UV, NS >::kPadBlk > *s_hot,
     const uint32_t * s_wp, uint32_t * acc, int par, int lo, int hi, bool exact, int *turn)
@@ -594,10 +619,10 @@ row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s
   *turn = (*turn + npass) & (kWaves - 1);
   if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, UV, CLS, true, RK, NS > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
+      row_pass < ND, UV, CLS, true, RK, NS, WP > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   } else {
     for (int k = k0; k < npass; k += kWaves)
-      row_pass < ND, UV, CLS, false, RK, NS > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
+      row_pass < ND, UV, CLS, false, RK, NS, WP > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
   }
 }
 
@@ -843,7 +868,8 @@ row_finish_uv (const PlaneIO & iou, const PlaneIO & iov, const uint32_t * acc, i
 // NORES (r05): every job of the launch is a prediction_only job (no residual to add: the combine form's launches,
 // bench.py's headline).  The eight registers that carry the prefetched residual through the passes are not held at all.
 // RK, NS (r06): the reference kind and the segments of a block row, see the head of the file.
-template < int ND, int NP, bool UV = false, int TH = kRTH, bool NORES = false, int RK = 1, int NS = 1 >
+// WP (r06): the picture's weights are not 1, 1 / 2 (a fade: blend_weighted).
+template < int ND, int NP, bool UV = false, int TH = kRTH, bool NORES = false, int RK = 1, int NS = 1, bool WP = false >
 __device__ __forceinline__ void
 obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __restrict__ order, uint32_t * __restrict__ overflow,
     const uint32_t * __restrict__ wtabs)
@@ -1238,7 +1264,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
       if constexpr (UV && RK == 0)
         refs.rsrc_b[r] = __builtin_amdgcn_make_buffer_rsrc ((void *) iov.ref[r], 0, (int) bytes, 0x00020000);
     }
-#define SCHRO_ROW_CLASS(C) row_class < ND, UV, C, RK, NS > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
+#define SCHRO_ROW_CLASS(C) row_class < ND, UV, C, RK, NS, WP > (job, pl, refs, s_item, s_hot, s_wp, acc, par, \
     ibase[C], ibase[C + 1], exact, &turn)
 #pragma unroll
     for (int rep_ = 0; rep_ < kRepPasses; rep_++) {

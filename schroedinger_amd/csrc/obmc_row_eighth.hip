@@ -18,11 +18,22 @@ SCHRO_ROW_KERNEL (obmc_row_eighth_p_uv_3, 7, 3, 1, true, kRTH, true, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_h2_3_1, 6, 3, 1, false, kRTH, false, 3, 2)
 SCHRO_ROW_KERNEL (obmc_row_eighth_h2_uv_3, 6, 3, 1, true, kRTH, false, 3, 2)
 
+// picture weights other than 1, 1 / 2 (fades)
+SCHRO_ROW_KERNEL (obmc_row_eighth_w_3_1, 6, 3, 1, false, kRTH, false, 3, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_eighth_w_uv_3, 6, 3, 1, true, kRTH, false, 3, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_eighth_w_p_3_1, 6, 3, 1, false, kRTH, true, 3, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_eighth_w_p_uv_3, 6, 3, 1, true, kRTH, true, 3, 1, true)
+
 }                               // namespace
 
 RowKernel
-obmc_row_kernel_eighth (int nd, int np, int ns, bool nores)
+obmc_row_kernel_eighth (int nd, int np, int ns, bool nores, bool weighted)
 {
+  if (weighted) {
+    if (ns != 1 || nd != 3)
+      return nullptr;
+    return np == 1 ? (nores ? obmc_row_eighth_w_p_3_1 : obmc_row_eighth_w_3_1) : np == 3 ? (nores ? obmc_row_eighth_w_p_uv_3 : obmc_row_eighth_w_uv_3) : nullptr;
+  }
   if (ns == 2)
     return nd == 3 && np == 1 ? obmc_row_eighth_h2_3_1 : nd == 3 && np == 3 ? obmc_row_eighth_h2_uv_3 : nullptr;
   if (nores && nd == 3 && np == 1)

@@ -35,11 +35,22 @@ SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_4, 4, 4, 1, true, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_h2_3_1, 6, 3, 1, false, kRTH, false, 0, 2)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_3_1, 7, 3, 1, false, kRTH, true, 0, 2)
 
+// picture weights other than 1, 1 / 2 (fades)
+SCHRO_ROW_KERNEL (obmc_row_plain_w_3_1, 6, 3, 1, false, kRTH, false, 0, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_plain_w_uv_3, 6, 3, 1, true, kRTH, false, 0, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_plain_w_p_3_1, 7, 3, 1, false, kRTH, true, 0, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_plain_w_p_uv_3, 7, 3, 1, true, kRTH, true, 0, 1, true)
+
 }                               // namespace
 
 RowKernel
-obmc_row_kernel_plain (int nd, int np, int ns, bool nores)
+obmc_row_kernel_plain (int nd, int np, int ns, bool nores, bool weighted)
 {
+  if (weighted) {
+    if (ns != 1 || nd != 3)
+      return nullptr;
+    return np == 1 ? (nores ? obmc_row_plain_w_p_3_1 : obmc_row_plain_w_3_1) : np == 3 ? (nores ? obmc_row_plain_w_p_uv_3 : obmc_row_plain_w_uv_3) : nullptr;
+  }
   if (ns == 2)
     return nd == 3 && np == 1 ? (nores ? obmc_row_plain_p_h2_3_1 : obmc_row_plain_h2_3_1) : nullptr;
   if (nores)

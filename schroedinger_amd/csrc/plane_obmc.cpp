@@ -397,7 +397,8 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
             "schro_hip_upsampled_bytes / _pair_bytes)", p, r + 1);
     j.out_s16 = pl.prediction_only == 2;
     const int variant = variant_of (pl);
-    const int nd_row = (variant == 1 && use_row && !j.out_s16) ? obmc_row_form (j, false, &row_ns[p]) : 0;
+    // (obmc_row_form looks at the weights itself: 1, 1 / 2 and, r06, every non-negative pair that adds up to 1 << bits)
+    const int nd_row = (use_row && !j.out_s16) ? obmc_row_form (j, false, &row_ns[p]) : 0;
     // (a launch per row length: the kernels differ in registers and so in workgroups per CU)
     key[p] = pl.mv_precision | (variant << 4) | (nd_row << 8) | (nd_row ? 1 << 16 : 0) | (pl.prediction_only == 1 ? 1 << 19 : 0)
         | (nd_row ? row_ns[p] << 20 : 0) | (j.out_s16 ? 1 << 22 : 0);
@@ -418,7 +419,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         && a.mvs == b.mvs && a.w == b.w && a.h == b.h && a.nbx == b.nbx && a.nby == b.nby && a.xblen == b.xblen
         && a.yblen == b.yblen && a.xbsep == b.xbsep && a.ybsep == b.ybsep && a.mv_shift_x == b.mv_shift_x
         && a.mv_shift_y == b.mv_shift_y && a.res_bpp == b.res_bpp && a.ref_stride[0] == b.ref_stride[0]
-        && a.ref_stride[1] == b.ref_stride[1] && a.prec == b.prec;
+        && a.ref_stride[1] == b.ref_stride[1] && a.prec == b.prec && a.w1 == b.w1 && a.w2 == b.w2 && a.wbits == b.wbits;
   };
   for (int p = 0; p + 1 < nplanes; p++) {
     const ObmcJob & a = all[p], &b = all[p + 1];
@@ -429,7 +430,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     // carries the V planes in ref_b and the kernel interleaves the rows
     const bool uv_plain = a.prec == 0 && b.prec == 0 && !a.ref_ps && !b.ref_ps;
     if (((a.ref_ps && b.ref_ps && a.ref[0] == b.ref[0] && a.ref[1] == b.ref[1]) || uv_plain)
-        && use_row && variant_of (planes[p]) == 1 && variant_of (planes[p + 1]) == 1 && same_blocks (a, b)
+        && use_row && same_blocks (a, b)
         && planes[p].prediction_only == planes[p + 1].prediction_only && !a.out_s16 && !b.out_s16) {
       int ns;
       ObmcJob au = a;
@@ -447,7 +448,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         continue;
     }
     if (pairs_pay && row_nd[p] && row_nd[p + 1] && key[p] == key[p + 1] && same_blocks (a, b)
-        && obmc_row_has_kernel (a.prec, row_nd[p], 2, row_ns[p])) {
+        && obmc_row_has_kernel (a.prec, row_nd[p], 2, row_ns[p], a.w1 != 1 || a.wbits != 1)) {
       key[p] |= 1 << 17;
       key[p + 1] |= 1 << 17;
       p++;
@@ -468,7 +469,9 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
     const bool paired = (key[first] >> 17) & 1, uv = (key[first] >> 18) & 1, pred_only = (key[first] >> 19) & 1;
     const int ns = row ? std::max (1, (key[first] >> 20) & 3) : 1;
     // (two planes per job: every row length of the group needs the kernel)
-    SCHRO_HIP_REQUIRE (!row || obmc_row_has_kernel (prec, nd, uv ? 3 : paired ? 2 : 1, ns),
+    // (a launch group's planes have one kind of weights: the key carries the variant)
+    const bool weighted = row && (all[first].w1 != 1 || all[first].wbits != 1);
+    SCHRO_HIP_REQUIRE (!row || obmc_row_has_kernel (prec, nd, uv ? 3 : paired ? 2 : 1, ns, weighted),
         "obmc_batch: no row kernel for precision %d, %d dwords x %d segments per row, %s", prec, nd, ns, uv ? "(U, V) pairs" : paired ? "two planes per job" : "one plane per job");
     uint32_t *overflow = nullptr;
     if (pred_only) {
@@ -606,7 +609,7 @@ schro_hip_obmc_batch (SchroHipContext * ctx, const SchroHipObmcPlane * planes, i
         (void) hipMemsetAsync (g_stamps, 0, 16384 * 16 * 8, ctx->stream);
       {
         ProfileScope ps (ctx, SCHRO_HIP_KERNEL_OBMC);
-        r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, nd, ns, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs)
+        r = row ? launch_obmc_row (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, nd, ns, uv ? 3 : paired ? 2 : 1, d_order, overflow, (const uint32_t *) d_wtabs, weighted)
             : launch_obmc (ctx->stream, (const ObmcJob *) d_jobs, (int) jobs.size (), tile_base, prec, variant, d_order, overflow);
       }
     }

@@ -497,7 +497,7 @@ int launch_obmc (hipStream_t stream, const ObmcJob * d_jobs, int njobs,
 // 0 = not their case
 int obmc_row_form (const ObmcJob & job, bool uv, int *ns);
 // is there a kernel of `np` planes per job (1, 2; 3: (U, V) pairs from pair images) for this precision and form?
-bool obmc_row_has_kernel (int prec, int nd, int np, int ns);
+bool obmc_row_has_kernel (int prec, int nd, int np, int ns, bool weighted);
 // obmc_strip.hip (r05): the register-accumulator form for the 12 / 8 block set
 bool obmc_strip_ok (const ObmcJob & j);
 void obmc_strip_tiles (const ObmcJob & j, int seg_rows, int *strips, int *segs);
@@ -506,7 +506,7 @@ int launch_obmc_strip (hipStream_t stream, const ObmcJob * d_jobs, int njobs, in
 int obmc_row_tile_width (bool uv);
 int obmc_row_tile_height ();
 int launch_obmc_row (hipStream_t stream, const ObmcJob * d_jobs, int njobs, int total_tiles, int prec, int nd, int ns,
-    int planes_per_job, const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs);
+    int planes_per_job, const uint32_t * d_order, uint32_t * overflow, const uint32_t * d_wtabs, bool weighted);
 // the weight table of a job's block geometry as the row kernels copy it into LDS (ObmcJob::ipw: its index in d_wtabs)
 // words 1 .. 3 of tile (tx, ty)'s record in a row launch's order table (word 0: job << 16 | tile)
 void obmc_row_tile_record (const ObmcJob & job, bool uv, int ns, int tx, int ty, uint32_t * rec);

@@ -13,5 +13,5 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 
 if __name__ == "__main__":
-    kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])}
+    kw = {k: (tuple(int(x) for x in v.split(",")) if "," in v else int(v)) for k, v in (a.split("=") for a in sys.argv[1:])}
     print(json.dumps(bench.decode_variant(0, **kw)))

@@ -87,9 +87,11 @@ def test_default_weights(ctx, blk, prec, chroma):
         run_case(ctx, 96, 64, blk[0], blk[1], prec, (1, 1, 1), chroma, mv_range, seed)
 
 
-@pytest.mark.parametrize("weights", [(3, 5, 3), (1, 2, 2), (2, 3, 1), (3, -1, 1), (5, 3, 2)])
+@pytest.mark.parametrize("weights", [(3, 5, 3), (1, 2, 2), (2, 3, 1), (3, -1, 1), (5, 3, 2), (1, 3, 2), (7, 1, 3), (0, 1, 0), (21, 43, 6)])
 @pytest.mark.parametrize("prec", [0, 2, 3])
 def test_weighted_prediction(ctx, weights, prec):
+    # (r06: non-negative weights that add up to 1 << bits -- (3, 5, 3), (1, 3, 2), (7, 1, 3), (0, 1, 0), (21, 43, 6): the fades --
+    # run the row kernels' weighted blend; the others obmc.hip's general kernel)
     # includes gain > 1 and a negative weight: the edge (u8) and interior (s16) block
     # arithmetic of the reference differ there and both must be reproduced
     for blk in ((12, 8), (16, 12)):
@@ -382,3 +384,14 @@ def test_add_batch(ctx):
             assert np.array_equal(gd.download(), O.frame_add(d, s)), (h, w, sdt)
             gd.free()
             gs.free()
+
+
+def test_fades_on_every_row_form(ctx):
+    """r06: normalised non-negative picture weights (a fade) through every form of the row kernels -- pair images and
+    plain planes, every precision, the 8 / 4, 16 / 12 and 24 / 16 block sets, edge-class blocks (vectors far outside), the
+    residual form and (tests/test_gpu_combine.py covers it too) prediction-only."""
+    for weights in ((3, 5, 3), (1, 3, 2), (63, 1, 6)):
+        for blk in ((8, 4), (12, 8), (16, 12), (24, 16)):
+            for prec in (0, 1, 2, 3):
+                for chroma in ((1, 1), (0, 0)):
+                    run_case(ctx, 136, 72, blk[0], blk[1], prec, weights, chroma, 40 << prec, 17, pair=True)
