@@ -1422,13 +1422,16 @@ def main():
             out["fullpel_2160p"] = decode_variant(dev, prec=0)
             out["eighthpel_2160p"] = decode_variant(dev, prec=3)
             out["blocks_24_16_2160p"] = decode_variant(dev, xblen=24, xbsep=16)
+            # (what the reference's own encoder makes of a 2160p picture by default: 32 x 32 blocks every 16 pixels --
+            # schroengine.c:411-453: separation by picture size, full overlap -- and full-pel vectors, schroencoder.c:4488)
+            out["encoder_default_2160p"] = decode_variant(dev, xblen=32, xbsep=16, prec=0)
             # (weighted prediction -- a fade: 3, 5 / 2^3; r06: the row kernels' weighted blend.  obmc.hip's general kernel, which
             # such pictures ran until then and which pictures with a gain or a negative weight still run: 2.22 ms of OBMC per step)
             out["weighted_2160p"] = decode_variant(dev, weights=(3, 5, 3))
             out["decode_1080p"] = decode_variant(dev, w=1920, h=1080)
             out["decode_1080p"]["pictures_32_per_step"] = decode_variant(dev, frames=32, w=1920, h=1080, check=False)
             if any(str(out[k].get("parity", "")).startswith("MISMATCH") for k in
-                   ("fullpel_2160p", "eighthpel_2160p", "blocks_24_16_2160p", "weighted_2160p", "decode_1080p")):
+                   ("fullpel_2160p", "eighthpel_2160p", "blocks_24_16_2160p", "encoder_default_2160p", "weighted_2160p", "decode_1080p")):
                 out["parity_variants"] = "MISMATCH"
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)      # a one-GPU box's CPU share

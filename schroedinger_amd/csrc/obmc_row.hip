@@ -22,27 +22,32 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_2_1, 6, 2, 1)
 SCHRO_ROW_KERNEL (obmc_row_kernel_2_2, 6, 2, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_3_1, 7, 3, 1)
 SCHRO_ROW_KERNEL (obmc_row_kernel_3_2, 5, 3, 2)
-SCHRO_ROW_KERNEL (obmc_row_kernel_4_1, 4, 4, 1)
-SCHRO_ROW_KERNEL (obmc_row_kernel_4_2, 4, 4, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_4_1, 6, 4, 1)
+SCHRO_ROW_KERNEL (obmc_row_kernel_4_2, 5, 4, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_2, 5, 2, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_uv_3, 7, 3, 1, true)
-SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 4, 4, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 6, 4, 1, true)
 // prediction_only launches (NORES, r05).  Without the residual's eight registers the 12-pixel-row kernel takes 60
 // VGPRs and -- compiled for eight waves -- 78 SGPRs: EIGHT workgroups per CU (LDS 8 x 19 776 B = 158 KB; a CU admits
 // floor (800 / (ceil (sgpr / 16) 16 + 16)) 256-thread workgroups: 7 at 81 .. 96 SGPRs).  8 x 2160p, same box: OBMC
 // 0.1706 -> 0.1674 ms per step.  The (U, V) kernel of 6-pixel rows too (r05, above).
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_2_1, 6, 2, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_3_1, 8, 3, 1, false, kRTH, true)
-SCHRO_ROW_KERNEL (obmc_row_kernel_p_4_1, 4, 4, 1, false, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_4_1, 7, 4, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_2, 5, 2, 1, true, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, 8, 3, 1, true, kRTH, true)
-SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_4, 4, 4, 1, true, kRTH, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_4, 7, 4, 1, true, kRTH, true)
 // r06, two segments per block row: the 24 / 16 block set's luma planes (24 = 2 x 12 pixels) and its 12-sample chroma
 // rows from pair images (2 x 6 (U, V) samples)
 SCHRO_ROW_KERNEL (obmc_row_kernel_h2_3_1, 6, 3, 1, false, kRTH, false, 1, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_h2_uv_3, 6, 3, 1, true, kRTH, false, 1, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_3_1, 7, 3, 1, false, kRTH, true, 1, 2)
-SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_uv_3, 7, 3, 1, true, kRTH, true, 1, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_uv_3, 6, 3, 1, true, kRTH, true, 1, 2)
+// ... and of 16: the 32 / 16 block set (luma 32 = 2 x 16 pixels, its 16-sample chroma rows 2 x 8 (U, V) samples)
+SCHRO_ROW_KERNEL (obmc_row_kernel_h2_4_1, 5, 4, 1, false, kRTH, false, 1, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_h2_uv_4, 5, 4, 1, true, kRTH, false, 1, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_4_1, 6, 4, 1, false, kRTH, true, 1, 2)
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_uv_4, 6, 4, 1, true, kRTH, true, 1, 2)
 
 // r06, picture weights other than 1, 1 / 2 (fades: non-negative, adding up to 1 << bits): the 12-pixel-row and (U, V) forms
 SCHRO_ROW_KERNEL (obmc_row_kernel_w_3_1, 6, 3, 1, false, kRTH, false, 1, 1, true)
@@ -67,6 +72,10 @@ obmc_row_kernel_half (int nd, int np, int ns, bool nores, bool weighted)
       return nores ? obmc_row_kernel_p_h2_3_1 : obmc_row_kernel_h2_3_1;
     if (nd == 3 && np == 3)
       return nores ? obmc_row_kernel_p_h2_uv_3 : obmc_row_kernel_h2_uv_3;
+    if (nd == 4 && np == 1)
+      return nores ? obmc_row_kernel_p_h2_4_1 : obmc_row_kernel_h2_4_1;
+    if (nd == 4 && np == 3)
+      return nores ? obmc_row_kernel_p_h2_uv_4 : obmc_row_kernel_h2_uv_4;
     return nullptr;
   }
   if (nores)
@@ -157,13 +166,14 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
   // reference's interior and edge arithmetic agree (obmc_row_body.h: blend_weighted); a gain or a negative weight: obmc.hip
   if (j.w1 < 0 || j.w2 < 0 || j.wbits < 0 || j.wbits > 6 || j.w1 + j.w2 != (1 << j.wbits))
     return 0;
-  // rows of up to 16 bytes are one run; the 24 / 16 block set's 24-byte rows two segments of 12
+  // rows of up to 16 bytes are one run; 24-byte rows (the 24 / 16 and 24 / 12 block sets) two segments of 12, 32-byte rows
+  // (32 / 16: what the reference's encoder makes of 1080p and larger pictures by default, schroengine.c:411-453) two of 16
   int seg_bytes = j.xblen << ps;
   if (seg_bytes > 16) {
-    if (seg_bytes != 24)
+    if (seg_bytes != 24 && seg_bytes != 32)
       return 0;
     *ns = 2;
-    seg_bytes = 12;
+    seg_bytes /= 2;
   }
   // rim blocks keep their clamped fetch origins (get_block: at most (size + 32) << prec) in 16 bits
   if (((std::max (j.w, j.h) + 32) << j.prec) > 32767)
@@ -195,12 +205,18 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
   if (*ns == 2) {
     blk_cap = uv ? RowGeo < 3, true, 2 >::kBlk : RowGeo < 3, false, 2 >::kBlk;
     item_cap = uv ? RowGeo < 3, true, 2 >::kItem : RowGeo < 3, false, 2 >::kItem;
+  } else if (nd == 4) {
+    blk_cap = uv ? RowGeo < 4, true >::kBlk : RowGeo < 4, false >::kBlk;
+    item_cap = uv ? RowGeo < 4, true >::kItem : RowGeo < 4, false >::kItem;
   } else {
     blk_cap = uv ? (nd <= 2 ? RowGeo < 2, true >::kBlk : RowGeo < 3, true >::kBlk) : (nd <= 2 ? RowGeo < 2, false >::kBlk : RowGeo < 3, false >::kBlk);
     item_cap = uv ? (nd <= 2 ? RowGeo < 2, true >::kItem : RowGeo < 3, true >::kItem)
         : (nd <= 2 ? RowGeo < 2, false >::kItem : RowGeo < 3, false >::kItem);
   }
-  if (nbi > 255 || nbi * nbj > blk_cap || nbi * (kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff) > item_cap)
+  // the rows of one column of blocks (segments) inside a tile: the tile's rows, each under at most ceil (yblen / ybsep)
+  // blocks -- or, for small overlaps the tighter count, the rows plus the overlaps of the block rows that meet it
+  const int rows_col = std::min (kRTH * ((j.yblen + j.ybsep - 1) / j.ybsep), kRTH + (kRTH / j.ybsep + 2) * 2 * j.yoff);
+  if (nbi > 255 || nbi * nbj > blk_cap || nbi * rows_col > item_cap)
     return 0;
   return nd;
 }
@@ -219,8 +235,11 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
 int
 obmc_row_weight_words (int nd, int ns)
 {
-  return ns == 2 ? RowGeo < 3, false, 2 >::kWTab : 64 * nd + 32 + 128 + 16 + 32;
+  const int wrow = 2 * nd * ns;
+  return 32 * wrow + 4 * (ns == 1 ? 8 : wrow) + 128 + (ns == 1 ? 16 : 32) + 32;       // (= RowGeo < nd, *, ns >::kWTab)
 }
+static_assert (RowGeo < 3, false, 2 >::kWTab == 32 * 12 + 48 + 128 + 32 + 32 && RowGeo < 4, true, 2 >::kWTab == 32 * 16 + 64 + 128 + 32 + 32
+    && RowGeo < 3, true >::kWTab == 64 * 3 + 32 + 128 + 16 + 32, "obmc_row_weight_words");
 
 void
 obmc_row_weight_table (const ObmcJob & j, int nd, int ns, bool uv, uint32_t * out)

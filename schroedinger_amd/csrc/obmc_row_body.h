@@ -83,10 +83,12 @@ template < int ND, bool UV, int NS = 1 > struct RowGeo {
   // every 4 pixels meets 18 x 10 of them)
   // (for a tile of kRTH rows: the caps grow with the tile's height)
   // (UV, 6 x 6 blocks every 4 pixels: 18 x 10 blocks meet a 64 x 32 tile, 18 x 52 of their rows)
-  // (NS 2: the 24 / 16 set's 10 x 4 blocks = 80 half blocks meet a luma tile, 20 x 64 of their rows at most;
-  // its 12 / 8 chroma as (U, V): 10 x 6 blocks = 120 halves, 20 x 56 rows)
-  static constexpr int kBlk = ND <= 2 ? 344 : (UV ? (ND == 3 ? 180 : 192) : 128) * kRTH / 32,
-      kItem = ND <= 2 ? 1792 : (NS > 1 ? (UV ? 1152 : 1280) : UV ? (ND == 3 ? 960 : 1152) : 1024) * kRTH / 32;
+  // (NS 2: the 24 / 16 set's 10 x 4 blocks = 80 half blocks meet a luma tile, 20 x 64 of their rows at most; the sets of
+  // full overlap the reference's encoder makes by default (schroengine.c:411-453: block length = 2 x separation) meet a
+  // tile with more: 24 / 12 -- 13 x 5 blocks = 130 halves, its 12 / 6 chroma as (U, V) 13 x 8 = 208 halves, 26 columns x 2
+  // blocks over each of 32 rows = 1664 items; 32 / 16 -- 80 halves of 16 pixels, 1280 items.  ND 4, 16 / 8: 18 columns x 64)
+  static constexpr int kBlk = ND <= 2 ? 344 : (NS > 1 ? (UV ? 208 : 144) : UV ? (ND == 3 ? 180 : 192) : 128) * kRTH / 32,
+      kItem = ND <= 2 ? 1792 : (NS > 1 ? 1664 : UV ? (ND == 3 ? 960 : 1152) : (ND == 3 ? 1024 : 1152)) * kRTH / 32;
   // (row, segment, pixel pair | UV: pixel) weight words: 2 * ND per row and segment (zero beyond the block), 32 rows
   static constexpr int kWRow = 2 * ND * NS;
   static constexpr int kWCap = 32 * kWRow;
@@ -876,7 +878,7 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
 {
   typedef RowGeo < ND, UV, NS > G;
   static_assert (!UV || NP == 1, "a UV job is one virtual plane of (U, V) samples");
-  static_assert (NS == 1 || (NS == 2 && ND == 3), "segments: halves of 12 bytes");
+  static_assert (NS == 1 || (NS == 2 && (ND == 3 || ND == 4)), "segments: halves of 12 or 16 bytes");
   constexpr int kRTW = G::kTW, ps = UV ? 1 : 0;
   __shared__ __attribute__ ((aligned (16))) uint32_t acc[TH * G::kAccW + 3];
   // (r05: s_wp | s_wx | s_wy are ONE block, copied from the job's weight table, see below)

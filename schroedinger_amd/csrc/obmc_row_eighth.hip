@@ -9,14 +9,16 @@ namespace {
 
 SCHRO_ROW_KERNEL (obmc_row_eighth_2_1, 6, 2, 1, false, kRTH, false, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_3_1, 6, 3, 1, false, kRTH, false, 3)
-SCHRO_ROW_KERNEL (obmc_row_eighth_4_1, 4, 4, 1, false, kRTH, false, 3)
+SCHRO_ROW_KERNEL (obmc_row_eighth_4_1, 5, 4, 1, false, kRTH, false, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_uv_2, 5, 2, 1, true, kRTH, false, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_uv_3, 6, 3, 1, true, kRTH, false, 3)
-SCHRO_ROW_KERNEL (obmc_row_eighth_uv_4, 4, 4, 1, true, kRTH, false, 3)
+SCHRO_ROW_KERNEL (obmc_row_eighth_uv_4, 5, 4, 1, true, kRTH, false, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_p_3_1, 7, 3, 1, false, kRTH, true, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_p_uv_3, 7, 3, 1, true, kRTH, true, 3)
 SCHRO_ROW_KERNEL (obmc_row_eighth_h2_3_1, 6, 3, 1, false, kRTH, false, 3, 2)
 SCHRO_ROW_KERNEL (obmc_row_eighth_h2_uv_3, 6, 3, 1, true, kRTH, false, 3, 2)
+SCHRO_ROW_KERNEL (obmc_row_eighth_h2_4_1, 5, 4, 1, false, kRTH, false, 3, 2)
+SCHRO_ROW_KERNEL (obmc_row_eighth_h2_uv_4, 5, 4, 1, true, kRTH, false, 3, 2)
 
 // picture weights other than 1, 1 / 2 (fades)
 SCHRO_ROW_KERNEL (obmc_row_eighth_w_3_1, 6, 3, 1, false, kRTH, false, 3, 1, true)
@@ -35,7 +37,8 @@ obmc_row_kernel_eighth (int nd, int np, int ns, bool nores, bool weighted)
     return np == 1 ? (nores ? obmc_row_eighth_w_p_3_1 : obmc_row_eighth_w_3_1) : np == 3 ? (nores ? obmc_row_eighth_w_p_uv_3 : obmc_row_eighth_w_uv_3) : nullptr;
   }
   if (ns == 2)
-    return nd == 3 && np == 1 ? obmc_row_eighth_h2_3_1 : nd == 3 && np == 3 ? obmc_row_eighth_h2_uv_3 : nullptr;
+    return nd == 3 && np == 1 ? obmc_row_eighth_h2_3_1 : nd == 3 && np == 3 ? obmc_row_eighth_h2_uv_3
+        : nd == 4 && np == 1 ? obmc_row_eighth_h2_4_1 : nd == 4 && np == 3 ? obmc_row_eighth_h2_uv_4 : nullptr;
   if (nores && nd == 3 && np == 1)
     return obmc_row_eighth_p_3_1;
   if (nores && nd == 3 && np == 3)

@@ -16,24 +16,32 @@ SCHRO_ROW_KERNEL (obmc_row_plain_2_1, 6, 2, 1, false, kRTH, false, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_2_2, 6, 2, 2, false, kRTH, false, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_3_1, 7, 3, 1, false, kRTH, false, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_3_2, 5, 3, 2, false, kRTH, false, 0)
-SCHRO_ROW_KERNEL (obmc_row_plain_4_1, 4, 4, 1, false, kRTH, false, 0)
-SCHRO_ROW_KERNEL (obmc_row_plain_4_2, 4, 4, 2, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_4_1, 7, 4, 1, false, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_4_2, 5, 4, 2, false, kRTH, false, 0)
 // prediction_only launches (the combine form): the U and V planes of a picture are two plain planes, one job
 SCHRO_ROW_KERNEL (obmc_row_plain_p_2_1, 6, 2, 1, false, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_2_2, 6, 2, 2, false, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_3_1, 8, 3, 1, false, kRTH, true, 0)
-SCHRO_ROW_KERNEL (obmc_row_plain_p_4_1, 4, 4, 1, false, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_4_1, 8, 4, 1, false, kRTH, true, 0)
 // r06: the U and V planes of a picture as ONE (U, V) job -- the two plain planes' rows interleaved in registers, then the
 // pair images' accumulator and finish (64-pixel tiles, one decode, one pass per item for both planes)
 SCHRO_ROW_KERNEL (obmc_row_plain_uv_2, 5, 2, 1, true, kRTH, false, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_uv_3, 7, 3, 1, true, kRTH, false, 0)
-SCHRO_ROW_KERNEL (obmc_row_plain_uv_4, 4, 4, 1, true, kRTH, false, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_uv_4, 7, 4, 1, true, kRTH, false, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_2, 5, 2, 1, true, kRTH, true, 0)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_3, 8, 3, 1, true, kRTH, true, 0)
-SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_4, 4, 4, 1, true, kRTH, true, 0)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_uv_4, 7, 4, 1, true, kRTH, true, 0)
 // the 24 / 16 block set's luma rows: two segments of 12
 SCHRO_ROW_KERNEL (obmc_row_plain_h2_3_1, 6, 3, 1, false, kRTH, false, 0, 2)
 SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_3_1, 7, 3, 1, false, kRTH, true, 0, 2)
+// ... and, as (U, V) jobs, the 12-sample chroma rows of the 24 / 12 set; the 32 / 16 set -- the reference encoder's default for
+// 1080p and larger pictures, at its default mv_precision 0 -- as two segments of 16 pixels / of 8 (U, V) samples
+SCHRO_ROW_KERNEL (obmc_row_plain_h2_uv_3, 6, 3, 1, true, kRTH, false, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_uv_3, 6, 3, 1, true, kRTH, true, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_h2_4_1, 5, 4, 1, false, kRTH, false, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_h2_uv_4, 5, 4, 1, true, kRTH, false, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_4_1, 6, 4, 1, false, kRTH, true, 0, 2)
+SCHRO_ROW_KERNEL (obmc_row_plain_p_h2_uv_4, 6, 4, 1, true, kRTH, true, 0, 2)
 
 // picture weights other than 1, 1 / 2 (fades)
 SCHRO_ROW_KERNEL (obmc_row_plain_w_3_1, 6, 3, 1, false, kRTH, false, 0, 1, true)
@@ -51,8 +59,13 @@ obmc_row_kernel_plain (int nd, int np, int ns, bool nores, bool weighted)
       return nullptr;
     return np == 1 ? (nores ? obmc_row_plain_w_p_3_1 : obmc_row_plain_w_3_1) : np == 3 ? (nores ? obmc_row_plain_w_p_uv_3 : obmc_row_plain_w_uv_3) : nullptr;
   }
-  if (ns == 2)
-    return nd == 3 && np == 1 ? (nores ? obmc_row_plain_p_h2_3_1 : obmc_row_plain_h2_3_1) : nullptr;
+  if (ns == 2) {
+    if (nd == 3)
+      return np == 1 ? (nores ? obmc_row_plain_p_h2_3_1 : obmc_row_plain_h2_3_1) : np == 3 ? (nores ? obmc_row_plain_p_h2_uv_3 : obmc_row_plain_h2_uv_3) : nullptr;
+    if (nd == 4)
+      return np == 1 ? (nores ? obmc_row_plain_p_h2_4_1 : obmc_row_plain_h2_4_1) : np == 3 ? (nores ? obmc_row_plain_p_h2_uv_4 : obmc_row_plain_h2_uv_4) : nullptr;
+    return nullptr;
+  }
   if (nores)
     switch (nd * 10 + np) {
       case 23: return obmc_row_plain_p_uv_2;

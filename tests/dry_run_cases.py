@@ -76,7 +76,7 @@ def test_obmc_geometries(ctx):
         obmc_case(ctx, w, h, blen, sep, prec, weights, chroma, pair=bool(rng.integers(0, 2)), pred=int(rng.integers(0, 3)))
     # the bench's sizes: every standard block set at 1080p / 2160p, all precisions, both chroma forms, a whole batch
     for (w, h) in ((1920, 1080), (3840, 2160)):
-        for (blen, sep) in ((8, 4), (12, 8), (16, 12), (24, 16)):
+        for (blen, sep) in ((8, 4), (12, 8), (16, 12), (24, 16), (16, 8), (24, 12), (32, 16)):
             for prec in range(4):
                 obmc_case(ctx, w, h, blen, sep, prec, (1, 1, 1), (1, 1), pair=True, pred=1)
     obmc_case(ctx, 7680, 4320, 12, 8, 2, (1, 1, 1), (1, 0), pair=True, pred=0)

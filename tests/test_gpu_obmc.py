@@ -13,7 +13,8 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-BLOCK_SETS = [(8, 4), (12, 8), (16, 12), (24, 16)]      # schroparams.c:192-198
+BLOCK_SETS = [(8, 4), (12, 8), (16, 12), (24, 16),      # schroparams.c:192-198
+              (16, 8), (24, 12), (32, 16)]              # full overlap: what the reference's ENCODER makes by default (schroengine.c:411-453)
 
 
 def comp_size(w, h, k, chroma):
@@ -395,3 +396,13 @@ def test_fades_on_every_row_form(ctx):
             for prec in (0, 1, 2, 3):
                 for chroma in ((1, 1), (0, 0)):
                     run_case(ctx, 136, 72, blk[0], blk[1], prec, weights, chroma, 40 << prec, 17, pair=True)
+
+
+def test_the_reference_encoders_default_block_sets_at_size(ctx):
+    """r06: the reference's encoder picks the block separation by picture size and, by default, FULL overlap
+    (schroengine.c:411-453): 16 / 8 below 960 x 540, 24 / 12 below 1080p, 32 / 16 from 1080p on -- with mv_precision 0.  Pictures
+    large enough for whole interior tiles, every precision, 4:2:0 (pair images where there are half-pel images) and 4:4:4."""
+    for (w, h, blk) in ((416, 240, (16, 8)), (704, 200, (24, 12)), (640, 168, (32, 16))):
+        for prec in (0, 2, 3):
+            for chroma in ((1, 1), (0, 0)):
+                run_case(ctx, w, h, blk[0], blk[1], prec, (1, 1, 1), chroma, 20 << prec, 23, pair=True)
