@@ -20,3 +20,5 @@ run eighth prec=3 check=0 queues=1
 run b2416 xblen=24 xbsep=16 check=0 queues=1
 run p1080 w=1920 h=1080 check=0 queues=1
 run headline check=0 queues=1
+run encdef xblen=32 xbsep=16 prec=0 check=0 queues=1
+run fade weights=3,5,3 check=0 queues=1

@@ -406,3 +406,18 @@ def test_the_reference_encoders_default_block_sets_at_size(ctx):
         for prec in (0, 2, 3):
             for chroma in ((1, 1), (0, 0)):
                 run_case(ctx, w, h, blk[0], blk[1], prec, (1, 1, 1), chroma, 20 << prec, 23, pair=True)
+
+
+def test_dc_values_outside_8_bits_in_two_segment_blocks(ctx):
+    """r06: a block of the 24 / 16, 24 / 12 or 32 / 16 set is two records in the row kernels (its segments); one whose DC value
+    does not fit 8 bits takes the rim path as a WHOLE block from its first segment's record, with the exact 16-bit
+    accumulation for the tile -- pair images and plain planes, blocks at the picture's rim and inside."""
+    def widen(mv, P):
+        dc_blocks = np.flatnonzero((mv["flags"] & 3) == 0)
+        vals = np.array([300, -400, 1000, -3000, 32767, -32768, 256, -129], np.int16)
+        for n, b in enumerate(dc_blocks[::3]):
+            mv["v"][b, :3] = vals[(n + np.arange(3)) % len(vals)]
+    for blk in ((24, 16), (24, 12), (32, 16)):
+        for prec in (0, 2):
+            run_case(ctx, 416, 160, blk[0], blk[1], prec, (1, 1, 1), (1, 1), 12 << prec, 29,
+                     modes=(0.3, 0.3, 0.1, 0.3), edit_mv=widen, pair=True)
