@@ -360,7 +360,8 @@ bool
 obmc_strip_ok (const ObmcJob & j)
 {
   return j.xblen == 12 && j.yblen == 12 && j.xbsep == 8 && j.ybsep == 8 && j.xoff == 2 && j.yoff == 2 && j.ref_ps == 0
-      && (j.prec == 1 || j.prec == 2) && (!j.residual || j.res_bpp == 2) && j.nbx >= 2 && j.nby >= 2 && !j.out_s16;
+      && (j.prec == 1 || j.prec == 2) && (!j.residual || j.res_bpp == 2) && j.nbx >= 2 && j.nby >= 2 && !j.out_s16
+      && j.w1 == 1 && j.w2 == 1 && j.wbits == 1;        // (the default weights: the row kernels' fades, r06, are not its case)
 }
 
 // waves of one plane: strips of 15 block columns x segments of seg_rows block rows
