@@ -133,7 +133,7 @@ def test_combine_random_geometry(ctx):
     two-step result: random sizes (pictures smaller than the padded transform), filters, depths, sample sizes, block sets."""
     from test_gpu_combine import run_case as combine_case
     rng = np.random.default_rng(606 + SEED)
-    seps = [4, 8, 12, 16]
+    seps = [4, 8, 12, 16, 24, 32]       # (r06: 24 and 32 -- the two-segment rows' prediction-only kernels in front of the combine)
     for rnd in range(60 * SCALE):
         sep = seps[int(rng.integers(0, len(seps)))]
         blen = min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep)
