@@ -113,6 +113,29 @@ def test_obmc_random_geometry(ctx):
                  res_dtype=[np.int16, np.int32][rnd & 1], modes=tuple(modes))
 
 
+def test_obmc_random_rectangular_blocks(ctx):
+    """r06: block sets drawn independently for x and y (the syntax allows it, schroparams.c:140-205 checks each axis on its
+    own): the row kernels' caps count rows by yblen / ybsep and columns by xblen / xbsep."""
+    rng = np.random.default_rng(808 + SEED)
+    seps = [4, 8, 12, 16, 24, 32]
+
+    def draw():
+        sep = seps[int(rng.integers(0, len(seps)))]
+        return min(sep + 4 * int(rng.integers(0, sep // 4 + 1)), 2 * sep, 64), sep
+    for rnd in range(120 * SCALE):
+        (xblen, xbsep), (yblen, ybsep) = draw(), draw()
+        w, h = int(rng.integers(xblen, 260 * BIG)), int(rng.integers(yblen, 140 * BIG))
+        prec = int(rng.integers(0, 4))
+        chroma = [(0, 0), (1, 0), (1, 1)][int(rng.integers(0, 3))]
+        weights = [(1, 1, 1), (1, 1, 1), (1, 1, 1), (3, 5, 3), (2, 3, 1)][int(rng.integers(0, 5))]
+        try:
+            run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, int(rng.integers(1, 120)) << prec, seed=int(rng.integers(1, 1 << 16)),
+                     res_dtype=[np.int16, np.int32][rnd & 1], modes=tuple(rng.dirichlet([1, 2, 1, 2])), pair=bool(rnd % 3 == 0),
+                     yblen=yblen, ybsep=ybsep)
+        except AssertionError as e:
+            raise AssertionError("draw %d: %r" % (rnd, (w, h, xblen, xbsep, yblen, ybsep, prec, chroma, weights))) from e
+
+
 def test_obmc_random_geometry_pair_images(ctx):
     """r04: the same draws with the chroma planes' references as (U, V) pair images (one UV job per picture)."""
     rng = np.random.default_rng(505 + SEED)

@@ -24,10 +24,11 @@ def comp_size(w, h, k, chroma):
 
 
 def run_case(ctx, w, h, xblen, xbsep, prec, weights, chroma, mv_range, seed, res_dtype=np.int16,
-             modes=(0.05, 0.45, 0.15, 0.35), edit_mv=None, pair=False, only=None):
+             modes=(0.05, 0.45, 0.15, 0.35), edit_mv=None, pair=False, only=None, yblen=None, ybsep=None):
     """pair: the chroma references are (U, V) PAIR images (include/schro_hip.h, r04) -- sub-pel precisions
-    of horizontally subsampled chroma only; only: the components whose planes are rendered (default all)."""
-    P = synth.motion_params(w, h, xblen, xbsep, prec, weights, chroma)
+    of horizontally subsampled chroma only; only: the components whose planes are rendered (default all);
+    yblen, ybsep: blocks that are not square (default: as wide as high)."""
+    P = synth.motion_params(w, h, xblen, xbsep, prec, weights, chroma, yblen=yblen, ybsep=ybsep)
     mv = synth.motion_field(P["x_num_blocks"], P["y_num_blocks"], mv_range, seed, modes)
     if edit_mv is not None:
         edit_mv(mv, P)
