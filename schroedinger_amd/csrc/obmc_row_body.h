@@ -619,6 +619,11 @@ row_class (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s
   constexpr int kWaves = kRThreads / 64;
   const int k0 = (wave - *turn) & (kWaves - 1);
   *turn = (*turn + npass) & (kWaves - 1);
+  // scratch builds (experiments only): the waves inside their passes at a higher issue priority than the waves that set a
+  // tile up (-DSCHRO_ROW_PRIO_PASS=3), or the other way round (-DSCHRO_ROW_PRIO_PASS=0 -DSCHRO_ROW_PRIO_SETUP=3)
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_PRIO_PASS)
+  __builtin_amdgcn_s_setprio (SCHRO_ROW_PRIO_PASS);
+#endif
   if (exact) {                  // a DC value outside 0..255 somewhere in the tile: rare, kept out of the hot loop
     for (int k = k0; k < npass; k += kWaves)
       row_pass < ND, UV, CLS, true, RK, NS, WP > (job, pl, refs, s_item, s_hot, s_wp, acc, par, lo + 64 * k + lane, hi);
@@ -894,6 +899,9 @@ obmc_row_body (const ObmcJob * __restrict__ jobs, int njobs, const uint32_t * __
   __shared__ int s_nrim, s_wide;
 
   const uint64_t t_start = __builtin_amdgcn_s_memtime ();
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_PRIO_SETUP)
+  __builtin_amdgcn_s_setprio (SCHRO_ROW_PRIO_SETUP);
+#endif
   const int bid = xcd_tile_id (blockIdx.x, gridDim.x);
   // r05: a tile's record from the host's order table (plane_obmc.cpp: obmc_tile_order) -- four words: job << 16 | tile,
   // x_lo | y_lo << 16, first block column | first block row << 16, block columns | block rows << 8 | ceil (2^16 /
