@@ -223,6 +223,14 @@ template < int ND > struct RawRun {
   uint32_t sh;                  // where the run starts in the first one
 };
 
+// scratch builds (experiments only): the gather's cache policy -- -DSCHRO_ROW_GATHER_AUX=2 non-temporal, 16 agent scope (sc1:
+// every load misses the CU's own cache), 17 sc0 | sc1
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_GATHER_AUX)
+constexpr int kGatherAux = SCHRO_ROW_GATHER_AUX;
+#else
+constexpr int kGatherAux = 0;
+#endif
+
 template < int ND >
 __device__ __forceinline__ void
 issue_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, RawRun < ND > &r)
@@ -230,24 +238,24 @@ issue_run (__amdgpu_buffer_rsrc_t ref, uint32_t off, RawRun < ND > &r)
   const uint32_t al = off & ~3u;
   r.sh = off & 3u;
   if constexpr (ND == 1) {
-    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al, 0, 0);
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al, 0, kGatherAux);
     r.c[0] = q.x;
     r.c[1] = q.y;
   } else if constexpr (ND == 2) {
     typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
-    const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) al, 0, 0);
+    const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96 (ref, (int) al, 0, kGatherAux);
     r.c[0] = q.x;
     r.c[1] = q.y;
     r.c[2] = q.z;
   } else if constexpr (ND == 3) {
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, 0);
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, kGatherAux);
     r.c[0] = q.x;
     r.c[1] = q.y;
     r.c[2] = q.z;
     r.c[3] = q.w;
   } else {
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, 0);
-    const u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al + 16, 0, 0);       // (8 bytes: as fast as 4)
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128 (ref, (int) al, 0, kGatherAux);
+    const u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64 (ref, (int) al + 16, 0, kGatherAux);       // (8 bytes: as fast as 4)
     r.c[0] = q.x;
     r.c[1] = q.y;
     r.c[2] = q.z;
