@@ -167,10 +167,12 @@ obmc_row_form (const ObmcJob & j, bool uv, int *ns)
   if (j.w1 < 0 || j.w2 < 0 || j.wbits < 0 || j.wbits > 6 || j.w1 + j.w2 != (1 << j.wbits))
     return 0;
   // rows of up to 16 bytes are one run; 24-byte rows (the 24 / 16 and 24 / 12 block sets) two segments of 12, 32-byte rows
-  // (32 / 16: what the reference's encoder makes of 1080p and larger pictures by default, schroengine.c:411-453) two of 16
+  // (32 / 16: what the reference's encoder makes of 1080p and larger pictures by default, schroengine.c:411-453) two of 16;
+  // 20 and 28 bytes (block lengths the syntax allows and no preset uses, schroparams.c:255-270) two of 10 and 14 in the
+  // same kernels -- a segment's weights beyond its length are zero (obmc_row_weight_table)
   int seg_bytes = j.xblen << ps;
   if (seg_bytes > 16) {
-    if (seg_bytes != 24 && seg_bytes != 32)
+    if (seg_bytes > 32 || (seg_bytes & 3))      // (halves of whole pixel pairs: luma lengths are multiples of 4)
       return 0;
     *ns = 2;
     seg_bytes /= 2;
@@ -271,21 +273,31 @@ obmc_row_weight_table (const ObmcJob & j, int nd, int ns, bool uv, uint32_t * ou
     return w;
   };
   const int wcap = 32 * wrow;
+  // word `pr` of a row -> the block's pixel (uv) or pixel pair it weights, -1: none.  One segment: word after word.  Two
+  // segments: 2 nd words each (the kernels' seg_w), of which a segment of xblen / 2 pixels fills the first ones -- all of
+  // them for rows of 24 and 32 bytes, 10 of 12 / 14 of 16 bytes for rows of 20 / 28
+  const int seg_words = ns == 1 ? wrow : 2 * nd, seg_units = ns == 1 ? (uv ? j.xblen : j.xblen >> 1) : (uv ? j.xblen / 2 : j.xblen >> 2);
+  auto unit_of = [&](int pr) {
+    const int seg = pr / seg_words, q = pr - seg * seg_words;
+    return q < seg_units ? seg * seg_units + q : -1;
+  };
   for (int i = 0; i < wcap; i++) {
-    const int r = i / wrow, pr = i - r * wrow;
+    const int r = i / wrow, u = unit_of (i - r * wrow);
     uint32_t v = 0;
-    if (r < j.yblen) {
+    if (r < j.yblen && u >= 0) {
       if (uv)
-        v = pr < j.xblen ? (uint32_t) (wx[pr] * wy[r]) * 0x00010001u : 0u;
+        v = (uint32_t) (wx[u] * wy[r]) * 0x00010001u;
       else
-        v = pr < (j.xblen >> 1) ? (uint32_t) (wx[2 * pr] * wy[r]) | ((uint32_t) (wx[2 * pr + 1] * wy[r]) << 16) : 0u;
+        v = (uint32_t) (wx[2 * u] * wy[r]) | ((uint32_t) (wx[2 * u + 1] * wy[r]) << 16);
     }
     out[i] = v;
   }
   for (int t = 0; t < 4 * xf; t++) {
     const int type = t / xf, pr = t - type * xf;
-    out[wcap + t] = uv ? (uint32_t) folded (wx, pr, j.xblen, j.xbsep, j.xoff, type) * 0x00010001u
-        : (uint32_t) folded (wx, 2 * pr, j.xblen, j.xbsep, j.xoff, type) | ((uint32_t) folded (wx, 2 * pr + 1, j.xblen, j.xbsep, j.xoff, type) << 16);
+    // (one segment: xf = 8 words, pixels beyond the block weigh nothing -- folded () --; two: xf = the row's words)
+    const int u = ns == 1 ? pr : unit_of (pr);
+    out[wcap + t] = u < 0 ? 0u : uv ? (uint32_t) folded (wx, u, j.xblen, j.xbsep, j.xoff, type) * 0x00010001u
+        : (uint32_t) folded (wx, 2 * u, j.xblen, j.xbsep, j.xoff, type) | ((uint32_t) folded (wx, 2 * u + 1, j.xblen, j.xbsep, j.xoff, type) << 16);
   }
   const int fy = wcap + 4 * xf;
   for (int t = 0; t < 128; t++)

@@ -89,6 +89,17 @@ def test_default_weights(ctx, blk, prec, chroma):
         run_case(ctx, 96, 64, blk[0], blk[1], prec, (1, 1, 1), chroma, mv_range, seed)
 
 
+@pytest.mark.parametrize("chroma", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("prec", [0, 1, 2, 3])
+@pytest.mark.parametrize("blk", [(20, 12), (20, 16), (28, 16), (28, 24)])
+def test_block_lengths_between_the_presets(ctx, blk, prec, chroma):
+    """r06: rows of 20 and 28 bytes (lengths the syntax allows, schroparams.c:255-270, and no preset uses) as two segments of 10 / 14 in
+    the 12- / 16-byte segment kernels -- a segment's weights beyond its length are zero; with pair images their 10- / 14-sample chroma
+    rows the same way; a size with interior tiles and tile edges inside blocks."""
+    run_case(ctx, 96, 64, blk[0], blk[1], prec, (1, 1, 1), chroma, 80 << prec, 3)
+    run_case(ctx, 300, 150, blk[0], blk[1], prec, (1, 1, 1), chroma, 24 << prec, 5, pair=True, yblen=blk[0] - 4, ybsep=blk[1] - 4)
+
+
 @pytest.mark.parametrize("weights", [(3, 5, 3), (1, 2, 2), (2, 3, 1), (3, -1, 1), (5, 3, 2), (1, 3, 2), (7, 1, 3), (0, 1, 0), (21, 43, 6)])
 @pytest.mark.parametrize("prec", [0, 2, 3])
 def test_weighted_prediction(ctx, weights, prec):
