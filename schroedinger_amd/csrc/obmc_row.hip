@@ -50,10 +50,20 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_4_1, 6, 4, 1, false, kRTH, true, 1, 2)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_h2_uv_4, 6, 4, 1, true, kRTH, true, 1, 2)
 
 // r06, picture weights other than 1, 1 / 2 (fades: non-negative, adding up to 1 << bits): the 12-pixel-row and (U, V) forms
+// with a prediction-only twin each (the headline's block set) ...
 SCHRO_ROW_KERNEL (obmc_row_kernel_w_3_1, 6, 3, 1, false, kRTH, false, 1, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_w_uv_3, 6, 3, 1, true, kRTH, false, 1, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_w_p_3_1, 7, 3, 1, false, kRTH, true, 1, 1, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_w_p_uv_3, 7, 3, 1, true, kRTH, true, 1, 1, true)
+// ... and one kernel per other form (with the residual's registers: it serves the prediction-only launches of its form too)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_2_1, 5, 2, 1, false, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_4_1, 6, 4, 1, false, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_uv_2, 5, 2, 1, true, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_uv_4, 6, 4, 1, true, kRTH, false, 1, 1, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_h2_3_1, 6, 3, 1, false, kRTH, false, 1, 2, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_h2_uv_3, 6, 3, 1, true, kRTH, false, 1, 2, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_h2_4_1, 6, 4, 1, false, kRTH, false, 1, 2, true)
+SCHRO_ROW_KERNEL (obmc_row_kernel_w_h2_uv_4, 6, 4, 1, true, kRTH, false, 1, 2, true)
 
 }                               // namespace
 
@@ -63,9 +73,14 @@ RowKernel
 obmc_row_kernel_half (int nd, int np, int ns, bool nores, bool weighted)
 {
   if (weighted) {
-    if (ns != 1 || nd != 3)
-      return nullptr;
-    return np == 1 ? (nores ? obmc_row_kernel_w_p_3_1 : obmc_row_kernel_w_3_1) : np == 3 ? (nores ? obmc_row_kernel_w_p_uv_3 : obmc_row_kernel_w_uv_3) : nullptr;
+    if (np != 1 && np != 3)
+      return nullptr;           // (two planes per job: the planes run as jobs of their own)
+    const bool uv = np == 3;
+    if (ns == 2)
+      return nd == 3 ? (uv ? obmc_row_kernel_w_h2_uv_3 : obmc_row_kernel_w_h2_3_1) : nd == 4 ? (uv ? obmc_row_kernel_w_h2_uv_4 : obmc_row_kernel_w_h2_4_1) : nullptr;
+    if (nd == 3)
+      return uv ? (nores ? obmc_row_kernel_w_p_uv_3 : obmc_row_kernel_w_uv_3) : (nores ? obmc_row_kernel_w_p_3_1 : obmc_row_kernel_w_3_1);
+    return nd == 2 ? (uv ? obmc_row_kernel_w_uv_2 : obmc_row_kernel_w_2_1) : nd == 4 ? (uv ? obmc_row_kernel_w_uv_4 : obmc_row_kernel_w_4_1) : nullptr;
   }
   if (ns == 2) {
     if (nd == 3 && np == 1)

@@ -261,6 +261,10 @@ def test_picture_weights(ctx):
     for weights in ((3, 5, 3), (1, 2, 2), (0, 4, 2)):
         for prec in range(4):
             run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=prec, seed=5 + prec, weights=weights)
+    # (r06: a fade on the other block sets -- their weighted row kernels serve the prediction-only launches too)
+    for n, blk in enumerate(((8, 4), (16, 12), (24, 16), (16, 8), (24, 12), (32, 16), (20, 12), (28, 16))):
+        for prec in range(4):
+            run_case(ctx, 208, 112, 3, 0, chroma=[(1, 1), (0, 0), (1, 0)][n % 3], prec=prec, blk=blk, seed=9 + prec, weights=(3, 5, 3))
     with pytest.raises(sa.SchroHipError, match="prediction_only"):
         run_case(ctx, 208, 112, 3, 0, chroma=(1, 1), prec=2, seed=5, weights=(2, 3, 1))
 

@@ -401,10 +401,11 @@ def test_add_batch(ctx):
 
 def test_fades_on_every_row_form(ctx):
     """r06: normalised non-negative picture weights (a fade) through every form of the row kernels -- pair images and
-    plain planes, every precision, the 8 / 4, 16 / 12 and 24 / 16 block sets, edge-class blocks (vectors far outside), the
-    residual form and (tests/test_gpu_combine.py covers it too) prediction-only."""
+    plain planes, every precision, every preset and every default of the reference's encoder (8 / 4 ... 32 / 16) and the lengths
+    between them (20, 28), edge-class blocks (vectors far outside), the residual form and (tests/test_gpu_combine.py covers it
+    too) prediction-only."""
     for weights in ((3, 5, 3), (1, 3, 2), (63, 1, 6)):
-        for blk in ((8, 4), (12, 8), (16, 12), (24, 16)):
+        for blk in ((8, 4), (12, 8), (16, 12), (24, 16), (16, 8), (24, 12), (32, 16), (20, 12), (28, 16)):
             for prec in (0, 1, 2, 3):
                 for chroma in ((1, 1), (0, 0)):
                     run_case(ctx, 136, 72, blk[0], blk[1], prec, weights, chroma, 40 << prec, 17, pair=True)
