@@ -33,6 +33,11 @@ SCHRO_ROW_KERNEL (obmc_row_kernel_uv_4, 6, 4, 1, true)
 // 0.1706 -> 0.1674 ms per step.  The (U, V) kernel of 6-pixel rows too (r05, above).
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_2_1, 6, 2, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_3_1, 8, 3, 1, false, kRTH, true)
+#ifdef SCHRO_HIP_EXPERIMENTS
+// r06, measured and not kept (HISTORY 9): the items of a block laid out so that every four lanes are the four rows of ONE
+// 128-byte line (obmc_row_body.h: PAD) -- SCHRO_HIP_OBMC_PAD=1 in the experiments library
+SCHRO_ROW_KERNEL (obmc_row_kernel_p_3_1_pad, 8, 3, 1, false, kRTH, true, 1, 1, false, true)
+#endif
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_4_1, 7, 4, 1, false, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_2, 5, 2, 1, true, kRTH, true)
 SCHRO_ROW_KERNEL (obmc_row_kernel_p_uv_3, 8, 3, 1, true, kRTH, true)
@@ -93,6 +98,11 @@ obmc_row_kernel_half (int nd, int np, int ns, bool nores, bool weighted)
       return nores ? obmc_row_kernel_p_h2_uv_4 : obmc_row_kernel_h2_uv_4;
     return nullptr;
   }
+#ifdef SCHRO_HIP_EXPERIMENTS
+  static const bool pad = SCHRO_ENV ("SCHRO_HIP_OBMC_PAD") && atoi (SCHRO_ENV ("SCHRO_HIP_OBMC_PAD")) != 0;
+  if (pad && nores && nd == 3 && np == 1)
+    return obmc_row_kernel_p_3_1_pad;
+#endif
   if (nores)
     switch (nd * 10 + np) {
       case 23: return obmc_row_kernel_p_uv_2;

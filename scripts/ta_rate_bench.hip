@@ -28,9 +28,13 @@ load (const uint8_t * p, uint32_t * d)
 }
 
 template < int W >
-__global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, int LPG, int GS, int span, uint32_t * out, int iters)
+__global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, int LPG, int GS, int span, uint32_t * out, int iters, int perm)
 {
-  const int lane = threadIdx.x & 63;
+  // perm > 1 (r06): the addresses dealt to the lanes like cards to `perm` hands -- lanes that were neighbours are 64 / perm apart,
+  // so lanes that share a 64-byte sector are no longer adjacent: does the unit still fetch the sector once?
+  int lane = threadIdx.x & 63;
+  if (perm > 1)
+    lane = (lane % perm) * (64 / perm) + lane / perm;
   const uint8_t *base = buf + (lane / LPG) * GS + (lane % LPG) * S + M;
   uint32_t acc = 0;
   for (int it = 0; it < iters; it++) {
@@ -47,7 +51,7 @@ __global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, in
     out[0] = acc;
 }
 
-struct Pat { const char *name; int W, S, M, LPG, GS; };
+struct Pat { const char *name; int W, S, M, LPG, GS, perm; };
 
 int main ()
 {
@@ -81,6 +85,18 @@ int main ()
     { "x1 byte-aligned (+1), lanes 32 B apart", 4, 32, 1, 64, 0 },
     { "x1 aligned, lanes 32 B apart", 4, 32, 0, 64, 0 },
     { "x1 aligned, lanes 16 B apart", 4, 16, 0, 64, 0 },
+    // r06: which lanes may share a sector -- the same 64 addresses, neighbours dealt 2 / 4 / 16 / 32 lanes apart
+    { "x4 aligned, lanes 32 B apart, sector mates 2 lanes apart", 16, 32, 0, 64, 0, 2 },
+    { "x4 aligned, lanes 32 B apart, sector mates 4 lanes apart", 16, 32, 0, 64, 0, 4 },
+    { "x4 aligned, lanes 32 B apart, sector mates 16 lanes apart", 16, 32, 0, 64, 0, 16 },
+    { "x4 aligned, lanes 32 B apart, sector mates 32 lanes apart", 16, 32, 0, 64, 0, 32 },
+    { "x4 aligned, lanes 16 B apart, sector mates 4 lanes apart", 16, 16, 0, 64, 0, 4 },
+    { "x4 aligned, lanes 16 B apart, sector mates k, k + 32, k + 1, k + 33", 16, 16, 0, 64, 0, 32 },
+    { "x4 dword-aligned (+4), lanes 32 B apart, mates 32 apart", 16, 32, 4, 64, 0, 32 },
+    // rows of a plain plane: every lane its own sector (rows 4 KB apart would miss L1: 256 B apart here)
+    { "x4 dword-aligned (+4), lanes 256 B apart", 16, 256, 4, 64, 0, 0 },
+    { "x4 (+4), pairs 16 B apart in a sector, pairs 256 B apart", 16, 16, 4, 2, 256, 0 },
+    { "x4 (+4), the same pairs, mates 32 lanes apart", 16, 16, 4, 2, 256, 32 },
   };
   const int iters = 512;
   printf ("%d CUs; ns per load instruction per CU (all L1 hits), at 4 and 8 waves per SIMD\n", cus);
@@ -93,10 +109,10 @@ int main ()
       for (int rep = 0; rep < 2; rep++) {
         (void) hipEventRecord (e0);
         switch (p.W) {
-          case 4: k < 4 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters); break;
-          case 8: k < 8 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters); break;
-          case 12: k < 12 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters); break;
-          default: k < 16 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters); break;
+          case 4: k < 4 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
+          case 8: k < 8 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
+          case 12: k < 12 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
+          default: k < 16 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
         }
         (void) hipEventRecord (e1); (void) hipEventSynchronize (e1);
         (void) hipEventElapsedTime (&ms, e0, e1);

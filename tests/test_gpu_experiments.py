@@ -14,7 +14,8 @@ with the same oracle on the whole case matrix of its test file:
   * SCHRO_HIP_IIWT_CHAIN=1: every level of the register wavelet in one launch (r04, iiwt_reg.hip);
   * SCHRO_HIP_OBMC_STRIP=1: the 12 / 8 block set's luma planes by the strip kernel (r05, obmc_strip.hip: accumulator in
     registers, no LDS tile -- a third formulation of the same arithmetic; measured 2.5 x slower);
-  * SCHRO_HIP_UPSAMPLE_PERSIST=n: the upsample as n persistent workgroups per CU that prefetch the next tile (r06).
+  * SCHRO_HIP_UPSAMPLE_PERSIST=n: the upsample as n persistent workgroups per CU that prefetch the next tile (r06);
+  * SCHRO_HIP_OBMC_PAD=1: the prediction-only 12-pixel-row OBMC kernel with line-aligned quads of lanes (r06).
 """
 import os
 import subprocess
@@ -68,3 +69,11 @@ def test_persistent_prefetching_upsample():
     tiles and asks for the next tile's source before it filters and stores the current one -- the same planes."""
     out = run(["test_gpu_frameops.py", "test_gpu_stream.py"], env={"SCHRO_HIP_UPSAMPLE_PERSIST": "1"})
     assert "passed" in out
+
+
+def test_line_aligned_quads_in_the_obmc_passes():
+    """r06 (measured slower, HISTORY 9): the prediction-only 12-pixel-row kernel with every block's lanes laid out as whole
+    128-byte lines of its reference (masked lanes in front of and behind the window's rows) -- the same pictures."""
+    out = run(["test_gpu_combine.py", "test_gpu_stages.py", "test_gpu_fuzz.py"], env={"SCHRO_HIP_OBMC_PAD": "1"})
+    assert "passed" in out
+
