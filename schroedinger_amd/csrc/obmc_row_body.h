@@ -387,6 +387,70 @@ predict_row (const ObmcJob & job, __amdgpu_buffer_rsrc_t ref, uint32_t stride, c
   }
 }
 
+// scratch builds (experiments only, -DSCHRO_ROW_BOTH_AT_ONCE): predict_row's two halves apart -- every load of BOTH references of a
+// two-reference item goes out before either prediction is made (half the round trips of such a pass, twice the registers in flight)
+template < int ND > struct TapRuns {
+  RawRun < ND > qa, qb, qc, qd;
+  bool any_b, any_c;
+};
+
+template < int ND >
+__device__ __forceinline__ void
+issue_taps (__amdgpu_buffer_rsrc_t ref, uint32_t stride, const RowRef & rr, int row, TapRuns < ND > &t)
+{
+  const int dB = (int) rr.ydb >> 16;
+  const uint32_t y = (rr.ydb & 0xffffu) + (uint32_t) row;
+  const uint32_t offA = (uint32_t) rr.base + row_ofs (y, stride);
+  t.any_b = __ballot (dB != 0) != 0;
+  t.any_c = __ballot (rr.dci != 0) != 0;
+  issue_run < ND > (ref, offA, t.qa);
+  if (t.any_b)
+    issue_run < ND > (ref, offA + (uint32_t) dB, t.qb);
+  if (t.any_c) {
+    const uint32_t offC = (uint32_t) (rr.base + (rr.dci >> 16)) + row_ofs (y + ((uint32_t) rr.dci & 1u), stride);
+    issue_run < ND > (ref, offC, t.qc);
+    if (t.any_b)
+      issue_run < ND > (ref, offC + (uint32_t) dB, t.qd);
+  }
+}
+
+template < int ND >
+__device__ __forceinline__ void
+finish_taps (const TapRuns < ND > &t, uint32_t * out)
+{
+  uint32_t a[ND];
+  align_run < ND > (t.qa, a);
+  if (!t.any_c) {
+    if (!t.any_b) {
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        out[k] = a[k];
+    } else {
+      uint32_t b[ND];
+      align_run < ND > (t.qb, b);
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        out[k] = lerp1 (a[k], b[k]);
+    }
+  } else if (!t.any_b) {
+    uint32_t c[ND];
+    align_run < ND > (t.qc, c);
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+      out[k] = lerp1 (a[k], c[k]);
+  } else {
+    uint32_t b[ND], c[ND], d[ND];
+    align_run < ND > (t.qb, b);
+    align_run < ND > (t.qc, c);
+    align_run < ND > (t.qd, d);
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      const uint32_t h0 = lerp1 (a[k], b[k]), h1 = lerp1 (c[k], d[k]);
+      out[k] = __builtin_amdgcn_lerp (h0, h1, ~((a[k] ^ b[k]) | (c[k] ^ d[k])));
+    }
+  }
+}
+
 // r06, RK 0 -- a block row from a PLAIN plane (mv_precision 0: schroframe.c:2111-2122, one tap): rr.base = the window's
 // first column, rr.ydb = its first row; a window of this class lies inside the picture
 template < int ND >
@@ -545,9 +609,21 @@ row_pass (const ObmcJob & job, int pl, const RowRefs & refs, const uint16_t * s_
     }
   } else if constexpr (CLS == kRBoth) {
     uint32_t p1[ND];
+#if defined (SCHRO_HIP_EXPERIMENTS) && defined (SCHRO_ROW_BOTH_AT_ONCE)
+    if constexpr (RK == 1) {
+      TapRuns < ND > t0, t1;
+      issue_taps < ND > (refs.rsrc[0], refs.stride[0], hb.r[0], row, t0);
+      issue_taps < ND > (refs.rsrc[1], refs.stride[1], hb.r[1], row, t1);
+      __builtin_amdgcn_sched_barrier (0);       // (or the scheduler moves the second reference's loads behind the first one's use)
+      finish_taps < ND > (t0, p);
+      finish_taps < ND > (t1, p1);
+    } else
+#endif
+    {
     predict < ND, RK, false, UV > (job, refs.rsrc[0], refs.rsrc_b[0], refs.stride[0], hb.r[0], 0u, row, p);
     __builtin_amdgcn_sched_barrier (0); // one reference at a time: half the registers in flight (both at once: measured slower)
     predict < ND, RK, false, UV > (job, refs.rsrc[1], refs.rsrc_b[1], refs.stride[1], hb.r[1], 0u, row, p1);
+    }
     if (weighted) {             // (a uniform branch: the job's weights)
 #pragma unroll
       for (int k = 0; k < ND; k++)

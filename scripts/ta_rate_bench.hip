@@ -28,7 +28,7 @@ load (const uint8_t * p, uint32_t * d)
 }
 
 template < int W >
-__global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, int LPG, int GS, int span, uint32_t * out, int iters, int perm)
+__global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, int LPG, int GS, int span, uint32_t * out, int iters, int perm, int active)
 {
   // perm > 1 (r06): the addresses dealt to the lanes like cards to `perm` hands -- lanes that were neighbours are 64 / perm apart,
   // so lanes that share a 64-byte sector are no longer adjacent: does the unit still fetch the sector once?
@@ -39,9 +39,12 @@ __global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, in
   uint32_t acc = 0;
   for (int it = 0; it < iters; it++) {
     __attribute__ ((aligned (16))) uint32_t d[8][4];
+    // (active < 64, r06: only the first `active` lanes of the wave take part in the loads -- is a load's price its lanes' or its own?)
+    if (active < 0 ? ((threadIdx.x & 63) % (unsigned) -active) == 0 : (int) (threadIdx.x & 63) < active) {
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      load < W > (base + ((j * span) & 16383), d[j]);
+      for (int j = 0; j < 8; j++)
+        load < W > (base + ((j * span) & 16383), d[j]);
+    }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 8; j++)
@@ -51,7 +54,7 @@ __global__ __launch_bounds__ (256) void k (const uint8_t * buf, int S, int M, in
     out[0] = acc;
 }
 
-struct Pat { const char *name; int W, S, M, LPG, GS, perm; };
+struct Pat { const char *name; int W, S, M, LPG, GS, perm, active; };
 
 int main ()
 {
@@ -97,6 +100,14 @@ int main ()
     { "x4 dword-aligned (+4), lanes 256 B apart", 16, 256, 4, 64, 0, 0 },
     { "x4 (+4), pairs 16 B apart in a sector, pairs 256 B apart", 16, 16, 4, 2, 256, 0 },
     { "x4 (+4), the same pairs, mates 32 lanes apart", 16, 16, 4, 2, 256, 32 },
+    // r06: lanes switched off (EXEC) -- the first 32 / 16 / 4 lanes of every wave load, the rest do not
+    { "x4 (+4), lanes 256 B apart, 32 of 64 lanes", 16, 256, 4, 64, 0, 0, 32 },
+    { "x4 (+4), lanes 256 B apart, 16 of 64 lanes", 16, 256, 4, 64, 0, 0, 16 },
+    { "x4 (+4), lanes 256 B apart, 4 of 64 lanes", 16, 256, 4, 64, 0, 0, 4 },
+    { "x4 (+4), lanes 32 B apart, 32 of 64 lanes", 16, 32, 4, 64, 0, 0, 32 },
+    { "x4 (+4), lanes 32 B apart, 16 of 64 lanes", 16, 32, 4, 64, 0, 0, 16 },
+    { "x4 (+4), lanes 256 B apart, lanes 0, 4, 8 .. (one per quad)", 16, 256, 4, 64, 0, 0, -4 },
+    { "x4 (+4), lanes 256 B apart, lanes 0, 2, 4 .. (two per quad)", 16, 256, 4, 64, 0, 0, -2 },
   };
   const int iters = 512;
   printf ("%d CUs; ns per load instruction per CU (all L1 hits), at 4 and 8 waves per SIMD\n", cus);
@@ -109,10 +120,10 @@ int main ()
       for (int rep = 0; rep < 2; rep++) {
         (void) hipEventRecord (e0);
         switch (p.W) {
-          case 4: k < 4 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
-          case 8: k < 8 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
-          case 12: k < 12 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
-          default: k < 16 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm); break;
+          case 4: k < 4 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm, p.active ? p.active : 64); break;
+          case 8: k < 8 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm, p.active ? p.active : 64); break;
+          case 12: k < 12 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm, p.active ? p.active : 64); break;
+          default: k < 16 ><<< grid, 256 >>> (buf, p.S, p.M, p.LPG, p.GS, span, out, iters, p.perm, p.active ? p.active : 64); break;
         }
         (void) hipEventRecord (e1); (void) hipEventSynchronize (e1);
         (void) hipEventElapsedTime (&ms, e0, e1);
